@@ -1,0 +1,96 @@
+// common.h — shared device helpers for libcomat_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/comat_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+
+// runtime-dtype scalar access (dtype is wave-uniform)
+__device__ __forceinline__ float ld_dt(const void* p, int64_t i, int dt) {
+    return dt == COMAT_F32 ? ((const float*)p)[i] : bf16_to_f32(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ void st_dt(void* p, int64_t i, float v, int dt) {
+    if (dt == COMAT_F32) ((float*)p)[i] = v; else ((bf16_t*)p)[i] = f32_to_bf16(v);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); sbuf: >= 4 floats of LDS. All threads get the result.
+__device__ __forceinline__ float block_sum_256(float v, float* sbuf) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sbuf[0] + sbuf[1] + sbuf[2] + sbuf[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* sbuf) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sbuf[0], sbuf[1]), fmaxf(sbuf[2], sbuf[3]));
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+void comat_set_error(const char* fmt, ...);
+int comat_check_launch(const char* what);
+
+#define COMAT_REQUIRE(cond, ...)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            comat_set_error(__VA_ARGS__);             \
+            return COMAT_EINVAL;                      \
+        }                                             \
+    } while (0)
+
+static inline bool dtype_ok(int dt) { return dt == COMAT_F32 || dt == COMAT_BF16; }
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int grid_1d(int64_t n_items, int per_block, int cap = 4096) {
+    int64_t g = cdiv64(n_items, per_block);
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

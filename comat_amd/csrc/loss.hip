@@ -1,0 +1,250 @@
+// loss.hip — loss heads of the CoMat step: BLIP token cross-entropy, discriminator BCE head, and the
+// attribute-concentration gather over captured cross-attention maps.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- cross entropy: one block per token row -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                    float* __restrict__ logp, float* __restrict__ row_lse,
+                                                    float* __restrict__ loss_sum_cnt, int V, int64_t ld,
+                                                    int ignore_index, float ls) {
+    __shared__ float sbuf[4];
+    const int64_t t = blockIdx.x;
+    const T* z = logits + t * ld;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += NT) m = fmaxf(m, ldf<T>(z + v));
+    m = block_max_256(m, sbuf);
+    float se = 0.f, sz = 0.f;
+    for (int v = threadIdx.x; v < V; v += NT) {
+        const float zv = ldf<T>(z + v);
+        se += __expf(zv - m);
+        sz += zv;
+    }
+    se = block_sum_256(se, sbuf);
+    sz = block_sum_256(sz, sbuf);
+    if (threadIdx.x == 0) {
+        const float lse = m + __logf(se);
+        row_lse[t] = lse;
+        const int64_t y = labels[t];
+        if (y == ignore_index || y < 0 || y >= V) {
+            logp[t] = 0.f;
+        } else {
+            const float lp = ldf<T>(z + y) - lse;
+            logp[t] = lp;
+            const float loss = (1.0f - ls) * (-lp) + ls * (lse - sz / V);
+            atomicAdd(&loss_sum_cnt[0], loss);
+            atomicAdd(&loss_sum_cnt[1], 1.0f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                    const float* __restrict__ row_lse, T* __restrict__ dlogits, int V,
+                                                    int64_t ld, int ignore_index, float ls, float gscale) {
+    const int64_t t = blockIdx.x;
+    const T* z = logits + t * ld;
+    T* d = dlogits + t * ld;
+    const int64_t y = labels[t];
+    const bool valid = !(y == ignore_index || y < 0 || y >= V);
+    const float lse = row_lse[t];
+    const float sm = ls / V;
+    for (int v = threadIdx.x; v < V; v += NT) {
+        float g = 0.f;
+        if (valid) {
+            g = __expf(ldf<T>(z + v) - lse) - sm;
+            if (v == y) g -= (1.0f - ls);
+            g *= gscale;
+        }
+        stf<T>(d + v, g);
+    }
+}
+
+// ---- discriminator head: Linear(4,1) + BCE-with-logits, mean over pixels ---------------------------------------------
+__device__ __forceinline__ float bce_logits(float z, float t) {
+    return fmaxf(z, 0.f) - z * t + log1pf(__expf(-fabsf(z)));
+}
+
+__global__ __launch_bounds__(NT) void disc_head_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           const float* __restrict__ target, float* __restrict__ loss,
+                                                           int64_t P, int64_t pps, int dt) {
+    __shared__ float sbuf[4];
+    float acc = 0.f;
+    const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], bb = b[0];
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < P; p += (int64_t)gridDim.x * NT) {
+        const float z = ld_dt(x, 4 * p, dt) * w0 + ld_dt(x, 4 * p + 1, dt) * w1 + ld_dt(x, 4 * p + 2, dt) * w2 +
+                        ld_dt(x, 4 * p + 3, dt) * w3 + bb;
+        acc += bce_logits(z, target[p / pps]);
+    }
+    acc = block_sum_256(acc, sbuf);
+    if (threadIdx.x == 0) atomicAdd(loss, acc / (float)P);
+}
+
+__global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           const float* __restrict__ target, float gscale,
+                                                           void* __restrict__ dx, float* __restrict__ dw,
+                                                           float* __restrict__ db, int64_t P, int64_t pps, int dt) {
+    __shared__ float sbuf[4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
+    const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], bb = b[0];
+    const float gs = gscale / (float)P;
+    for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < P; p += (int64_t)gridDim.x * NT) {
+        const float x0 = ld_dt(x, 4 * p, dt), x1 = ld_dt(x, 4 * p + 1, dt), x2 = ld_dt(x, 4 * p + 2, dt),
+                    x3 = ld_dt(x, 4 * p + 3, dt);
+        const float z = x0 * w0 + x1 * w1 + x2 * w2 + x3 * w3 + bb;
+        const float dz = gs * (1.0f / (1.0f + __expf(-z)) - target[p / pps]);
+        if (dx) {
+            st_dt(dx, 4 * p, dz * w0, dt);
+            st_dt(dx, 4 * p + 1, dz * w1, dt);
+            st_dt(dx, 4 * p + 2, dz * w2, dt);
+            st_dt(dx, 4 * p + 3, dz * w3, dt);
+        }
+        a0 += dz * x0; a1 += dz * x1; a2 += dz * x2; a3 += dz * x3; ab += dz;
+    }
+    if (dw) {
+        a0 = block_sum_256(a0, sbuf);
+        a1 = block_sum_256(a1, sbuf);
+        a2 = block_sum_256(a2, sbuf);
+        a3 = block_sum_256(a3, sbuf);
+        ab = block_sum_256(ab, sbuf);
+        if (threadIdx.x == 0) {
+            atomicAdd(&dw[0], a0); atomicAdd(&dw[1], a1); atomicAdd(&dw[2], a2); atomicAdd(&dw[3], a3);
+            atomicAdd(&db[0], ab);
+        }
+    }
+}
+
+// ---- attribute-concentration gather over one captured map [heads, npix, L] ----------------------------------------
+constexpr int MAX_TOK = 32;
+
+__global__ __launch_bounds__(NT) void attnmap_fwd_kernel(const void* __restrict__ amap, const float* __restrict__ mask,
+                                                         const int32_t* __restrict__ tok_idx,
+                                                         const int32_t* __restrict__ tok_obj, float* __restrict__ num,
+                                                         float* __restrict__ den, float* __restrict__ avg, int heads,
+                                                         int npix, int L, int n_tok, int dt) {
+    __shared__ float sbuf[4];
+    const int h = blockIdx.y;
+    const int px = blockIdx.x * NT + threadIdx.x;
+    const float inv_h = 1.0f / heads;
+    for (int t = 0; t < n_tok; ++t) {
+        float v = 0.f, vm = 0.f;
+        if (px < npix) {
+            v = ld_dt(amap, ((int64_t)h * npix + px) * L + tok_idx[t], dt);
+            vm = v * mask[(int64_t)tok_obj[t] * npix + px];
+            atomicAdd(&avg[(int64_t)t * npix + px], v * inv_h);
+        }
+        const float sn = block_sum_256(vm, sbuf);
+        const float sd = block_sum_256(v, sbuf);
+        if (threadIdx.x == 0) {
+            atomicAdd(&num[h * n_tok + t], sn);
+            atomicAdd(&den[h * n_tok + t], sd);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void attnmap_bwd_kernel(const float* __restrict__ g_num,
+                                                         const float* __restrict__ g_den,
+                                                         const float* __restrict__ g_avg,
+                                                         const float* __restrict__ mask,
+                                                         const int32_t* __restrict__ tok_idx,
+                                                         const int32_t* __restrict__ tok_obj, void* __restrict__ damap,
+                                                         int heads, int npix, int L, int n_tok, int dt) {
+    const int h = blockIdx.y;
+    const int px = blockIdx.x * NT + threadIdx.x;
+    if (px >= npix) return;
+    const float inv_h = 1.0f / heads;
+    for (int t = 0; t < n_tok; ++t) {  // sequential per (h, px): repeated token columns accumulate safely
+        const int64_t i = ((int64_t)h * npix + px) * L + tok_idx[t];
+        float g = g_num[h * n_tok + t] * mask[(int64_t)tok_obj[t] * npix + px] + g_den[h * n_tok + t];
+        if (g_avg) g += g_avg[(int64_t)t * npix + px] * inv_h;
+        st_dt(damap, i, ld_dt(damap, i, dt) + g, dt);
+    }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int comat_cross_entropy_fwd(const void* logits, const int64_t* labels, float* logp, float* row_lse,
+                                       float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld, int32_t ignore_index,
+                                       float label_smoothing, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(logits && labels && logp && row_lse && loss_sum_cnt, "comat_cross_entropy_fwd: null pointer");
+    COMAT_REQUIRE(T > 0 && V > 0 && ld >= V && T < (1ll << 31) && dtype_ok(dtype), "comat_cross_entropy_fwd: bad args");
+    if (hipMemsetAsync(loss_sum_cnt, 0, 2 * sizeof(float), ST) != hipSuccess) {
+        comat_set_error("comat_cross_entropy_fwd: memset failed");
+        return COMAT_ELAUNCH;
+    }
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3((unsigned)T), dim3(NT), 0, ST, (const bf16_t*)logits, labels, logp,
+                           row_lse, loss_sum_cnt, V, ld, ignore_index, label_smoothing);
+    else
+        hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3((unsigned)T), dim3(NT), 0, ST, (const float*)logits, labels, logp,
+                           row_lse, loss_sum_cnt, V, ld, ignore_index, label_smoothing);
+    return comat_check_launch("comat_cross_entropy_fwd");
+}
+
+extern "C" int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse, void* dlogits,
+                                       int64_t T, int32_t V, int64_t ld, int32_t ignore_index, float label_smoothing,
+                                       float gscale, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(logits && labels && row_lse && dlogits, "comat_cross_entropy_bwd: null pointer");
+    COMAT_REQUIRE(T > 0 && V > 0 && ld >= V && T < (1ll << 31) && dtype_ok(dtype), "comat_cross_entropy_bwd: bad args");
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3((unsigned)T), dim3(NT), 0, ST, (const bf16_t*)logits, labels,
+                           row_lse, (bf16_t*)dlogits, V, ld, ignore_index, label_smoothing, gscale);
+    else
+        hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3((unsigned)T), dim3(NT), 0, ST, (const float*)logits, labels, row_lse,
+                           (float*)dlogits, V, ld, ignore_index, label_smoothing, gscale);
+    return comat_check_launch("comat_cross_entropy_bwd");
+}
+
+extern "C" int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss,
+                                   int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && w && b && target && loss, "comat_disc_head_fwd: null pointer");
+    COMAT_REQUIRE(P > 0 && pix_per_sample > 0 && dtype_ok(dtype), "comat_disc_head_fwd: bad args");
+    if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) {
+        comat_set_error("comat_disc_head_fwd: memset failed");
+        return COMAT_ELAUNCH;
+    }
+    hipLaunchKernelGGL(disc_head_fwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, loss, P,
+                       pix_per_sample, dtype);
+    return comat_check_launch("comat_disc_head_fwd");
+}
+
+extern "C" int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, float gscale,
+                                   void* dx, float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype,
+                                   void* stream) {
+    COMAT_REQUIRE(x && w && b && target, "comat_disc_head_bwd: null pointer");
+    COMAT_REQUIRE((dw == nullptr) == (db == nullptr), "comat_disc_head_bwd: dw and db must both be given or both NULL");
+    COMAT_REQUIRE(P > 0 && pix_per_sample > 0 && dtype_ok(dtype), "comat_disc_head_bwd: bad args");
+    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, gscale, dx, dw,
+                       db, P, pix_per_sample, dtype);
+    return comat_check_launch("comat_disc_head_bwd");
+}
+
+extern "C" int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx,
+                                        const int32_t* tok_obj, float* num, float* den, float* avg, int32_t heads,
+                                        int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(amap && mask && tok_idx && tok_obj && num && den && avg, "comat_attnmap_gather_fwd: null pointer");
+    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
+                  "comat_attnmap_gather_fwd: bad args");
+    hipLaunchKernelGGL(attnmap_fwd_kernel, dim3((npix + NT - 1) / NT, heads), dim3(NT), 0, ST, amap, mask, tok_idx,
+                       tok_obj, num, den, avg, heads, npix, L, n_tok, dtype);
+    return comat_check_launch("comat_attnmap_gather_fwd");
+}
+
+extern "C" int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float* g_avg, const float* mask,
+                                        const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,
+                                        int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(g_num && g_den && mask && tok_idx && tok_obj && damap, "comat_attnmap_gather_bwd: null pointer");
+    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
+                  "comat_attnmap_gather_bwd: bad args");
+    hipLaunchKernelGGL(attnmap_bwd_kernel, dim3((npix + NT - 1) / NT, heads), dim3(NT), 0, ST, g_num, g_den, g_avg, mask,
+                       tok_idx, tok_obj, damap, heads, npix, L, n_tok, dtype);
+    return comat_check_launch("comat_attnmap_gather_bwd");
+}

@@ -1,0 +1,302 @@
+// norm.hip — GroupNorm(+SiLU) and LayerNorm, forward and data-gradient, on channels-last token matrices.
+// HBM-bound kernels: every pass reads whole rows (C contiguous elements) so that a wave's accesses coalesce.
+// Statistics are accumulated per block in fp32 and combined across blocks in fp64 (hardware double atomics),
+// which keeps E[x^2]-E[x]^2 stable enough for the fp32 parity mode.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int GN_ROWS = 32;     // rows of one sample handled per block in the statistics passes
+constexpr int MAX_SLOTS = 16;   // channels per thread: C <= 256*16 = 4096
+constexpr int MAX_G = 64;
+
+// ---- GroupNorm forward: per-(b,g) sum / sum of squares -----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int64_t HW,
+                                                      int C, int G) {
+    __shared__ float s_sum[MAX_G], s_sq[MAX_G];
+    const int b = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS;
+    const int64_t r1 = (r0 + GN_ROWS < HW) ? r0 + GN_ROWS : HW;
+    const int cpg = C / G;
+    if (threadIdx.x < MAX_G) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    float a1[MAX_SLOTS], a2[MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) { a1[s] = 0.f; a2[s] = 0.f; }
+    const T* base = x + ((int64_t)b * HW) * C;
+    for (int64_t r = r0; r < r1; ++r) {
+        const T* row = base + r * C;
+#pragma unroll
+        for (int s = 0; s < MAX_SLOTS; ++s) {
+            const int c = threadIdx.x + s * NT;
+            if (c < C) {
+                const float v = ldf<T>(row + c);
+                a1[s] += v;
+                a2[s] += v * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        const int c = threadIdx.x + s * NT;
+        if (c < C) {
+            atomicAdd(&s_sum[c / cpg], a1[s]);
+            atomicAdd(&s_sq[c / cpg], a2[s]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_sum[threadIdx.x]);
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_sq[threadIdx.x]);
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int n, double count,
+                                   float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double mean = ws[2 * i] / count;
+        double var = ws[2 * i + 1] / count - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ stats,
+                                                      T* __restrict__ y, int64_t HW, int C, int G, int silu,
+                                                      int64_t total) {
+    const int cpg = C / G;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const int64_t b = i / ((int64_t)HW * C);
+        const float* st = stats + (b * G + c / cpg) * 2;
+        float v = (ldf<T>(x + i) - st[0]) * st[1] * gamma[c] + beta[c];
+        if (silu) v = silu_f(v);
+        stf<T>(y + i, v);
+    }
+}
+
+// ---- GroupNorm backward ------------------------------------------------------------------------------------------
+// gy = dy * silu'(yhat) (if fused), yhat = xhat*gamma + beta;  s1 = sum gy*gamma,  s2 = sum gy*gamma*xhat
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, double* __restrict__ ws,
+                                                          int64_t HW, int C, int G, int silu) {
+    __shared__ float s_1[MAX_G], s_2[MAX_G];
+    const int b = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS;
+    const int64_t r1 = (r0 + GN_ROWS < HW) ? r0 + GN_ROWS : HW;
+    const int cpg = C / G;
+    if (threadIdx.x < MAX_G) { s_1[threadIdx.x] = 0.f; s_2[threadIdx.x] = 0.f; }
+    __syncthreads();
+    float a1[MAX_SLOTS], a2[MAX_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) { a1[s] = 0.f; a2[s] = 0.f; }
+    const int64_t base = ((int64_t)b * HW) * C;
+    for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int s = 0; s < MAX_SLOTS; ++s) {
+            const int c = threadIdx.x + s * NT;
+            if (c < C) {
+                const float* st = stats + ((int64_t)b * G + c / cpg) * 2;
+                const int64_t i = base + r * C + c;
+                const float xh = (ldf<T>(x + i) - st[0]) * st[1];
+                float g = ldf<T>(dy + i);
+                if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
+                g *= gamma[c];
+                a1[s] += g;
+                a2[s] += g * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < MAX_SLOTS; ++s) {
+        const int c = threadIdx.x + s * NT;
+        if (c < C) {
+            atomicAdd(&s_1[c / cpg], a1[s]);
+            atomicAdd(&s_2[c / cpg], a2[s]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_1[threadIdx.x]);
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_2[threadIdx.x]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats,
+                                                          const double* __restrict__ ws, T* __restrict__ dx,
+                                                          int64_t HW, int C, int G, int silu, int64_t total) {
+    const int cpg = C / G;
+    const float inv_n = 1.0f / (float)((double)HW * cpg);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const int64_t b = i / ((int64_t)HW * C);
+        const int64_t sg = b * G + c / cpg;
+        const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
+        const float s1 = (float)ws[2 * sg], s2 = (float)ws[2 * sg + 1];
+        const float xh = (ldf<T>(x + i) - mean) * rstd;
+        float g = ldf<T>(dy + i);
+        if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
+        g *= gamma[c];
+        stf<T>(dx + i, rstd * (g - (s1 + xh * s2) * inv_n));
+    }
+}
+
+// ---- LayerNorm: one wave per row ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, T* __restrict__ y,
+                                                    float* __restrict__ stats, int64_t M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ldf<T>(xr + c);
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = ldf<T>(xr + c) - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    T* yr = y + row * C;
+    for (int c = lane; c < C; c += 64) stf<T>(yr + c, (ldf<T>(xr + c) - mean) * rstd * gamma[c] + beta[c]);
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                    const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                    T* __restrict__ dx, int64_t M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * C;
+    const T* gr = dy + row * C;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float g = ldf<T>(gr + c) * gamma[c];
+        const float xh = (ldf<T>(xr + c) - mean) * rstd;
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    T* dr = dx + row * C;
+    for (int c = lane; c < C; c += 64) {
+        const float g = ldf<T>(gr + c) * gamma[c];
+        const float xh = (ldf<T>(xr + c) - mean) * rstd;
+        stf<T>(dr + c, rstd * (g - s1 - xh * s2));
+    }
+}
+
+}  // namespace
+
+extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                   double* ws, int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t silu,
+                                   int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && gamma && beta && y && stats && ws, "comat_groupnorm_fwd: null pointer");
+    COMAT_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "comat_groupnorm_fwd: bad shape");
+    COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_fwd: C or G too large");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_fwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
+        comat_set_error("comat_groupnorm_fwd: memset failed");
+        return COMAT_ELAUNCH;
+    }
+    dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
+    const int64_t total = (int64_t)B * HW * C;
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, sg, dim3(NT), 0, st, (const bf16_t*)x, ws, HW, C, G);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<float>, sg, dim3(NT), 0, st, (const float*)x, ws, HW, C, G);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, (const double*)ws, stats,
+                       B * G, (double)HW * (C / G), eps);
+    const int grid = grid_1d(total, NT, 8192);
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)x, gamma, beta,
+                           (const float*)stats, (bf16_t*)y, HW, C, G, silu, total);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)x, gamma, beta,
+                           (const float*)stats, (float*)y, HW, C, G, silu, total);
+    return comat_check_launch("comat_groupnorm_fwd");
+}
+
+extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                                   const float* stats, void* dx, double* ws, int32_t B, int64_t HW, int32_t C,
+                                   int32_t G, int32_t silu, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(dy && x && gamma && beta && stats && dx && ws, "comat_groupnorm_bwd: null pointer");
+    COMAT_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "comat_groupnorm_bwd: bad shape");
+    COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_bwd: C or G too large");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_bwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
+        comat_set_error("comat_groupnorm_bwd: memset failed");
+        return COMAT_ELAUNCH;
+    }
+    dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
+    const int64_t total = (int64_t)B * HW * C;
+    const int grid = grid_1d(total, NT, 8192);
+    if (dtype == COMAT_BF16) {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, sg, dim3(NT), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+                           gamma, beta, stats, ws, HW, C, G, silu);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)dy,
+                           (const bf16_t*)x, gamma, beta, stats, (const double*)ws, (bf16_t*)dx, HW, C, G, silu,
+                           total);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, sg, dim3(NT), 0, st, (const float*)dy, (const float*)x, gamma,
+                           beta, stats, ws, HW, C, G, silu);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)dy,
+                           (const float*)x, gamma, beta, stats, (const double*)ws, (float*)dx, HW, C, G, silu, total);
+    }
+    return comat_check_launch("comat_groupnorm_bwd");
+}
+
+extern "C" int comat_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                   int64_t M, int32_t C, float eps, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && gamma && beta && y && stats, "comat_layernorm_fwd: null pointer");
+    COMAT_REQUIRE(M > 0 && C > 0, "comat_layernorm_fwd: bad shape");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_layernorm_fwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(M, NT / 64));
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
+                           stats, M, C, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(NT), 0, st, (const float*)x, gamma, beta, (float*)y,
+                           stats, M, C, eps);
+    return comat_check_launch("comat_layernorm_fwd");
+}
+
+extern "C" int comat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
+                                   int64_t M, int32_t C, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(dy && x && gamma && stats && dx, "comat_layernorm_bwd: null pointer");
+    COMAT_REQUIRE(M > 0 && C > 0, "comat_layernorm_bwd: bad shape");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_layernorm_bwd: bad dtype");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(M, NT / 64));
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma,
+                           stats, (bf16_t*)dx, M, C);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(NT), 0, st, (const float*)dy, (const float*)x, gamma,
+                           stats, (float*)dx, M, C);
+    return comat_check_launch("comat_layernorm_bwd");
+}

@@ -1,0 +1,55 @@
+// optim.hip — optimizer tail on the flat fp32 trainable buffers: global-norm reduction and fused clip + AdamW.
+// (training_script.py:661-664,692-694: clip_grad_norm_ then AdamW.step, one HBM pass over p/g/m/v.)
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float sbuf[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) acc += x[i] * x[i];
+    acc = block_sum_256(acc, sbuf);
+    if (threadIdx.x == 0) atomicAdd(out, acc);
+}
+
+__global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                   const float* __restrict__ gnorm_sq, float max_norm) {
+    float clip = 1.0f;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(*gnorm_sq) + 1e-6f);
+        clip = c < 1.0f ? c : 1.0f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        float pi = p[i] * (1.0f - lr * wd);
+        pi -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+        p[i] = pi;
+    }
+}
+
+}  // namespace
+
+extern "C" int comat_sumsq(const float* x, int64_t n, float* out, void* stream) {
+    COMAT_REQUIRE(x && out && n > 0, "comat_sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_1d(n, NT, 1024)), dim3(NT), 0, (hipStream_t)stream, x, n, out);
+    return comat_check_launch("comat_sumsq");
+}
+
+extern "C" int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                           float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm,
+                           void* stream) {
+    COMAT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "comat_adamw: bad args");
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_1d(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2s, gnorm_sq, max_norm);
+    return comat_check_launch("comat_adamw");
+}

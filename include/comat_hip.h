@@ -1,0 +1,223 @@
+/*
+ * comat_hip.h — C ABI of libcomat_hip.so: the MI355X (gfx950) kernels behind the CoMat training step.
+ *
+ * The reference (CaraJ7/CoMat) has no FFI: its "operator API" for the hot path is the set of Python call
+ * conventions listed in SURVEY.md §8(b).  Every entry point below replaces the third-party kernel class that the
+ * cited reference line launches (through diffusers / transformers / torch).  Conventions:
+ *   - plain C types only; device pointers are raw `void*`; the caller (PyTorch-ROCm) owns every buffer,
+ *     including workspaces; the library never allocates, frees or keeps state between calls;
+ *   - all work is enqueued on the caller's `hipStream_t` (passed as void*), no internal synchronisation;
+ *   - return 0 on success, a negative COMAT_E* code otherwise; `comat_last_error()` gives a thread-local message;
+ *   - activations are channels-last token matrices: an image tensor (B,H,W,C) is the row-major matrix
+ *     [B*H*W, C]; attention maps are [B, heads, N, L] row-major (== the reference's (B*h, N, 77) layout,
+ *     attn_utils/tc_attn_utils.py:198-217);
+ *   - dtype codes: COMAT_F32 (fp32 storage, exact-f32 MFMA 32x32x2) and COMAT_BF16 (bf16 storage,
+ *     MFMA 32x32x16, fp32 accumulate).  Biases, norm statistics, losses and optimizer state are always fp32.
+ */
+#ifndef COMAT_HIP_H
+#define COMAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMAT_ABI_VERSION 1
+
+enum { COMAT_F32 = 0, COMAT_BF16 = 1 };
+enum { COMAT_OK = 0, COMAT_EINVAL = -1, COMAT_ELAUNCH = -2, COMAT_EUNSUPPORTED = -3 };
+enum { COMAT_ACT_NONE = 0, COMAT_ACT_SILU = 1, COMAT_ACT_GELU = 2 };
+
+int comat_abi_version(void);
+const char* comat_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM:  C = act(alpha * op(A) op(B)^T + bias + bias2) + beta * R         (fp32 accumulate on MFMA)
+ *   transA == 0: A is [M,K] row-major (lda = row stride);  transA == 1: A is stored [K,M] (lda = stride of k).
+ *   transB == 0: B is [N,K] row-major (a torch Linear weight);  transB == 1: B is stored [K,N].
+ *   Two-level batch (batch1 x batch2) with independent element strides lets attention heads be addressed in
+ *   place inside [tokens, heads*dim] matrices.
+ * Replaces: every nn.Linear / 1x1 conv / torch.bmm on the path — UNet to_q/to_k/to_v/to_out + LoRA
+ * (training_utils/pipeline.py:94-115), proj_in/out, GEGLU FFN, time embedding; the patched attention's
+ * QK^T and `torch.bmm(attention_probs, value)` (attn_utils/tc_attn_utils.py:126-146); BLIP ViT/decoder linears
+ * (concept_mat_utils/caption_blip.py:57); the VAE attention (TrainableSDPipeline.py:220).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const float* bias;   /* [N] fp32 or NULL */
+    const float* bias2;  /* [M / rows_per_bias2, N] fp32 or NULL (per-row-group bias, e.g. time embedding) */
+    const void* R;       /* residual, same shape as C, or NULL.  May alias C (accumulate). */
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ldr;
+    int64_t batch1, batch2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
+    int64_t rows_per_bias2;
+    float alpha, beta;
+    int32_t transA, transB;
+    int32_t act;
+    int32_t in_dtype;   /* dtype of A and B */
+    int32_t out_dtype;  /* dtype of C */
+    int32_t r_dtype;    /* dtype of R */
+} comat_gemm_params;
+int comat_gemm(const comat_gemm_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * conv2d as implicit GEMM on channels-last tensors.
+ *   X: [B, Hin, Win, Cin], W: [Cout, KH, KW, Cin] (K-contiguous), Y: [B, Hout, Wout, Cout].
+ *   mode 0 (forward gather):    src = dst*stride + k - pad   (in the `ups`-times nearest-upsampled input)
+ *   mode 1 (transposed gather): src = (dst + k - pad)/stride, taken only when divisible  (dgrad of a strided conv)
+ *   The data-gradient of a stride-1 conv is mode 0 with the tap-flipped, channel-transposed weight.
+ *   Epilogue as in comat_gemm (bias [Cout], bias2 [B, Cout] = per-sample time-embedding add, residual R).
+ * Replaces: cuDNN conv2d of ResnetBlock2D / Downsample2D / Upsample2D / conv_in / conv_out in the UNet call
+ * (TrainableSDPipeline.py:144-150), the discriminator UNet (training_utils/gan_sdxl.py:72-88,112-131) and the
+ * VAE decoder (TrainableSDPipeline.py:220).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* X; const void* W; void* Y;
+    const float* bias; const float* bias2; const void* R;
+    int32_t B, Hin, Win, Cin, Hout, Wout, Cout;
+    int32_t KH, KW, stride, pad, mode, ups;
+    float alpha, beta;
+    int32_t act;
+    int32_t in_dtype, out_dtype, r_dtype;
+} comat_conv_params;
+int comat_conv2d(const comat_conv_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional fused SiLU) on [B, HW, C] channels-last, G groups.  stats: [B, G, 2] fp32 (mean, rstd),
+ * written by fwd and read by bwd.  ws: caller workspace of B*G*2 doubles (zeroed by the call).
+ * gamma/beta fp32 [C].  bwd returns dx only (norm affine parameters are frozen: training_utils/pipeline.py:68-70).
+ * Replaces: torch GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / VAE decoder.
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws,
+                        int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype,
+                        void* stream);
+int comat_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
+                        void* dx, double* ws, int32_t B, int64_t HW, int32_t C, int32_t G, int32_t silu,
+                        int32_t dtype, void* stream);
+
+/* LayerNorm over the last dim of [M, C]; stats [M, 2] fp32 (mean, rstd). */
+int comat_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t M,
+                        int32_t C, float eps, int32_t dtype, void* stream);
+int comat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int64_t M,
+                        int32_t C, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Row softmax of attention scores.  S: [rows, cols] (s_dtype), P: [rows, cols] (p_dtype).
+ *   causal != 0: row r attends keys j <= (r % q_len) + causal_offset.   key_mask: int8 [rows / rows_per_mask, cols]
+ *   (1 = keep) or NULL.  P is the materialised probability map that the attention-store clones
+ *   (attn_utils/tc_attn_utils.py:60-68): written once, coalesced, never copied.
+ * bwd: dS = scale * P * (dP - sum_j dP*P).
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_softmax_fwd(const void* S, void* P, int64_t rows, int32_t cols, int32_t q_len, int32_t causal,
+                      int32_t causal_offset, const int8_t* key_mask, int64_t rows_per_mask, int32_t s_dtype,
+                      int32_t p_dtype, void* stream);
+int comat_softmax_bwd(const void* P, const void* dP, void* dS, int64_t rows, int32_t cols, float scale,
+                      int32_t p_dtype, int32_t dp_dtype, int32_t ds_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Elementwise family (HBM-bound, 16-byte vectorised).
+ * ---------------------------------------------------------------------------------------------------------- */
+enum { COMAT_UN_COPY = 0, COMAT_UN_SILU = 1, COMAT_UN_GELU = 2, COMAT_UN_AFFINE = 3 };
+/* y = f(x) (AFFINE: p0*x + p1); dtype conversion allowed (COPY == cast). */
+int comat_unary(int32_t op, const void* x, void* y, int64_t n, float p0, float p1, int32_t x_dtype, int32_t y_dtype,
+                void* stream);
+/* dx = dy * f'(x) */
+int comat_unary_bwd(int32_t op, const void* dy, const void* x, void* dx, int64_t n, int32_t dtype, void* stream);
+/* out = a*x + b*y (y may be NULL) */
+int comat_axpby(float a, const void* x, float b, const void* y, void* out, int64_t n, int32_t x_dtype,
+                int32_t y_dtype, int32_t out_dtype, void* stream);
+/* GEGLU: x [M, 2D] -> y[m, d] = x[m, d] * gelu(x[m, D + d]) */
+int comat_geglu_fwd(const void* x, void* y, int64_t M, int32_t D, int32_t dtype, void* stream);
+int comat_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int32_t D, int32_t dtype, void* stream);
+/* strided 2-D copy (channel concat / split): dst[r, c] = src[r, c] for r < rows, c < cols */
+int comat_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                 int32_t src_dtype, int32_t dst_dtype, void* stream);
+/* out[r, c] = x[r, c] + v[c] broadcast over rows (positional embeddings) */
+int comat_add_rowvec(const void* x, const void* v, void* out, int64_t rows, int64_t cols, int32_t dtype,
+                     void* stream);
+/* 2x2 sum pooling [B, 2H, 2W, C] -> [B, H, W, C]: adjoint of the nearest-2x upsample fused in comat_conv2d. */
+int comat_sumpool2x2(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* NCHW <-> NHWC permutation of small boundary tensors (latents, images). to_nhwc != 0: [B,C,H,W] -> [B,H,W,C]. */
+int comat_permute_nchw_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t to_nhwc,
+                            int32_t x_dtype, int32_t y_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Classifier-free guidance + DDPM ancestral step, fused (fp32, tiny):
+ *   eps = e_u + s (e_c - e_u);   x_prev = cx * x + ce * eps + sigma * z
+ * with cx, ce the closed-form coefficients of DDPMScheduler.step.  eps2 holds [uncond; cond].
+ * Replaces TrainableSDPipeline.py:155-157,166.  bwd: dx = cx*g, de_u = ce*(1-s)*g, de_c = ce*s*g.
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_cfg_ddpm_fwd(const float* x, const void* eps2, const float* z, float* x_prev, int64_t n, float s,
+                       float cx, float ce, float sigma, int32_t eps_dtype, void* stream);
+int comat_cfg_ddpm_bwd(const float* g, float* dx, void* deps2, int64_t n, float s, float cx, float ce,
+                       int32_t eps_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Image path between VAE and BLIP (training_script.py:606-611, concept_mat_utils/caption_blip.py:33-36,45):
+ * separable resampling with precomputed sparse taps (crop + antialiased bicubic + per-channel affine in one
+ * pass); the same kernel with transposed tap tables is its adjoint.
+ *   in: [B, Hin, Win, C], out: [B, Hout, Wout, C];  ystart[Hout], ywt[Hout, KT], xstart[Wout], xwt[Wout, KT];
+ *   out = scale[c] * sum_ty sum_tx ywt*xwt*in[ystart+ty, xstart+tx, c] + shift[c]
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_resample2d(const void* in, void* out, int32_t B, int32_t Hin, int32_t Win, int32_t Hout, int32_t Wout,
+                     int32_t C, const int32_t* ystart, const float* ywt, const int32_t* xstart, const float* xwt,
+                     int32_t KT, const float* scale, const float* shift, int32_t in_dtype, int32_t out_dtype,
+                     void* stream);
+/* ViT patch embedding gather: img [B, H, W, C] -> patches [B*(H/P)*(W/P), P*P*C] (fwd) and its adjoint (bwd). */
+int comat_patchify(const void* img, void* patches, int32_t B, int32_t H, int32_t W, int32_t C, int32_t P,
+                   int32_t inverse, int32_t dtype, void* stream);
+/* rows of a table: out[i, :] = table[ids[i], :] */
+int comat_embedding(const int64_t* ids, const void* table, void* out, int64_t n, int32_t dim, int64_t vocab,
+                    int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Losses.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* Token cross-entropy with ignore_index and label smoothing (BLIP decoder LM loss, caption_blip.py:51-58).
+ * logits [T, V]; labels int64 [T] (already shifted by the caller); logp[T] = log-prob of the label ("token-level
+ * concept score", 0 where ignored); loss_sum_cnt[2] = {sum of per-token losses, number of valid tokens}. */
+int comat_cross_entropy_fwd(const void* logits, const int64_t* labels, float* logp, float* row_lse,
+                            float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld, int32_t ignore_index,
+                            float label_smoothing, int32_t dtype, void* stream);
+/* dlogits = gscale * (softmax - smoothed one-hot) on valid rows, 0 elsewhere; gscale = upstream / n_valid. */
+int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse, void* dlogits,
+                            int64_t T, int32_t V, int64_t ld, int32_t ignore_index, float label_smoothing,
+                            float gscale, int32_t dtype, void* stream);
+/* Discriminator head (training_utils/gan_sdxl.py:32-35,83-88,124-131): pred = x[p, 0:4] . w + b per pixel,
+ * BCE-with-logits against target[p / pix_per_sample], mean over pixels.  x: [P, 4] channels-last UNet output.
+ * fwd writes loss[0]; bwd writes dx [P,4] and accumulates dw[4], db[1] (fp32, caller zeroes). */
+int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss, int64_t P,
+                        int64_t pix_per_sample, int32_t dtype, void* stream);
+int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, float gscale, void* dx,
+                        float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream);
+
+/* Attribute-concentration losses on one captured cross-attention map (attn_utils/tc_loss_utils.py:104-167).
+ *   amap: [heads, res*res, L] probabilities of ONE sample and ONE layer; mask: [n_obj, res*res] fp32 {0,1};
+ *   tok_idx: int32 [n_tok] token positions, tok_obj: int32 [n_tok] owning object.
+ * Stage 1 (HBM-bound strided gather, one pass over the map):
+ *   num[h, t] = sum_px A[h,px,tok_t] * mask[obj_t, px];  den[h, t] = sum_px A[h,px,tok_t];
+ *   avg[t, px] += (1/heads) * A[h,px,tok_t]   (head-mean map per token, accumulated across layers by the caller)
+ * The (tiny) remaining reductions are host-side torch on [heads, n_tok] and [n_tok, res*res] tensors.
+ * bwd: dA[h,px,tok_t] += g_num[h,t]*mask + g_den[h,t] + g_avg[t,px]/heads   (dA zero elsewhere; caller zeroes). */
+int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx, const int32_t* tok_obj,
+                             float* num, float* den, float* avg, int32_t heads, int32_t npix, int32_t L,
+                             int32_t n_tok, int32_t dtype, void* stream);
+int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float* g_avg, const float* mask,
+                             const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,
+                             int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer tail on the flat fp32 LoRA buffers (training_script.py:661-664,692-694).
+ * ---------------------------------------------------------------------------------------------------------- */
+/* out[0] += sum(x^2)  (caller zeroes out) */
+int comat_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)). */
+int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMAT_HIP_H */
