@@ -1,0 +1,307 @@
+"""ctypes binding of libcomat_hip.so (the C ABI declared in include/comat_hip.h).
+
+This module is the ONLY place where device pointers leave PyTorch.  It takes torch tensors that live in HBM,
+passes raw pointers + sizes + the current HIP stream to the C entry points, and raises on any error.  There is no
+CPU path here: if the shared library is missing or a tensor is not on the GPU, it fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+UN_COPY, UN_SILU, UN_GELU, UN_AFFINE = 0, 1, 2, 3
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcomat_hip.so")
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("bias", C.c_void_p), ("bias2", C.c_void_p), ("R", C.c_void_p),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64),
+        ("batch1", C.c_int64), ("batch2", C.c_int64),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+        ("sC1", C.c_int64), ("sC2", C.c_int64), ("sR1", C.c_int64), ("sR2", C.c_int64),
+        ("rows_per_bias2", C.c_int64),
+        ("alpha", C.c_float), ("beta", C.c_float),
+        ("transA", C.c_int32), ("transB", C.c_int32), ("act", C.c_int32),
+        ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
+    ]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p),
+        ("bias", C.c_void_p), ("bias2", C.c_void_p), ("R", C.c_void_p),
+        ("B", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Cin", C.c_int32),
+        ("Hout", C.c_int32), ("Wout", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("mode", C.c_int32), ("ups", C.c_int32),
+        ("alpha", C.c_float), ("beta", C.c_float),
+        ("act", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
+    ]
+
+
+_vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int unless noted); mirrors include/comat_hip.h one to one.
+SIGNATURES = {
+    "comat_gemm": [C.POINTER(GemmParams), _vp],
+    "comat_conv2d": [C.POINTER(ConvParams), _vp],
+    "comat_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp],
+    "comat_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp],
+    "comat_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f, _i32, _vp],
+    "comat_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_softmax_fwd": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp],
+    "comat_softmax_bwd": [_vp, _vp, _vp, _i64, _i32, _f, _i32, _i32, _i32, _vp],
+    "comat_unary": [_i32, _vp, _vp, _i64, _f, _f, _i32, _i32, _vp],
+    "comat_unary_bwd": [_i32, _vp, _vp, _vp, _i64, _i32, _vp],
+    "comat_axpby": [_f, _vp, _f, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "comat_geglu_fwd": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_geglu_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_copy2d": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
+    "comat_add_rowvec": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "comat_sumpool2x2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_permute_nchw_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_cfg_ddpm_fwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i32, _vp],
+    "comat_cfg_ddpm_bwd": [_vp, _vp, _vp, _i64, _f, _f, _f, _i32, _vp],
+    "comat_resample2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
+                         _i32, _vp],
+    "comat_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_embedding": [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
+    "comat_cross_entropy_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _i32, _vp],
+    "comat_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _f, _i32, _vp],
+    "comat_disc_head_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "comat_disc_head_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_attnmap_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_sumsq": [_vp, _i64, _vp, _vp],
+    "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _f, _vp],
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Load libcomat_hip.so (idempotent).  Raises if the library was not built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"libcomat_hip.so not found at {p}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(comat_amd has no CPU fallback)")
+    lib = C.CDLL(p)
+    lib.comat_abi_version.restype = C.c_int
+    lib.comat_last_error.restype = C.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.comat_abi_version() != 1:
+        raise RuntimeError("libcomat_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        msg = _lib.comat_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (rc={rc}): {msg}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"comat_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+
+
+def _ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("comat_amd HIP kernels need tensors resident in HBM (cuda device); got a CPU tensor")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipKernels:
+    """Thin, 1:1 wrappers over the C ABI.  Every method enqueues on the current torch HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        load_library()
+
+    # ---- contraction ---------------------------------------------------------------------------------------
+    def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE):
+        p = GemmParams()
+        p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(Cout)
+        p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
+        if bias is not None:
+            assert bias.dtype == torch.float32
+        if bias2 is not None:
+            assert bias2.dtype == torch.float32
+        p.M, p.N, p.K = M, N, K
+        p.lda, p.ldb, p.ldc, p.ldr = lda, ldb, ldc, ldr
+        p.batch1, p.batch2 = batch
+        p.sA1, p.sA2 = sA
+        p.sB1, p.sB2 = sB
+        p.sC1, p.sC2 = sC
+        p.sR1, p.sR2 = sR
+        p.rows_per_bias2 = rows_per_bias2
+        p.alpha, p.beta = alpha, beta
+        p.transA, p.transB, p.act = int(transA), int(transB), act
+        assert A.dtype == B.dtype
+        p.in_dtype, p.out_dtype = dt(A), dt(Cout)
+        p.r_dtype = dt(R) if R is not None else 0
+        _check(_lib.comat_gemm(C.byref(p), _stream()), "comat_gemm")
+
+    def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):
+        p = ConvParams()
+        p.X, p.W, p.Y = _ptr(X), _ptr(W), _ptr(Y)
+        p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
+        if bias is not None:
+            assert bias.dtype == torch.float32
+        if bias2 is not None:
+            assert bias2.dtype == torch.float32
+        p.B, p.Hin, p.Win, p.Cin, p.Hout, p.Wout, p.Cout = B, Hin, Win, Cin, Hout, Wout, Cout
+        p.KH, p.KW, p.stride, p.pad, p.mode, p.ups = KH, KW, stride, pad, mode, ups
+        p.alpha, p.beta, p.act = alpha, beta, act
+        assert X.dtype == W.dtype
+        p.in_dtype, p.out_dtype = dt(X), dt(Y)
+        p.r_dtype = dt(R) if R is not None else 0
+        _check(_lib.comat_conv2d(C.byref(p), _stream()), "comat_conv2d")
+
+    # ---- normalisation -------------------------------------------------------------------------------------
+    def groupnorm_fwd(self, x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu):
+        _check(_lib.comat_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), B, HW, Cc,
+                                        G, eps, int(silu), dt(x), _stream()), "comat_groupnorm_fwd")
+
+    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu):
+        _check(_lib.comat_groupnorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dx), _ptr(ws),
+                                        B, HW, Cc, G, int(silu), dt(x), _stream()), "comat_groupnorm_bwd")
+
+    def layernorm_fwd(self, x, gamma, beta, y, stats, M, Cc, eps):
+        _check(_lib.comat_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, Cc, eps, dt(x),
+                                        _stream()), "comat_layernorm_fwd")
+
+    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc):
+        _check(_lib.comat_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(stats), _ptr(dx), M, Cc, dt(x),
+                                        _stream()), "comat_layernorm_bwd")
+
+    # ---- softmax -------------------------------------------------------------------------------------------
+    def softmax_fwd(self, S, P, rows, cols, q_len=0, causal=False, causal_offset=0, key_mask=None, rows_per_mask=0):
+        _check(_lib.comat_softmax_fwd(_ptr(S), _ptr(P), rows, cols, q_len, int(causal), causal_offset,
+                                      _ptr(key_mask), rows_per_mask, dt(S), dt(P), _stream()), "comat_softmax_fwd")
+
+    def softmax_bwd(self, P, dP, dS, rows, cols, scale):
+        _check(_lib.comat_softmax_bwd(_ptr(P), _ptr(dP), _ptr(dS), rows, cols, scale, dt(P), dt(dP), dt(dS),
+                                      _stream()), "comat_softmax_bwd")
+
+    # ---- elementwise ---------------------------------------------------------------------------------------
+    def unary(self, op, x, y, n, p0=0.0, p1=0.0):
+        _check(_lib.comat_unary(op, _ptr(x), _ptr(y), n, p0, p1, dt(x), dt(y), _stream()), "comat_unary")
+
+    def unary_bwd(self, op, dy, x, dx, n):
+        _check(_lib.comat_unary_bwd(op, _ptr(dy), _ptr(x), _ptr(dx), n, dt(x), _stream()), "comat_unary_bwd")
+
+    def axpby(self, a, x, b, y, out, n):
+        _check(_lib.comat_axpby(a, _ptr(x), b, _ptr(y), _ptr(out), n, dt(x), dt(y) if y is not None else 0, dt(out),
+                                _stream()), "comat_axpby")
+
+    def geglu_fwd(self, x, y, M, D):
+        _check(_lib.comat_geglu_fwd(_ptr(x), _ptr(y), M, D, dt(x), _stream()), "comat_geglu_fwd")
+
+    def geglu_bwd(self, dy, x, dx, M, D):
+        _check(_lib.comat_geglu_bwd(_ptr(dy), _ptr(x), _ptr(dx), M, D, dt(x), _stream()), "comat_geglu_bwd")
+
+    def copy2d(self, src, ld_src, dst, ld_dst, rows, cols):
+        _check(_lib.comat_copy2d(_ptr(src), ld_src, _ptr(dst), ld_dst, rows, cols, dt(src), dt(dst), _stream()),
+               "comat_copy2d")
+
+    def add_rowvec(self, x, v, out, rows, cols):
+        _check(_lib.comat_add_rowvec(_ptr(x), _ptr(v), _ptr(out), rows, cols, dt(x), _stream()), "comat_add_rowvec")
+
+    def sumpool2x2(self, x, y, B, H, W, Cc):
+        _check(_lib.comat_sumpool2x2(_ptr(x), _ptr(y), B, H, W, Cc, dt(x), _stream()), "comat_sumpool2x2")
+
+    def permute_nchw_nhwc(self, x, y, B, Cc, H, W, to_nhwc):
+        _check(_lib.comat_permute_nchw_nhwc(_ptr(x), _ptr(y), B, Cc, H, W, int(to_nhwc), dt(x), dt(y), _stream()),
+               "comat_permute_nchw_nhwc")
+
+    def cfg_ddpm_fwd(self, x, eps2, z, x_prev, n, s, cx, ce, sigma):
+        _check(_lib.comat_cfg_ddpm_fwd(_ptr(x), _ptr(eps2), _ptr(z), _ptr(x_prev), n, s, cx, ce, sigma, dt(eps2),
+                                       _stream()), "comat_cfg_ddpm_fwd")
+
+    def cfg_ddpm_bwd(self, g, dx, deps2, n, s, cx, ce):
+        _check(_lib.comat_cfg_ddpm_bwd(_ptr(g), _ptr(dx), _ptr(deps2), n, s, cx, ce, dt(deps2), _stream()),
+               "comat_cfg_ddpm_bwd")
+
+    # ---- image path ----------------------------------------------------------------------------------------
+    def resample2d(self, src, out, B, Hin, Win, Hout, Wout, Cc, ystart, ywt, xstart, xwt, KT, scale, shift):
+        _check(_lib.comat_resample2d(_ptr(src), _ptr(out), B, Hin, Win, Hout, Wout, Cc, _ptr(ystart), _ptr(ywt),
+                                     _ptr(xstart), _ptr(xwt), KT, _ptr(scale), _ptr(shift), dt(src), dt(out),
+                                     _stream()), "comat_resample2d")
+
+    def patchify(self, img, patches, B, H, W, Cc, P, inverse):
+        _check(_lib.comat_patchify(_ptr(img), _ptr(patches), B, H, W, Cc, P, int(inverse), dt(img), _stream()),
+               "comat_patchify")
+
+    def embedding(self, ids, table, out, n, dim, vocab):
+        assert ids.dtype == torch.int64
+        _check(_lib.comat_embedding(_ptr(ids), _ptr(table), _ptr(out), n, dim, vocab, dt(table), _stream()),
+               "comat_embedding")
+
+    # ---- losses --------------------------------------------------------------------------------------------
+    def cross_entropy_fwd(self, logits, labels, logp, row_lse, loss_sum_cnt, T, V, ld, ignore_index, ls):
+        assert labels.dtype == torch.int64
+        _check(_lib.comat_cross_entropy_fwd(_ptr(logits), _ptr(labels), _ptr(logp), _ptr(row_lse),
+                                            _ptr(loss_sum_cnt), T, V, ld, ignore_index, ls, dt(logits), _stream()),
+               "comat_cross_entropy_fwd")
+
+    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, gscale):
+        _check(_lib.comat_cross_entropy_bwd(_ptr(logits), _ptr(labels), _ptr(row_lse), _ptr(dlogits), T, V, ld,
+                                            ignore_index, ls, gscale, dt(logits), _stream()),
+               "comat_cross_entropy_bwd")
+
+    def disc_head_fwd(self, x, w, b, target, loss, P, pix_per_sample):
+        _check(_lib.comat_disc_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(loss), P, pix_per_sample,
+                                        dt(x), _stream()), "comat_disc_head_fwd")
+
+    def disc_head_bwd(self, x, w, b, target, gscale, dx, dw, db, P, pix_per_sample):
+        _check(_lib.comat_disc_head_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), gscale, _ptr(dx), _ptr(dw),
+                                        _ptr(db), P, pix_per_sample, dt(x), _stream()), "comat_disc_head_bwd")
+
+    def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):
+        assert tok_idx.dtype == torch.int32 and tok_obj.dtype == torch.int32
+        _check(_lib.comat_attnmap_gather_fwd(_ptr(amap), _ptr(mask), _ptr(tok_idx), _ptr(tok_obj), _ptr(num),
+                                             _ptr(den), _ptr(avg), heads, npix, L, n_tok, dt(amap), _stream()),
+               "comat_attnmap_gather_fwd")
+
+    def attnmap_gather_bwd(self, g_num, g_den, g_avg, mask, tok_idx, tok_obj, damap, heads, npix, L, n_tok):
+        _check(_lib.comat_attnmap_gather_bwd(_ptr(g_num), _ptr(g_den), _ptr(g_avg), _ptr(mask), _ptr(tok_idx),
+                                             _ptr(tok_obj), _ptr(damap), heads, npix, L, n_tok, dt(damap),
+                                             _stream()), "comat_attnmap_gather_bwd")
+
+    # ---- optimizer -----------------------------------------------------------------------------------------
+    def sumsq(self, x, n, out):
+        _check(_lib.comat_sumsq(_ptr(x), n, _ptr(out), _stream()), "comat_sumsq")
+
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
+        _check(_lib.comat_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, wd, step,
+                                _ptr(gnorm_sq), max_norm, _stream()), "comat_adamw")

@@ -1,0 +1,786 @@
+"""Autograd operators of the CoMat step, each a thin `torch.autograd.Function` over the C-ABI kernels.
+
+Activations are channels-last token matrices: an image tensor (B, H, W, C) is the contiguous 2-D tensor
+[B*H*W, C].  Frozen weights carry both orientations (`w` [N,K] for the forward GEMM, `wt` [K,N] for the
+data-gradient) so that every large contraction runs through the k-contiguous MFMA path; only LoRA factors and
+attention use the k-major operand paths.  Nothing here computes on the CPU: the kernel backend is the HIP library
+(`comat_amd._hip.HipKernels`); `set_kernel_backend` exists only so that `tests/` can check the host logic on a
+machine without a GPU by plugging in a simulator of the C ABI.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import ACT_GELU, ACT_NONE, ACT_SILU, UN_AFFINE, UN_COPY, UN_GELU, UN_SILU  # noqa: F401
+
+_K = None
+
+
+def kernels():
+    global _K
+    if _K is None:
+        _K = _hip.HipKernels()  # raises if libcomat_hip.so is missing: no fallback
+    return _K
+
+
+def set_kernel_backend(k):
+    """Test seam (tests/ only): replace the kernel backend by an object with the HipKernels method set."""
+    global _K
+    _K = k
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# parameter holders
+# ----------------------------------------------------------------------------------------------------------------
+class FrozenLinear:
+    """A frozen nn.Linear: weight [N,K] and its transpose [K,N] in the compute dtype, bias fp32."""
+
+    def __init__(self, weight: torch.Tensor, bias, dtype, device):
+        w = weight.to(device=device, dtype=torch.float32)
+        self.w = w.to(dtype).contiguous()
+        self.wt = w.t().contiguous().to(dtype)
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+        self.out_features, self.in_features = self.w.shape
+
+
+class FrozenConv:
+    """A frozen conv2d.  `w` is [Cout, KH, KW, Cin]; `wd` is the tap-flipped, channel-transposed weight
+    [Cin, KH, KW, Cout] that turns the data-gradient into the same implicit-GEMM gather."""
+
+    def __init__(self, weight_oihw: torch.Tensor, bias, dtype, device, stride=1, pad=1):
+        w = weight_oihw.to(device=device, dtype=torch.float32)
+        self.cout, self.cin, self.kh, self.kw = w.shape
+        self.w = w.permute(0, 2, 3, 1).contiguous().to(dtype)
+        self.wd = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(dtype)
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+        self.stride, self.pad = stride, pad
+
+
+class LoRAPair:
+    """fp32 master LoRA factors (trainable leaves) with cached compute-dtype copies.
+    y += scale * up(down(x)); down [r, in], up [out, r]  (diffusers LoRALinearLayer)."""
+
+    def __init__(self, down: torch.Tensor, up: torch.Tensor, dtype, scale=1.0):
+        self.down, self.up = down, up  # views into the flat fp32 parameter buffer, requires_grad
+        self.dtype, self.scale = dtype, scale
+        self._cache = None
+
+    def compute_copies(self):
+        if self.dtype == torch.float32:
+            return self.down.detach(), self.up.detach()
+        key = (self.down._version, self.up._version)
+        if self._cache is None or self._cache[0] != key:
+            self._cache = (key, cast(self.down.detach(), self.dtype), cast(self.up.detach(), self.dtype))
+        return self._cache[1], self._cache[2]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# elementwise
+# ----------------------------------------------------------------------------------------------------------------
+def cast(x, dtype):
+    """dtype conversion (no autograd)."""
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    y = torch.empty_like(x, dtype=dtype)
+    kernels().unary(UN_COPY, x, y, x.numel())
+    return y
+
+
+class _Cast(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return cast(_c(g), ctx.src_dtype), None
+
+
+def cast_grad(x, dtype):
+    return x if x.dtype == dtype else _Cast.apply(x, dtype)
+
+
+class _Unary(Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        x = _c(x)
+        y = torch.empty_like(x)
+        kernels().unary(op, x, y, x.numel())
+        ctx.save_for_backward(x)
+        ctx.op = op
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        kernels().unary_bwd(ctx.op, _c(g), x, dx, x.numel())
+        return dx, None
+
+
+def silu(x):
+    return _Unary.apply(x, UN_SILU)
+
+
+def gelu(x):
+    return _Unary.apply(x, UN_GELU)
+
+
+class _Axpby(Function):
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        x, y = _c(x), _c(y)
+        out = torch.empty_like(x)
+        kernels().axpby(a, x, b, y, out, x.numel())
+        ctx.a, ctx.b = a, b
+        ctx.ydtype = y.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            if ctx.a == 1.0:
+                gx = g
+            else:
+                gx = torch.empty_like(g)
+                kernels().axpby(ctx.a, g, 0.0, None, gx, g.numel())
+        if ctx.needs_input_grad[1]:
+            if ctx.b == 1.0 and ctx.ydtype == g.dtype:
+                gy = g
+            else:
+                gy = torch.empty_like(g, dtype=ctx.ydtype)
+                kernels().axpby(ctx.b, g, 0.0, None, gy, g.numel())
+        return gx, gy, None, None
+
+
+def add(x, y, a=1.0, b=1.0):
+    """a*x + b*y (same shape); result has x's dtype."""
+    return _Axpby.apply(x, y, float(a), float(b))
+
+
+class _Affine(Function):
+    @staticmethod
+    def forward(ctx, x, a, b):
+        x = _c(x)
+        y = torch.empty_like(x)
+        kernels().unary(UN_AFFINE, x, y, x.numel(), a, b)
+        ctx.a = a
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        dx = torch.empty_like(g)
+        kernels().unary(UN_AFFINE, g, dx, g.numel(), ctx.a, 0.0)
+        return dx, None, None
+
+
+def affine(x, a, b):
+    """a*x + b with scalars."""
+    return _Affine.apply(x, float(a), float(b))
+
+
+class _Geglu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        M, D2 = x.shape
+        y = x.new_empty((M, D2 // 2))
+        kernels().geglu_fwd(x, y, M, D2 // 2)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        kernels().geglu_bwd(_c(g), x, dx, x.shape[0], x.shape[1] // 2)
+        return dx
+
+
+def geglu(x):
+    return _Geglu.apply(x)
+
+
+class _ConcatCols(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        M, Ca = a.shape
+        Cb = b.shape[1]
+        out = a.new_empty((M, Ca + Cb))
+        k = kernels()
+        k.copy2d(a, Ca, out, Ca + Cb, M, Ca)
+        k.copy2d(b, Cb, out[:, Ca:], Ca + Cb, M, Cb)
+        ctx.ca, ctx.cb = Ca, Cb
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        M = g.shape[0]
+        Ca, Cb = ctx.ca, ctx.cb
+        k = kernels()
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = g.new_empty((M, Ca))
+            k.copy2d(g, Ca + Cb, ga, Ca, M, Ca)
+        if ctx.needs_input_grad[1]:
+            gb = g.new_empty((M, Cb))
+            k.copy2d(g[:, Ca:], Ca + Cb, gb, Cb, M, Cb)
+        return ga, gb
+
+
+def concat_cols(a, b):
+    """channel concat of two [M, C*] token matrices (UNet skip connections)."""
+    return _ConcatCols.apply(a, b)
+
+
+class _ConcatRows(Function):
+    """row concat: out = [a; b] (batch concat of token matrices)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        out = a.new_empty((a.shape[0] + b.shape[0], a.shape[1]))
+        k = kernels()
+        k.unary(UN_COPY, a, out[: a.shape[0]], a.numel())
+        k.unary(UN_COPY, b, out[a.shape[0]:], b.numel())
+        ctx.ma = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        return g[: ctx.ma], g[ctx.ma:]
+
+
+def concat_rows(a, b):
+    return _ConcatRows.apply(a, b)
+
+
+class _AddRowVec(Function):
+    @staticmethod
+    def forward(ctx, x, v):
+        x, v = _c(x), _c(v)
+        out = torch.empty_like(x)
+        kernels().add_rowvec(x, v, out, x.shape[0], x.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None  # v is a frozen positional table
+
+
+def add_rowvec(x, v):
+    """x[r, :] + v[:] with a frozen vector/table v (x: [rows, cols], v: [cols])."""
+    return _AddRowVec.apply(x, v)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dense contractions
+# ----------------------------------------------------------------------------------------------------------------
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, residual, lin, act):
+        x = _c(x)
+        M, Kd = x.shape
+        N = lin.out_features
+        y = x.new_empty((M, N))
+        if residual is not None:
+            residual = _c(residual)
+        kernels().gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
+                       beta=1.0 if residual is not None else 0.0, act=act)
+        ctx.lin = lin
+        ctx.has_res = residual is not None
+        ctx.shape = (M, N, Kd)
+        assert act == ACT_NONE or not ctx.needs_input_grad[0], "fused activation is for no-grad calls only"
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        M, N, Kd = ctx.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = g.new_empty((M, Kd))
+            kernels().gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)
+        return dx, (g if ctx.has_res else None), None, None
+
+
+def linear(x, lin: FrozenLinear, residual=None, act=ACT_NONE):
+    """y = x W^T + b (+ residual); W frozen."""
+    return _Linear.apply(x, residual, lin, act)
+
+
+class _LoRALinear(Function):
+    """y = x W^T + b + s * (x D^T) U^T (+ residual).  Gradients: x, residual, D (down), U (up) — the last two in
+    fp32 straight out of the GEMM epilogue (training_utils/pipeline.py:123-144 keeps LoRA params in fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, down, up, lin, lora):
+        x = _c(x)
+        M, Kd = x.shape
+        N = lin.out_features
+        dc, uc = lora.compute_copies()
+        r = dc.shape[0]
+        k = kernels()
+        h = x.new_empty((M, r))
+        k.gemm(x, dc, h, M, r, Kd, Kd, Kd, r)
+        y = x.new_empty((M, N))
+        if residual is not None:
+            residual = _c(residual)
+        k.gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
+               beta=1.0 if residual is not None else 0.0)
+        k.gemm(h, uc, y, M, N, r, r, r, N, R=y, ldr=N, alpha=lora.scale, beta=1.0)
+        ctx.save_for_backward(x, h, dc, uc)
+        ctx.lin, ctx.scale = lin, lora.scale
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        x, h, dc, uc = ctx.saved_tensors
+        M, Kd = x.shape
+        N = ctx.lin.out_features
+        r = dc.shape[0]
+        s = ctx.scale
+        k = kernels()
+        # dh = s * g U            (B = U stored [N(k), r(n)] -> k-major)
+        dh = g.new_empty((M, r))
+        k.gemm(g, uc, dh, M, r, N, N, r, r, transB=True, alpha=s)
+        d_up = d_down = dx = None
+        if ctx.needs_input_grad[3]:  # dU [N, r] = s * g^T h
+            d_up = torch.empty((N, r), dtype=torch.float32, device=g.device)
+            k.gemm(g, h, d_up, N, r, M, N, r, r, transA=True, transB=True, alpha=s)
+        if ctx.needs_input_grad[2]:  # dD [r, K] = dh^T x
+            d_down = torch.empty((r, Kd), dtype=torch.float32, device=g.device)
+            k.gemm(dh, x, d_down, r, Kd, M, r, Kd, Kd, transA=True, transB=True)
+        if ctx.needs_input_grad[0]:
+            dx = g.new_empty((M, Kd))
+            k.gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)
+            k.gemm(dh, dc, dx, M, Kd, r, r, Kd, Kd, transB=True, R=dx, ldr=Kd, beta=1.0)
+        return dx, (g if ctx.has_res else None), d_down, d_up, None, None
+
+
+def lora_linear(x, lin: FrozenLinear, lora: LoRAPair | None, residual=None):
+    if lora is None:
+        return linear(x, lin, residual)
+    return _LoRALinear.apply(x, residual, lora.down, lora.up, lin, lora)
+
+
+class _Conv(Function):
+    @staticmethod
+    def forward(ctx, x, residual, conv, B, H, W, ups, bias2):
+        x = _c(x)
+        Hs, Ws = H * ups, W * ups
+        Ho = (Hs + 2 * conv.pad - conv.kh) // conv.stride + 1
+        Wo = (Ws + 2 * conv.pad - conv.kw) // conv.stride + 1
+        assert x.shape == (B * H * W, conv.cin), (x.shape, B, H, W, conv.cin)
+        y = x.new_empty((B * Ho * Wo, conv.cout))
+        if residual is not None:
+            residual = _c(residual)
+        kernels().conv2d(x, conv.w, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad,
+                         mode=0, ups=ups, bias=conv.bias, bias2=bias2, R=residual,
+                         beta=1.0 if residual is not None else 0.0)
+        ctx.conv, ctx.geo = conv, (B, H, W, Ho, Wo, ups)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        conv = ctx.conv
+        B, H, W, Ho, Wo, ups = ctx.geo
+        dx = None
+        if ctx.needs_input_grad[0]:
+            k = kernels()
+            padd = conv.kh - 1 - conv.pad
+            if conv.stride == 1:
+                Hs, Ws = H * ups, W * ups
+                du = g.new_empty((B * Hs * Ws, conv.cin))
+                k.conv2d(g, conv.wd, du, B, Ho, Wo, conv.cout, Hs, Ws, conv.cin, conv.kh, conv.kw, 1, padd, mode=0)
+                if ups == 2:
+                    dx = g.new_empty((B * H * W, conv.cin))
+                    k.sumpool2x2(du, dx, B, H, W, conv.cin)
+                else:
+                    dx = du
+            else:
+                assert ups == 1
+                dx = g.new_empty((B * H * W, conv.cin))
+                k.conv2d(g, conv.wd, dx, B, Ho, Wo, conv.cout, H, W, conv.cin, conv.kh, conv.kw, conv.stride, padd,
+                         mode=1)
+        return dx, (g if ctx.has_res else None), None, None, None, None, None, None
+
+
+def conv2d(x, conv: FrozenConv, B, H, W, ups=1, residual=None, bias2=None):
+    """Channels-last conv (frozen weight).  x: [B*H*W, Cin] -> ([B*Ho*Wo, Cout]).  `ups=2` fuses a nearest 2x
+    upsample of the input; `bias2` [B, Cout] fp32 is the per-sample time-embedding add (no gradient: the time
+    embedding depends only on t and frozen weights); `residual` is added in the epilogue."""
+    return _Conv.apply(x, residual, conv, B, H, W, ups, bias2)
+
+
+def conv_out_hw(conv: FrozenConv, H, W, ups=1):
+    return ((H * ups + 2 * conv.pad - conv.kh) // conv.stride + 1, (W * ups + 2 * conv.pad - conv.kw) // conv.stride + 1)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------------------------
+class _GroupNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, B, HW, G, eps, silu_):
+        x = _c(x)
+        Cc = x.shape[1]
+        assert x.shape[0] == B * HW
+        y = torch.empty_like(x)
+        stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
+        ws = torch.empty((B * G * 2,), dtype=torch.float64, device=x.device)
+        kernels().groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu_)
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.cfg = (B, HW, Cc, G, silu_)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, stats = ctx.saved_tensors
+        B, HW, Cc, G, silu_ = ctx.cfg
+        dx = torch.empty_like(x)
+        ws = torch.empty((B * G * 2,), dtype=torch.float64, device=x.device)
+        kernels().groupnorm_bwd(_c(g), x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu_)
+        return dx, None, None, None, None, None, None, None
+
+
+def group_norm(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False):
+    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu))
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+        kernels().layernorm_fwd(x, gamma, beta, y, stats, M, Cc, eps)
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, stats = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        kernels().layernorm_bwd(_c(g), x, gamma, stats, dx, x.shape[0], x.shape[1])
+        return dx, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# attention with materialised probabilities (the map the reference's AttentionStore captures)
+# ----------------------------------------------------------------------------------------------------------------
+class _Attention(Function):
+    """softmax(scale * Q K^T) V per (batch, head), heads addressed in place inside [tokens, heads*dim] matrices.
+    Returns (O [B*Nq, H*d], P [B, H, Nq, Nk]).  P is a differentiable output: an upstream gradient on it (from the
+    attribute-concentration loss) is added to dP before the softmax backward (attn_utils/tc_attn_utils.py:140-146)."""
+
+    @staticmethod
+    def forward(ctx, q, k_, v, B, Nq, Nk, H, d, scale, causal, key_mask):
+        q, k_, v = _c(q), _c(k_), _c(v)
+        K = kernels()
+        dev = q.device
+        HD = H * d
+        S = torch.empty((B, H, Nq, Nk), dtype=torch.float32, device=dev)
+        K.gemm(q, k_, S, Nq, Nk, d, HD, HD, Nk, batch=(B, H), sA=(Nq * HD, d), sB=(Nk * HD, d),
+               sC=(H * Nq * Nk, Nq * Nk), alpha=scale)
+        P = torch.empty((B, H, Nq, Nk), dtype=q.dtype, device=dev)
+        K.softmax_fwd(S, P, B * H * Nq, Nk, q_len=Nq, causal=causal, causal_offset=Nk - Nq, key_mask=key_mask,
+                      rows_per_mask=H * Nq)
+        del S
+        O = q.new_empty((B * Nq, HD))
+        K.gemm(P, v, O, Nq, d, Nk, Nk, HD, HD, transB=True, batch=(B, H), sA=(H * Nq * Nk, Nq * Nk),
+               sB=(Nk * HD, d), sC=(Nq * HD, d))
+        ctx.save_for_backward(q, k_, v, P)
+        ctx.cfg = (B, Nq, Nk, H, d, scale)
+        return O, P
+
+    @staticmethod
+    def backward(ctx, gO, gP):
+        q, k_, v, P = ctx.saved_tensors
+        B, Nq, Nk, H, d, scale = ctx.cfg
+        K = kernels()
+        dev = q.device
+        HD = H * d
+        sP = (H * Nq * Nk, Nq * Nk)
+        dV = dQ = dK = None
+        if gO is None:
+            gO = torch.zeros((B * Nq, HD), dtype=q.dtype, device=dev)
+        gO = _c(gO)
+        # dP = gO V^T  (fp32)
+        dP = torch.empty((B, H, Nq, Nk), dtype=torch.float32, device=dev)
+        K.gemm(gO, v, dP, Nq, Nk, d, HD, HD, Nk, batch=(B, H), sA=(Nq * HD, d), sB=(Nk * HD, d), sC=sP)
+        if gP is not None:
+            gP = _c(gP)
+            K.axpby(1.0, dP, 1.0, gP, dP, dP.numel())
+        if ctx.needs_input_grad[2]:  # dV [Nk, d] = P^T gO
+            dV = torch.empty_like(v)
+            K.gemm(P, gO, dV, Nk, d, Nq, Nk, HD, HD, transA=True, transB=True, batch=(B, H), sA=sP,
+                   sB=(Nq * HD, d), sC=(Nk * HD, d))
+        dS = torch.empty((B, H, Nq, Nk), dtype=q.dtype, device=dev)
+        K.softmax_bwd(P, dP, dS, B * H * Nq, Nk, scale)
+        del dP
+        if ctx.needs_input_grad[0]:  # dQ = dS K
+            dQ = torch.empty_like(q)
+            K.gemm(dS, k_, dQ, Nq, d, Nk, Nk, HD, HD, transB=True, batch=(B, H), sA=sP, sB=(Nk * HD, d),
+                   sC=(Nq * HD, d))
+        if ctx.needs_input_grad[1]:  # dK = dS^T Q
+            dK = torch.empty_like(k_)
+            K.gemm(dS, q, dK, Nk, d, Nq, Nk, HD, HD, transA=True, transB=True, batch=(B, H), sA=sP,
+                   sB=(Nq * HD, d), sC=(Nk * HD, d))
+        return dQ, dK, dV, None, None, None, None, None, None, None, None
+
+
+def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None):
+    """q: [B*Nq, heads*dim], k/v: [B*Nk, heads*dim] -> (out [B*Nq, heads*dim], probs [B, heads, Nq, Nk])."""
+    if scale is None:
+        scale = dim ** -0.5
+    return _Attention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale), bool(causal), key_mask)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# scheduler step
+# ----------------------------------------------------------------------------------------------------------------
+class _CfgDdpm(Function):
+    @staticmethod
+    def forward(ctx, x, eps2, z, s, cx, ce, sigma):
+        x, eps2 = _c(x), _c(eps2)
+        assert x.dtype == torch.float32 and eps2.numel() == 2 * x.numel()
+        xp = torch.empty_like(x)
+        kernels().cfg_ddpm_fwd(x, eps2, None if z is None else _c(z), xp, x.numel(), s, cx, ce, sigma)
+        ctx.cfg = (s, cx, ce, eps2.dtype, eps2.shape)
+        return xp
+
+    @staticmethod
+    def backward(ctx, g):
+        s, cx, ce, edt, eshape = ctx.cfg
+        g = _c(g)
+        dx = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        deps = torch.empty(eshape, dtype=edt, device=g.device)
+        kernels().cfg_ddpm_bwd(g, dx, deps, g.numel(), s, cx, ce)
+        return dx, (deps if ctx.needs_input_grad[1] else None), None, None, None, None, None
+
+
+def cfg_ddpm_step(x, eps2, z, guidance, cx, ce, sigma):
+    """x_prev = cx*x + ce*(e_u + s(e_c - e_u)) + sigma*z;  x fp32 [n], eps2 = [uncond; cond] in compute dtype."""
+    return _CfgDdpm.apply(x, eps2, z, float(guidance), float(cx), float(ce), float(sigma))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# image path
+# ----------------------------------------------------------------------------------------------------------------
+class ResampleTables:
+    """Device-resident sparse tap tables of a separable linear resampling operator and of its transpose."""
+
+    def __init__(self, fwd, bwd, Hin, Win, Hout, Wout, device):
+        # fwd / bwd: dicts with ystart, ywt, xstart, xwt (numpy), KT
+        def put(d):
+            return dict(ystart=torch.from_numpy(d["ystart"]).to(device), ywt=torch.from_numpy(d["ywt"]).to(device),
+                        xstart=torch.from_numpy(d["xstart"]).to(device), xwt=torch.from_numpy(d["xwt"]).to(device),
+                        KT=int(d["KT"]))
+        self.fwd, self.bwd = put(fwd), put(bwd)
+        self.Hin, self.Win, self.Hout, self.Wout = Hin, Win, Hout, Wout
+
+
+class _Resample(Function):
+    @staticmethod
+    def forward(ctx, img, tab, B, Cc, scale, shift, out_dtype):
+        img = _c(img)
+        out = torch.empty((B * tab.Hout * tab.Wout, Cc), dtype=out_dtype, device=img.device)
+        t = tab.fwd
+        kernels().resample2d(img, out, B, tab.Hin, tab.Win, tab.Hout, tab.Wout, Cc, t["ystart"], t["ywt"], t["xstart"],
+                             t["xwt"], t["KT"], scale, shift)
+        ctx.tab, ctx.B, ctx.C, ctx.scale = tab, B, Cc, scale
+        ctx.in_dtype = img.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        tab = ctx.tab
+        t = tab.bwd
+        dimg = torch.empty((ctx.B * tab.Hin * tab.Win, ctx.C), dtype=ctx.in_dtype, device=g.device)
+        kernels().resample2d(g, dimg, ctx.B, tab.Hout, tab.Wout, tab.Hin, tab.Win, ctx.C, t["ystart"], t["ywt"],
+                             t["xstart"], t["xwt"], t["KT"], ctx.scale, None)
+        return dimg, None, None, None, None, None, None
+
+
+def resample(img, tab: ResampleTables, B, C, scale=None, shift=None, out_dtype=None):
+    """out = scale[c] * R(img) + shift[c] with R the separable resampling operator of `tab`."""
+    return _Resample.apply(img, tab, B, C, scale, shift, out_dtype or img.dtype)
+
+
+class _Patchify(Function):
+    @staticmethod
+    def forward(ctx, img, B, H, W, Cc, P):
+        img = _c(img)
+        out = img.new_empty((B * (H // P) * (W // P), P * P * Cc))
+        kernels().patchify(img, out, B, H, W, Cc, P, False)
+        ctx.cfg = (B, H, W, Cc, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, Cc, P = ctx.cfg
+        g = _c(g)
+        dimg = g.new_empty((B * H * W, Cc))
+        kernels().patchify(dimg, g, B, H, W, Cc, P, True)
+        return dimg, None, None, None, None, None
+
+
+def patchify(img, B, H, W, C, P):
+    return _Patchify.apply(img, B, H, W, C, P)
+
+
+def embedding(ids, table):
+    """rows of a frozen table (no gradient)."""
+    ids = _c(ids.reshape(-1))
+    out = table.new_empty((ids.numel(), table.shape[1]))
+    kernels().embedding(ids, table, out, ids.numel(), table.shape[1], table.shape[0])
+    return out
+
+
+class _Permute(Function):
+    @staticmethod
+    def forward(ctx, x, B, Cc, H, W, to_nhwc, out_dtype):
+        x = _c(x)
+        y = torch.empty(((B * H * W, Cc) if to_nhwc else (B, Cc, H, W)), dtype=out_dtype, device=x.device)
+        kernels().permute_nchw_nhwc(x, y, B, Cc, H, W, to_nhwc)
+        ctx.cfg = (B, Cc, H, W, to_nhwc, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, H, W, to_nhwc, xdt = ctx.cfg
+        g = _c(g)
+        dx = torch.empty(((B, Cc, H, W) if to_nhwc else (B * H * W, Cc)), dtype=xdt, device=g.device)
+        kernels().permute_nchw_nhwc(g, dx, B, Cc, H, W, not to_nhwc)
+        return dx, None, None, None, None, None, None
+
+
+def nchw_to_tokens(x, out_dtype=None):
+    B, Cc, H, W = x.shape
+    return _Permute.apply(x, B, Cc, H, W, True, out_dtype or x.dtype)
+
+
+def tokens_to_nchw(x, B, H, W, out_dtype=None):
+    return _Permute.apply(x, B, x.shape[1], H, W, False, out_dtype or x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------------------------
+class _CrossEntropy(Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index, ls):
+        logits = _c(logits)
+        T, V = logits.shape
+        dev = logits.device
+        logp = torch.empty((T,), dtype=torch.float32, device=dev)
+        lse = torch.empty((T,), dtype=torch.float32, device=dev)
+        acc = torch.empty((2,), dtype=torch.float32, device=dev)
+        kernels().cross_entropy_fwd(logits, labels, logp, lse, acc, T, V, V, ignore_index, ls)
+        ctx.save_for_backward(logits, labels, lse, acc)
+        ctx.cfg = (ignore_index, ls)
+        ctx.mark_non_differentiable(logp)
+        return acc[0] / acc[1], logp
+
+    @staticmethod
+    def backward(ctx, g, _):
+        logits, labels, lse, acc = ctx.saved_tensors
+        ignore_index, ls = ctx.cfg
+        T, V = logits.shape
+        gscale = float(g) / float(acc[1])  # host sync on two scalars, once per step
+        dl = torch.empty_like(logits)
+        kernels().cross_entropy_bwd(logits, labels, lse, dl, T, V, V, ignore_index, ls, gscale)
+        return dl, None, None, None
+
+
+def cross_entropy(logits, labels, ignore_index=-100, label_smoothing=0.0):
+    """mean token CE over labels != ignore_index.  Returns (loss, per-token log-prob of the label)."""
+    return _CrossEntropy.apply(logits, labels, int(ignore_index), float(label_smoothing))
+
+
+class _DiscHead(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, target, pix_per_sample):
+        x = _c(x)
+        P = x.shape[0]
+        assert x.shape[1] == 4
+        loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+        kernels().disc_head_fwd(x, w, b, target, loss, P, pix_per_sample)
+        ctx.save_for_backward(x, w, b, target)
+        ctx.pps = pix_per_sample
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, b, target = ctx.saved_tensors
+        P = x.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.zeros((4,), dtype=torch.float32, device=x.device)
+            db = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        kernels().disc_head_bwd(x, w, b, target, float(g), dx, dw, db, P, ctx.pps)
+        return dx, dw, db, None, None
+
+
+def disc_head_loss(x, w, b, target, pix_per_sample):
+    """mean BCE-with-logits of Linear(4,1)(x) against target[pixel // pix_per_sample] (gan_sdxl.py:83-88)."""
+    return _DiscHead.apply(x, w, b, target, int(pix_per_sample))
+
+
+class _AttnMapGather(Function):
+    @staticmethod
+    def forward(ctx, amap, mask, tok_idx, tok_obj):
+        amap = _c(amap)
+        H, npix, L = amap.shape
+        n_tok = tok_idx.numel()
+        dev = amap.device
+        num = torch.zeros((H, n_tok), dtype=torch.float32, device=dev)
+        den = torch.zeros((H, n_tok), dtype=torch.float32, device=dev)
+        avg = torch.zeros((n_tok, npix), dtype=torch.float32, device=dev)
+        kernels().attnmap_gather_fwd(amap, mask, tok_idx, tok_obj, num, den, avg, H, npix, L, n_tok)
+        ctx.save_for_backward(mask, tok_idx, tok_obj)
+        ctx.cfg = (H, npix, L, n_tok, amap.dtype)
+        return num, den, avg
+
+    @staticmethod
+    def backward(ctx, g_num, g_den, g_avg):
+        mask, tok_idx, tok_obj = ctx.saved_tensors
+        H, npix, L, n_tok, adt = ctx.cfg
+        dev = mask.device
+        z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else _c(t)
+        g_num, g_den = z(g_num, (H, n_tok)), z(g_den, (H, n_tok))
+        g_avg = None if g_avg is None else _c(g_avg)
+        damap = torch.zeros((H, npix, L), dtype=adt, device=dev)
+        kernels().attnmap_gather_bwd(g_num, g_den, g_avg, mask, tok_idx, tok_obj, damap, H, npix, L, n_tok)
+        return damap, None, None, None
+
+
+def attnmap_gather(amap, mask, tok_idx, tok_obj):
+    """amap [heads, npix, L] -> (num [heads, n_tok], den [heads, n_tok], avg [n_tok, npix])."""
+    return _AttnMapGather.apply(amap, mask, tok_idx, tok_obj)

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+def _use_sim():
+    from comat_amd import ops
+    from sim_backend import SimKernels
+    ops.set_kernel_backend(SimKernels())
+    return torch.device("cpu")
+
+
+def _use_hip():
+    from comat_amd import _hip, ops
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    ops.set_kernel_backend(_hip.HipKernels())  # raises if the .so is missing: no silent fallback
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
+def dev(request):
+    """Device + kernel backend: 'sim' = CPU simulator of the C ABI (host-logic check, runs anywhere),
+    'hip' = the real libcomat_hip.so on cuda:0 (the parity tests proper)."""
+    d = _use_sim() if request.param == "sim" else _use_hip()
+    yield d
+    from comat_amd import ops
+    ops.set_kernel_backend(None)
+
+
+@pytest.fixture
+def sim():
+    d = _use_sim()
+    yield d
+    from comat_amd import ops
+    ops.set_kernel_backend(None)
+
+
+@pytest.fixture
+def hip():
+    d = _use_hip()
+    yield d
+    from comat_amd import ops
+    ops.set_kernel_backend(None)

@@ -1,0 +1,316 @@
+"""CPU simulator of the libcomat_hip C ABI — TEST INFRASTRUCTURE ONLY.
+
+It implements, with plain torch CPU ops, the documented semantics of every entry point in include/comat_hip.h
+(same argument lists as comat_amd._hip.HipKernels).  tests/ plug it in through
+`comat_amd.ops.set_kernel_backend(SimKernels())` to exercise the host logic (operator wiring, model assembly,
+gradient gating, the step graph, the 2-rank gloo path) on machines without a GPU.  The product never imports it.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+UN_COPY, UN_SILU, UN_GELU, UN_AFFINE = 0, 1, 2, 3
+
+
+def _v(t, sizes, strides):
+    return torch.as_strided(t, sizes, strides, t.storage_offset())
+
+
+def _act(x, act):
+    if act == ACT_SILU:
+        return F.silu(x)
+    if act == ACT_GELU:
+        return F.gelu(x)
+    return x
+
+
+class SimKernels:
+    name = "sim"
+
+    # ---- contraction ---------------------------------------------------------------------------------------
+    def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
+             sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
+             beta=0.0, act=ACT_NONE):
+        b1, b2 = batch
+        Av = _v(A, (b1, b2, M, K), (sA[0], sA[1], 1, lda) if transA else (sA[0], sA[1], lda, 1))
+        Bv = _v(B, (b1, b2, N, K), (sB[0], sB[1], 1, ldb) if transB else (sB[0], sB[1], ldb, 1))
+        acc = alpha * (Av.float() @ Bv.float().transpose(-1, -2))
+        if bias is not None:
+            acc = acc + bias.float()
+        if bias2 is not None:
+            acc = acc + bias2.float().repeat_interleave(rows_per_bias2, 0)[:M]
+        acc = _act(acc, act)
+        if R is not None:
+            acc = acc + beta * _v(R, (b1, b2, M, N), (sR[0], sR[1], ldr, 1)).float()
+        _v(Cout, (b1, b2, M, N), (sC[0], sC[1], ldc, 1)).copy_(acc.to(Cout.dtype))
+
+    def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):
+        x = _v(X, (B, Hin, Win, Cin), (Hin * Win * Cin, Win * Cin, Cin, 1)).float().permute(0, 3, 1, 2)
+        w = _v(W, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)).float().permute(0, 3, 1, 2)
+        if mode == 0:
+            if ups == 2:
+                x = F.interpolate(x, scale_factor=2, mode="nearest")
+            y = F.conv2d(x, w, stride=stride, padding=pad)
+        else:
+            # transposed gather: src = (dst + k - pad)/stride when divisible
+            xz = torch.zeros((B, Cin, (Hin - 1) * stride + 1, (Win - 1) * stride + 1))
+            xz[:, :, ::stride, ::stride] = x
+            pb = Hout + KH - 1 - pad - xz.shape[2]
+            pr = Wout + KW - 1 - pad - xz.shape[3]
+            xz = F.pad(xz, (pad, max(pr, 0), pad, max(pb, 0)))
+            y = F.conv2d(xz, w)[:, :, :Hout, :Wout]
+        assert y.shape == (B, Cout, Hout, Wout), (y.shape, (B, Cout, Hout, Wout))
+        acc = alpha * y.permute(0, 2, 3, 1).reshape(B * Hout * Wout, Cout)
+        if bias is not None:
+            acc = acc + bias.float()
+        if bias2 is not None:
+            acc = acc + bias2.float().repeat_interleave(Hout * Wout, 0)
+        acc = _act(acc, act)
+        if R is not None:
+            acc = acc + beta * _v(R, (B * Hout * Wout, Cout), (Cout, 1)).float()
+        _v(Y, (B * Hout * Wout, Cout), (Cout, 1)).copy_(acc.to(Y.dtype))
+
+    # ---- normalisation -------------------------------------------------------------------------------------
+    @staticmethod
+    def _gn(xf, gamma, beta, B, HW, Cc, G, eps, silu):
+        xg = xf.reshape(B, HW, G, Cc // G)
+        mean = xg.mean(dim=(1, 3), keepdim=True)
+        var = xg.var(dim=(1, 3), unbiased=False, keepdim=True)
+        rstd = (var + eps).rsqrt()
+        y = ((xg - mean) * rstd).reshape(B * HW, Cc) * gamma + beta
+        if silu:
+            y = F.silu(y)
+        return y, mean.reshape(B, G), rstd.reshape(B, G)
+
+    def groupnorm_fwd(self, x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu):
+        yy, mean, rstd = self._gn(x.float(), gamma, beta, B, HW, Cc, G, eps, silu)
+        y.copy_(yy.to(y.dtype))
+        stats.copy_(torch.stack([mean, rstd], dim=-1))
+
+    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu):
+        mean = stats[..., 0].reshape(B, 1, G, 1)
+        rstd = stats[..., 1].reshape(B, 1, G, 1)
+        xf = x.float()
+        xh = ((xf.reshape(B, HW, G, Cc // G) - mean) * rstd).reshape(B * HW, Cc)
+        g = dy.float()
+        if silu:
+            yhat = xh * gamma + beta
+            s = torch.sigmoid(yhat)
+            g = g * (s * (1 + yhat * (1 - s)))
+        g = g * gamma
+        gg = g.reshape(B, HW, G, Cc // G)
+        xhg = xh.reshape(B, HW, G, Cc // G)
+        s1 = gg.mean(dim=(1, 3), keepdim=True)
+        s2 = (gg * xhg).mean(dim=(1, 3), keepdim=True)
+        out = (rstd * (gg - s1 - xhg * s2)).reshape(B * HW, Cc)
+        dx.copy_(out.to(dx.dtype))
+
+    def layernorm_fwd(self, x, gamma, beta, y, stats, M, Cc, eps):
+        xf = x.float()
+        mean = xf.mean(-1, keepdim=True)
+        rstd = (xf.var(-1, unbiased=False, keepdim=True) + eps).rsqrt()
+        y.copy_((((xf - mean) * rstd) * gamma + beta).to(y.dtype))
+        stats.copy_(torch.cat([mean, rstd], dim=-1))
+
+    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc):
+        mean, rstd = stats[:, :1], stats[:, 1:]
+        xh = (x.float() - mean) * rstd
+        g = dy.float() * gamma
+        s1 = g.mean(-1, keepdim=True)
+        s2 = (g * xh).mean(-1, keepdim=True)
+        dx.copy_((rstd * (g - s1 - xh * s2)).to(dx.dtype))
+
+    # ---- softmax -------------------------------------------------------------------------------------------
+    def softmax_fwd(self, S, P, rows, cols, q_len=0, causal=False, causal_offset=0, key_mask=None, rows_per_mask=0):
+        s = S.reshape(rows, cols).float().clone()
+        if causal:
+            q = torch.arange(rows) % q_len
+            j = torch.arange(cols)
+            s = s.masked_fill(j[None, :] > (q[:, None] + causal_offset), float("-inf"))
+        if key_mask is not None:
+            km = key_mask.reshape(-1, cols).bool().repeat_interleave(rows_per_mask, 0)[:rows]
+            s = s.masked_fill(~km, float("-inf"))
+        p = torch.softmax(s, dim=-1)
+        p = torch.nan_to_num(p, nan=0.0)
+        P.reshape(rows, cols).copy_(p.to(P.dtype))
+
+    def softmax_bwd(self, P, dP, dS, rows, cols, scale):
+        p = P.reshape(rows, cols).float()
+        g = dP.reshape(rows, cols).float()
+        dS.reshape(rows, cols).copy_((scale * p * (g - (g * p).sum(-1, keepdim=True))).to(dS.dtype))
+
+    # ---- elementwise ---------------------------------------------------------------------------------------
+    def unary(self, op, x, y, n, p0=0.0, p1=0.0):
+        v = x.reshape(-1)[:n].float()
+        if op == UN_SILU:
+            v = F.silu(v)
+        elif op == UN_GELU:
+            v = F.gelu(v)
+        elif op == UN_AFFINE:
+            v = p0 * v + p1
+        y.reshape(-1)[:n].copy_(v.to(y.dtype))
+
+    def unary_bwd(self, op, dy, x, dx, n):
+        v = x.reshape(-1)[:n].float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = F.silu(v) if op == UN_SILU else F.gelu(v)
+            (g,) = torch.autograd.grad(out, v, dy.reshape(-1)[:n].float())
+        dx.reshape(-1)[:n].copy_(g.to(dx.dtype))
+
+    def axpby(self, a, x, b, y, out, n):
+        v = a * x.reshape(-1)[:n].float()
+        if y is not None:
+            v = v + b * y.reshape(-1)[:n].float()
+        out.reshape(-1)[:n].copy_(v.to(out.dtype))
+
+    def geglu_fwd(self, x, y, M, D):
+        xf = x.float()
+        y.copy_((xf[:, :D] * F.gelu(xf[:, D:])).to(y.dtype))
+
+    def geglu_bwd(self, dy, x, dx, M, D):
+        xf = x.float().detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = xf[:, :D] * F.gelu(xf[:, D:])
+            (g,) = torch.autograd.grad(out, xf, dy.float())
+        dx.copy_(g.to(dx.dtype))
+
+    def copy2d(self, src, ld_src, dst, ld_dst, rows, cols):
+        _v(dst, (rows, cols), (ld_dst, 1)).copy_(_v(src, (rows, cols), (ld_src, 1)).to(dst.dtype))
+
+    def add_rowvec(self, x, v, out, rows, cols):
+        out.copy_((x.float() + v.float().reshape(1, cols)).to(out.dtype))
+
+    def sumpool2x2(self, x, y, B, H, W, Cc):
+        xv = x.reshape(B, H, 2, W, 2, Cc).float()
+        y.copy_(xv.sum(dim=(2, 4)).reshape(B * H * W, Cc).to(y.dtype))
+
+    def permute_nchw_nhwc(self, x, y, B, Cc, H, W, to_nhwc):
+        if to_nhwc:
+            y.reshape(B, H, W, Cc).copy_(x.reshape(B, Cc, H, W).permute(0, 2, 3, 1).to(y.dtype))
+        else:
+            y.reshape(B, Cc, H, W).copy_(x.reshape(B, H, W, Cc).permute(0, 3, 1, 2).to(y.dtype))
+
+    def cfg_ddpm_fwd(self, x, eps2, z, x_prev, n, s, cx, ce, sigma):
+        e = eps2.reshape(2, n).float()
+        eps = e[0] + s * (e[1] - e[0])
+        v = cx * x.reshape(-1) + ce * eps
+        if z is not None:
+            v = v + sigma * z.reshape(-1)
+        x_prev.reshape(-1).copy_(v)
+
+    def cfg_ddpm_bwd(self, g, dx, deps2, n, s, cx, ce):
+        gf = g.reshape(-1).float()
+        if dx is not None:
+            dx.reshape(-1).copy_(cx * gf)
+        d = deps2.reshape(2, n)
+        d[0].copy_((ce * (1 - s) * gf).to(deps2.dtype))
+        d[1].copy_((ce * s * gf).to(deps2.dtype))
+
+    # ---- image path ----------------------------------------------------------------------------------------
+    def resample2d(self, src, out, B, Hin, Win, Hout, Wout, Cc, ystart, ywt, xstart, xwt, KT, scale, shift):
+        def dense(start, wt, n_out, n_in):
+            Mx = torch.zeros((n_out, n_in))
+            for o in range(n_out):
+                for t in range(KT):
+                    i = int(start[o]) + t
+                    if 0 <= i < n_in and float(wt[o, t]) != 0.0:
+                        Mx[o, i] += float(wt[o, t])
+            return Mx
+        Wy = dense(ystart, ywt.reshape(Hout, KT), Hout, Hin)
+        Wx = dense(xstart, xwt.reshape(Wout, KT), Wout, Win)
+        x = src.reshape(B, Hin, Win, Cc).float()
+        y = torch.einsum("oh,bhwc->bowc", Wy, x)
+        y = torch.einsum("pw,bowc->bopc", Wx, y)
+        if scale is not None:
+            y = y * scale
+        if shift is not None:
+            y = y + shift
+        out.reshape(B, Hout, Wout, Cc).copy_(y.to(out.dtype))
+
+    def patchify(self, img, patches, B, H, W, Cc, P, inverse):
+        nH, nW = H // P, W // P
+        if not inverse:
+            v = img.reshape(B, nH, P, nW, P, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B * nH * nW, P * P * Cc)
+            patches.copy_(v)
+        else:
+            v = patches.reshape(B, nH, nW, P, P, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B * H * W, Cc)
+            img.copy_(v)
+
+    def embedding(self, ids, table, out, n, dim, vocab):
+        out.copy_(table[ids.clamp(0, vocab - 1)])
+
+    # ---- losses --------------------------------------------------------------------------------------------
+    def cross_entropy_fwd(self, logits, labels, logp, row_lse, loss_sum_cnt, T, V, ld, ignore_index, ls):
+        z = logits.float()
+        lse = torch.logsumexp(z, dim=-1)
+        row_lse.copy_(lse)
+        valid = (labels != ignore_index) & (labels >= 0) & (labels < V)
+        y = labels.clamp(0, V - 1)
+        lp = z.gather(1, y[:, None])[:, 0] - lse
+        logp.copy_(torch.where(valid, lp, torch.zeros_like(lp)))
+        loss = (1 - ls) * (-lp) + ls * (lse - z.mean(-1))
+        loss_sum_cnt[0] = loss[valid].sum()
+        loss_sum_cnt[1] = valid.sum().float()
+
+    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, gscale):
+        z = logits.float()
+        valid = (labels != ignore_index) & (labels >= 0) & (labels < V)
+        g = torch.exp(z - row_lse[:, None]) - ls / V
+        y = labels.clamp(0, V - 1)
+        g[torch.arange(T), y] -= (1 - ls)
+        g = g * gscale * valid[:, None].float()
+        dlogits.copy_(g.to(dlogits.dtype))
+
+    def disc_head_fwd(self, x, w, b, target, loss, P, pix_per_sample):
+        z = x.float() @ w.float() + b.float()
+        t = target.float().repeat_interleave(pix_per_sample)[:P]
+        loss[0] = F.binary_cross_entropy_with_logits(z, t)
+
+    def disc_head_bwd(self, x, w, b, target, gscale, dx, dw, db, P, pix_per_sample):
+        xf = x.float()
+        z = xf @ w.float() + b.float()
+        t = target.float().repeat_interleave(pix_per_sample)[:P]
+        dz = gscale * (torch.sigmoid(z) - t) / P
+        if dx is not None:
+            dx.copy_((dz[:, None] * w.float()[None, :]).to(dx.dtype))
+        if dw is not None:
+            dw += dz @ xf
+            db += dz.sum()
+
+    def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):
+        a = amap.float()[:, :, tok_idx.long()]  # [h, npix, n_tok]
+        m = mask[tok_obj.long()]  # [n_tok, npix]
+        num += torch.einsum("hpt,tp->ht", a, m)
+        den += a.sum(1)
+        avg += a.mean(0).t()
+
+    def attnmap_gather_bwd(self, g_num, g_den, g_avg, mask, tok_idx, tok_obj, damap, heads, npix, L, n_tok):
+        m = mask[tok_obj.long()]  # [n_tok, npix]
+        g = g_num[:, None, :] * m.t()[None] + g_den[:, None, :]
+        if g_avg is not None:
+            g = g + g_avg.t()[None] / heads
+        d = damap.float()
+        for t in range(n_tok):
+            d[:, :, int(tok_idx[t])] += g[:, :, t]
+        damap.copy_(d.to(damap.dtype))
+
+    # ---- optimizer -----------------------------------------------------------------------------------------
+    def sumsq(self, x, n, out):
+        out[0] += (x.reshape(-1)[:n].double() ** 2).sum().float()
+
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
+        clip = 1.0
+        if gnorm_sq is not None and max_norm > 0:
+            clip = min(1.0, max_norm / (math.sqrt(float(gnorm_sq[0])) + 1e-6))
+        gg = g * clip
+        m.mul_(beta1).add_(gg, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+        bc1 = 1 - beta1 ** step
+        bc2s = math.sqrt(1 - beta2 ** step)
+        p.mul_(1 - lr * wd)
+        p.addcdiv_(m, v.sqrt() / bc2s + eps, value=-lr / bc1)

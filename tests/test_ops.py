@@ -1,0 +1,441 @@
+"""Operator parity: every comat_amd op (HIP kernels through the C ABI) against a plain PyTorch fp32 reference of the
+same op, forward and backward.  Parametrised over the kernel backend: `sim` (CPU simulator of the ABI, validates the
+test + host wiring anywhere) and `hip` (the real kernels on an MI355X, marked gpu).  Tolerances: fp32 storage uses
+exact-f32 MFMA -> 2e-4 of the output scale; bf16 storage -> 2e-2 (8 mantissa bits) against the fp32 reference
+evaluated on the bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from comat_amd import ops
+from comat_amd.resize import resize_tables
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 2e-2
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dtype).float()  # value representable in `dtype`, held in fp32
+
+
+def check(got, ref, dtype, what="", factor=1.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err / scale < tol(dtype) * factor, f"{what}: max err {err:.3e} vs scale {scale:.3e} ({dtype})"
+
+
+def dv(x, dev, dtype=None, grad=False):
+    t = x.detach().to(device=dev, dtype=dtype or x.dtype).contiguous()
+    return t.clone().requires_grad_(True) if grad else t
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("transA", [False, True])
+@pytest.mark.parametrize("transB", [False, True])
+@pytest.mark.parametrize("shape", [(150, 77, 93), (256, 320, 128), (33, 500, 40), (300, 200, 264)])
+def test_gemm_layouts(dev, dtype, transA, transB, shape):
+    M, N, K = shape
+    A = rnd(M, K, dtype=dtype, seed=1)
+    B = rnd(N, K, dtype=dtype, seed=2)
+    bias = rnd(N, seed=3)
+    bias2 = rnd(3, N, seed=4)
+    R = rnd(M, N, dtype=dtype, seed=5)
+    rpb = (M + 2) // 3
+    ref = 0.5 * (A @ B.t()) + bias + bias2.repeat_interleave(rpb, 0)[:M]
+    ref = F.silu(ref) + 2.0 * R
+    Ad = dv(A.t() if transA else A, dev, dtype)
+    Bd = dv(B.t() if transB else B, dev, dtype)
+    C = torch.empty((M, N), dtype=dtype, device=dev)
+    ops.kernels().gemm(Ad, Bd, C, M, N, K, M if transA else K, N if transB else K, N, transA=transA, transB=transB,
+                       bias=dv(bias, dev), bias2=dv(bias2, dev), rows_per_bias2=rpb, R=dv(R, dev, dtype), ldr=N,
+                       alpha=0.5, beta=2.0, act=ops.ACT_SILU)
+    check(C, ref, dtype, "gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_asymmetric_identity(dev, dtype):
+    """A = I against an asymmetric B catches a transposed C-write (cdna guide G9)."""
+    n = 96
+    A = torch.eye(n)
+    B = (torch.arange(n * n).reshape(n, n) % 17).float() - 8 + torch.arange(n)[:, None].float() * 0.25
+    B = B.to(dtype).float()
+    C = torch.empty((n, n), dtype=torch.float32, device=dev)
+    ops.kernels().gemm(dv(A, dev, dtype), dv(B, dev, dtype), C, n, n, n, n, n, n)
+    check(C, B.t(), dtype, "A=I")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_batched_heads_in_place(dev, dtype):
+    """Two-level batch addressing heads inside [tokens, heads*dim] matrices, fp32 output."""
+    B_, H, N, L, d = 2, 3, 70, 45, 40
+    q = rnd(B_ * N, H * d, dtype=dtype, seed=1)
+    k = rnd(B_ * L, H * d, dtype=dtype, seed=2)
+    S = torch.empty((B_, H, N, L), dtype=torch.float32, device=dev)
+    HD = H * d
+    ops.kernels().gemm(dv(q, dev, dtype), dv(k, dev, dtype), S, N, L, d, HD, HD, L, batch=(B_, H),
+                       sA=(N * HD, d), sB=(L * HD, d), sC=(H * N * L, N * L), alpha=0.3)
+    ref = 0.3 * torch.einsum("bnhd,blhd->bhnl", q.reshape(B_, N, H, d), k.reshape(B_, L, H, d))
+    check(S, ref, dtype, "batched QK^T")
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, ups
+    (2, 12, 12, 16, 24, 3, 1, 1, 1),
+    (1, 9, 7, 4, 40, 3, 1, 1, 1),      # Cin=4: unaligned gather path (conv_in)
+    (2, 16, 16, 32, 8, 3, 2, 1, 1),    # Downsample2D; dgrad = transposed gather
+    (1, 8, 8, 32, 16, 3, 1, 1, 2),     # Upsample2D: nearest 2x fused
+    (2, 10, 10, 24, 136, 1, 1, 0, 1),  # 1x1
+    (1, 24, 24, 64, 132, 3, 1, 1, 1),  # several k-tiles / n-tiles
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, dtype, case):
+    B_, H, W, Cin, Cout, k, stride, pad, ups = case
+    x = rnd(B_, Cin, H, W, dtype=dtype, seed=1)
+    w = rnd(Cout, Cin, k, k, dtype=dtype, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3)
+    temb = rnd(B_, Cout, seed=4)
+    conv = ops.FrozenConv(w, b, dtype, dev, stride=stride, pad=pad)
+    Ho, Wo = ops.conv_out_hw(conv, H, W, ups)
+    res = rnd(B_, Cout, Ho, Wo, dtype=dtype, seed=5)
+    gy = rnd(B_, Cout, Ho, Wo, dtype=dtype, seed=6)
+
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups == 2 else xr
+    yref = F.conv2d(xin, w, b, stride=stride, padding=pad) + temb[:, :, None, None] + rr
+    yref.backward(gy)
+
+    def tok(t):
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    xd = dv(tok(x), dev, dtype, grad=True)
+    rd = dv(tok(res), dev, dtype, grad=True)
+    y = ops.conv2d(xd, conv, B_, H, W, ups=ups, residual=rd, bias2=dv(temb, dev))
+    y.backward(dv(tok(gy), dev, dtype))
+    check(y, tok(yref), dtype, "conv fwd")
+    check(xd.grad, tok(xr.grad), dtype, "conv dgrad")
+    check(rd.grad, tok(rr.grad), dtype, "conv residual grad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("shape", [(2, 50, 32, 8), (1, 130, 320, 32), (2, 64, 80, 8)])
+def test_groupnorm(dev, dtype, silu, shape):
+    B_, HW, C, G = shape
+    x = rnd(B_, HW, C, dtype=dtype, seed=1) * 2 + 0.7
+    gamma, beta = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.3
+    gy = rnd(B_ * HW, C, dtype=dtype, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.group_norm(xr.permute(0, 2, 1), G, gamma, beta, eps=1e-5).permute(0, 2, 1)
+    if silu:
+        yr = F.silu(yr)
+    yr = yr.reshape(B_ * HW, C)
+    yr.backward(gy)
+    xd = dv(x.reshape(B_ * HW, C), dev, dtype, grad=True)
+    y = ops.group_norm(xd, dv(gamma, dev), dv(beta, dev), B_, HW, G=G, eps=1e-5, silu=silu)
+    y.backward(dv(gy, dev, dtype))
+    check(y, yr, dtype, "gn fwd")
+    check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, "gn bwd", factor=2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(37, 96), (8, 1280), (5, 70)])
+def test_layernorm(dev, dtype, shape):
+    M, C = shape
+    x = rnd(M, C, dtype=dtype, seed=1) * 1.5 - 0.4
+    gamma, beta = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.3
+    gy = rnd(M, C, dtype=dtype, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gamma, beta, eps=1e-5)
+    yr.backward(gy)
+    xd = dv(x, dev, dtype, grad=True)
+    y = ops.layer_norm(xd, dv(gamma, dev), dv(beta, dev), eps=1e-5)
+    y.backward(dv(gy, dev, dtype))
+    check(y, yr, dtype, "ln fwd")
+    check(xd.grad, xr.grad, dtype, "ln bwd", factor=2)
+
+
+def ref_attention(q, k, v, B_, Nq, Nk, H, d, causal, key_mask):
+    qh = q.reshape(B_, Nq, H, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B_, Nk, H, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B_, Nk, H, d).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) * d ** -0.5
+    if causal:
+        m = torch.ones(Nq, Nk, dtype=torch.bool).tril(diagonal=Nk - Nq)
+        s = s.masked_fill(~m, float("-inf"))
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ vh).permute(0, 2, 1, 3).reshape(B_ * Nq, H * d)
+    return o, p
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    (2, 70, 70, 2, 40, False, False),   # self-attention, head dim 40 (SD1.5 level 0)
+    (2, 64, 77, 8, 8, False, False),    # cross-attention to 77 text tokens, with a loss on the captured map
+    (1, 10, 10, 3, 16, True, False),    # BLIP decoder causal self-attention
+    (2, 6, 20, 2, 16, False, True),     # key padding mask
+    (1, 200, 136, 1, 64, False, False),
+])
+def test_attention(dev, dtype, cfg):
+    B_, Nq, Nk, H, d, causal, masked = cfg
+    q, k, v = (rnd(B_ * n, H * d, dtype=dtype, seed=s) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    go = rnd(B_ * Nq, H * d, dtype=dtype, seed=4)
+    gp = rnd(B_, H, Nq, Nk, dtype=dtype, seed=5) * 0.1
+    km = None
+    if masked:
+        km = torch.ones(B_, Nk, dtype=torch.int8)
+        km[0, Nk - 5:] = 0
+        km[1, Nk - 1:] = 0
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, p_ref = ref_attention(qr, kr, vr, B_, Nq, Nk, H, d, causal, km)
+    ((o_ref * go).sum() + (p_ref * gp).sum()).backward()
+    qd, kd, vd = (dv(t, dev, dtype, grad=True) for t in (q, k, v))
+    o, p = ops.attention(qd, kd, vd, B_, Nq, Nk, H, d, causal=causal, key_mask=None if km is None else km.to(dev))
+    ((o.float() * dv(go, dev)).sum() + (p.float() * dv(gp, dev)).sum()).backward()
+    check(o, o_ref, dtype, "attn out")
+    check(p, p_ref, dtype, "attn probs")
+    assert torch.allclose(p.float().sum(-1).cpu(), torch.ones(B_, H, Nq), atol=2e-2 if dtype == torch.bfloat16 else 1e-5)
+    check(qd.grad, qr.grad, dtype, "dQ", factor=3)
+    check(kd.grad, kr.grad, dtype, "dK", factor=3)
+    check(vd.grad, vr.grad, dtype, "dV", factor=3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_lora_linear(dev, dtype):
+    M, K, N, r = 130, 64, 96, 8
+    x = rnd(M, K, dtype=dtype, seed=1)
+    w = rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3)
+    down = rnd(r, K, seed=4, scale=r ** -0.5)
+    up = rnd(N, r, seed=5, scale=0.2)
+    res = rnd(M, N, dtype=dtype, seed=6)
+    gy = rnd(M, N, dtype=dtype, seed=7)
+    dq, uq = down.to(dtype).float(), up.to(dtype).float()  # the kernels see the compute-dtype copies
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    dr, ur = dq.clone().requires_grad_(True), uq.clone().requires_grad_(True)
+    yr = xr @ w.t() + b + (xr @ dr.t()) @ ur.t() + rr
+    yr.backward(gy)
+    lin = ops.FrozenLinear(w, b, dtype, dev)
+    dd, ud = dv(down, dev, grad=True), dv(up, dev, grad=True)
+    lora = ops.LoRAPair(dd, ud, dtype)
+    xd, rd = dv(x, dev, dtype, grad=True), dv(res, dev, dtype, grad=True)
+    y = ops.lora_linear(xd, lin, lora, residual=rd)
+    y.backward(dv(gy, dev, dtype))
+    check(y, yr, dtype, "lora fwd")
+    check(xd.grad, xr.grad, dtype, "lora dx")
+    check(rd.grad, rr.grad, dtype, "lora dres")
+    assert dd.grad.dtype == torch.float32 and ud.grad.dtype == torch.float32
+    check(dd.grad, dr.grad, dtype, "lora d_down", factor=2)
+    check(ud.grad, ur.grad, dtype, "lora d_up", factor=2)
+    # plain frozen linear, with and without input grad
+    y2 = ops.linear(xd.detach(), lin, act=ops.ACT_GELU)
+    check(y2, F.gelu(x @ w.t() + b), dtype, "linear+gelu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_elementwise(dev, dtype):
+    x = rnd(37, 24, dtype=dtype, seed=1) * 2
+    y = rnd(37, 24, dtype=dtype, seed=2)
+    g = rnd(37, 24, dtype=dtype, seed=3)
+    for name, fn, rf in (("silu", ops.silu, F.silu), ("gelu", ops.gelu, F.gelu)):
+        xr = x.clone().requires_grad_(True)
+        rf(xr).backward(g)
+        xd = dv(x, dev, dtype, grad=True)
+        out = fn(xd)
+        out.backward(dv(g, dev, dtype))
+        check(out, rf(x), dtype, name)
+        check(xd.grad, xr.grad, dtype, name + " bwd")
+    xd, yd = dv(x, dev, dtype, grad=True), dv(y, dev, dtype, grad=True)
+    out = ops.add(xd, yd, 0.5, -2.0)
+    out.backward(dv(g, dev, dtype))
+    check(out, 0.5 * x - 2 * y, dtype, "axpby")
+    check(xd.grad, 0.5 * g, dtype, "axpby dx")
+    check(yd.grad, -2 * g, dtype, "axpby dy")
+    check(ops.affine(dv(x, dev, dtype), 0.5, 0.5), 0.5 * x + 0.5, dtype, "affine")
+    # geglu
+    xr = x.clone().requires_grad_(True)
+    ref = xr[:, :12] * F.gelu(xr[:, 12:])
+    ref.backward(g[:, :12])
+    xd = dv(x, dev, dtype, grad=True)
+    out = ops.geglu(xd)
+    out.backward(dv(g[:, :12], dev, dtype))
+    check(out, ref, dtype, "geglu")
+    check(xd.grad, xr.grad, dtype, "geglu bwd")
+    # concat (cols / rows) + cast
+    xd, yd = dv(x, dev, dtype, grad=True), dv(y[:, :8], dev, dtype, grad=True)
+    cc = ops.concat_cols(xd, yd)
+    gg = rnd(37, 32, dtype=dtype, seed=9)
+    cc.backward(dv(gg, dev, dtype))
+    check(cc, torch.cat([x, y[:, :8]], 1), dtype, "concat_cols")
+    check(xd.grad, gg[:, :24], dtype, "concat_cols ga")
+    check(yd.grad, gg[:, 24:], dtype, "concat_cols gb")
+    cr = ops.concat_rows(dv(x, dev, dtype), dv(y, dev, dtype))
+    check(cr, torch.cat([x, y], 0), dtype, "concat_rows")
+    c32 = ops.cast(dv(x, dev, dtype), torch.float32)
+    assert c32.dtype == torch.float32
+    check(c32, x, dtype, "cast")
+    check(ops.add_rowvec(dv(x, dev, dtype), dv(y[0], dev, dtype)), x + y[0], dtype, "add_rowvec")
+    # NCHW <-> tokens
+    img = rnd(2, 3, 5, 7, dtype=dtype, seed=11)
+    t = ops.nchw_to_tokens(dv(img, dev, dtype))
+    check(t, img.permute(0, 2, 3, 1).reshape(-1, 3), dtype, "to tokens")
+    check(ops.tokens_to_nchw(t, 2, 5, 7), img, dtype, "to nchw")
+    # sumpool (adjoint of nearest 2x)
+    u = rnd(2, 6, 8, 5, dtype=dtype, seed=12)
+    sp = torch.empty((2 * 3 * 4, 5), dtype=dtype, device=dev)
+    ops.kernels().sumpool2x2(dv(u.reshape(-1, 5), dev, dtype), sp, 2, 3, 4, 5)
+    check(sp, u.reshape(2, 3, 2, 4, 2, 5).sum(dim=(2, 4)).reshape(-1, 5), dtype, "sumpool")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cfg_ddpm_step(dev, dtype):
+    n = 2 * 4 * 8 * 8
+    x, z = rnd(n, seed=1), rnd(n, seed=2)
+    e = rnd(2 * n, dtype=dtype, seed=3)
+    s, cx, ce, sg = 7.5, 0.93, -0.21, 0.05
+    xr, er = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    ref = cx * xr + ce * (er[:n] + s * (er[n:] - er[:n])) + sg * z
+    g = rnd(n, seed=4)
+    ref.backward(g)
+    xd, ed = dv(x, dev, grad=True), dv(e, dev, dtype, grad=True)
+    out = ops.cfg_ddpm_step(xd, ed, dv(z, dev), s, cx, ce, sg)
+    out.backward(dv(g, dev))
+    check(out, ref, torch.float32, "ddpm fwd")
+    check(xd.grad, xr.grad, torch.float32, "ddpm dx")
+    check(ed.grad, er.grad, dtype, "ddpm deps")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resample_and_patchify(dev, dtype):
+    B_, C, Hf, crop, out = 2, 3, 40, (1, 2, 37, 37), (24, 24)
+    img = rnd(B_, C, Hf, Hf, dtype=dtype, seed=1)
+    mean, std = torch.tensor([0.48, 0.45, 0.40]), torch.tensor([0.27, 0.26, 0.28])
+    ir = img.clone().requires_grad_(True)
+    y0, x0, ch, cw = crop
+    ref = F.interpolate(ir[:, :, y0:y0 + ch, x0:x0 + cw], size=out, mode="bicubic", antialias=True,
+                        align_corners=False)
+    ref = (ref - mean[None, :, None, None]) / std[None, :, None, None]
+    g = rnd(B_, C, *out, dtype=dtype, seed=2)
+    ref.backward(g)
+    fwd, bwd = resize_tables(Hf, Hf, crop, out, "bicubic")
+    tab = ops.ResampleTables(fwd, bwd, Hf, Hf, out[0], out[1], dev)
+
+    def tok(t):
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    idv = dv(tok(img), dev, dtype, grad=True)
+    y = ops.resample(idv, tab, B_, C, scale=dv(1 / std, dev), shift=dv(-mean / std, dev))
+    y.backward(dv(tok(g), dev, dtype))
+    check(y, tok(ref), dtype, "resample fwd")
+    check(idv.grad, tok(ir.grad), dtype, "resample bwd")
+    # patchify == unfold with (ky, kx, c) inner order
+    P = 8
+    pr = rnd(B_, 24, 24, C, dtype=dtype, seed=3)
+    pd = dv(pr.reshape(-1, C), dev, dtype, grad=True)
+    pt = ops.patchify(pd, B_, 24, 24, C, P)
+    refp = pr.reshape(B_, 3, P, 3, P, C).permute(0, 1, 3, 2, 4, 5).reshape(B_ * 9, P * P * C)
+    check(pt, refp, dtype, "patchify")
+    gp = rnd(*refp.shape, dtype=dtype, seed=4)
+    pt.backward(dv(gp, dev, dtype))
+    refg = gp.reshape(B_, 3, 3, P, P, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, C)
+    check(pd.grad, refg, dtype, "patchify bwd")
+    ids = torch.tensor([3, 0, 7, 7, 1])
+    table = rnd(9, 16, dtype=dtype, seed=5)
+    check(ops.embedding(ids.to(dev), dv(table, dev, dtype)), table[ids], dtype, "embedding")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ls", [0.0, 0.1])
+def test_cross_entropy(dev, dtype, ls):
+    T, V = 12, 1531
+    z = rnd(T, V, dtype=dtype, seed=1, scale=3.0)
+    labels = torch.randint(0, V, (T,), generator=torch.Generator().manual_seed(2))
+    labels[:4] = -100
+    labels[9] = -100
+    zr = z.clone().requires_grad_(True)
+    ref = F.cross_entropy(zr, labels, ignore_index=-100, label_smoothing=ls)
+    (2.5 * ref).backward()
+    zd = dv(z, dev, dtype, grad=True)
+    loss, logp = ops.cross_entropy(zd, labels.to(dev), -100, ls)
+    (2.5 * loss).backward()
+    check(loss, ref, torch.float32, "ce loss", factor=5)
+    lp_ref = torch.log_softmax(z, -1).gather(1, labels.clamp(min=0)[:, None])[:, 0] * (labels >= 0)
+    check(logp, lp_ref, torch.float32, "token log-probs", factor=5)
+    check(zd.grad, zr.grad, dtype, "ce bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_disc_head(dev, dtype):
+    bs, pps = 2, 8 * 8
+    x = rnd(bs * pps, 4, dtype=dtype, seed=1)
+    w, b = rnd(4, seed=2), rnd(1, seed=3)
+    target = torch.tensor([0.0, 1.0])
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.binary_cross_entropy_with_logits(xr @ wr + br, target.repeat_interleave(pps))
+    (1.7 * ref).backward()
+    xd = dv(x, dev, dtype, grad=True)
+    wd, bd = dv(w, dev, grad=True), dv(b, dev, grad=True)
+    loss = ops.disc_head_loss(xd, wd, bd, dv(target, dev), pps)
+    (1.7 * loss).backward()
+    check(loss, ref, torch.float32, "bce", factor=5)
+    check(xd.grad, xr.grad, dtype, "bce dx")
+    check(wd.grad, wr.grad, torch.float32, "bce dw", factor=20)
+    check(bd.grad, br.grad, torch.float32, "bce db", factor=20)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attnmap_gather(dev, dtype):
+    h, res, L = 4, 12, 77
+    npix = res * res
+    a = torch.softmax(rnd(h, npix, L, seed=1), -1).to(dtype).float()
+    mask = (rnd(2, npix, seed=2) > 0).float()
+    tok_idx = torch.tensor([2, 3, 6, 7, 3], dtype=torch.int32)
+    tok_obj = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32)
+    gn, gd, ga = rnd(h, 5, seed=3), rnd(h, 5, seed=4), rnd(5, npix, seed=5)
+    ar = a.clone().requires_grad_(True)
+    sel = ar[:, :, tok_idx.long()]
+    num_r = torch.einsum("hpt,tp->ht", sel, mask[tok_obj.long()])
+    den_r = sel.sum(1)
+    avg_r = sel.mean(0).t()
+    ((num_r * gn).sum() + (den_r * gd).sum() + (avg_r * ga).sum()).backward()
+    ad = dv(a, dev, dtype, grad=True)
+    num, den, avg = ops.attnmap_gather(ad, dv(mask, dev), tok_idx.to(dev), tok_obj.to(dev))
+    ((num * dv(gn, dev)).sum() + (den * dv(gd, dev)).sum() + (avg * dv(ga, dev)).sum()).backward()
+    check(num, num_r, torch.float32, "num", factor=5)
+    check(den, den_r, torch.float32, "den", factor=5)
+    check(avg, avg_r, torch.float32, "avg", factor=5)
+    check(ad.grad, ar.grad, dtype, "damap")
+
+
+def test_adamw_with_clip(dev):
+    n = 5000
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=5e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p = dv(p0, dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 0.1)
+        opt.step()
+        gd = dv(g, dev)
+        nsq = torch.zeros(1, device=dev)
+        ops.kernels().sumsq(gd, n, nsq)
+        check(nsq, (g.double() ** 2).sum().float().reshape(1), torch.float32, "sumsq", factor=5)
+        ops.kernels().adamw(p, gd, m, v, n, 5e-3, 0.9, 0.999, 1e-8, 1e-2, step, nsq, 0.1)
+    check(p, pr, torch.float32, "adamw", factor=0.5)
