@@ -1,0 +1,127 @@
+"""K-of-N differentiable DDPM sampler — the MI355X-native counterpart of `TrainableSDPipeline.forward`
+(TrainableSDPipeline.py:20-225) and of its attribute-concentration variant
+(AttrConcenTrainableSDPipeline.py:38-279), with the same argument names and gradient topology:
+
+  * UNet runs without grad on non-trained steps, and with grad on a NON-detached input on the K trained steps
+    (`bp_on_trained=True`, TrainableSDPipeline.py:138-145);
+  * the CFG combine + scheduler step runs with grad for every i >= min(training_timesteps) (:163-167), so the loss
+    gradient reaches earlier trained steps through the (affine) DDPM chain;
+  * on `attrcon_train_steps` the cross-attention maps of the COND half are handed out per timestep
+    (`attn_dict[str(t)] = {place_res: [maps]}`, AttrConcenTrainableSDPipeline.py:239-279).  The reference runs the
+    cond and uncond halves as two UNet calls there; here it stays one batched call and the cond half of the
+    probability tensor is sliced — same arithmetic, half the launches.
+Latents stay fp32 channels-last tokens for the whole loop; CFG + DDPM step is one fused kernel.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .unet import UNet, VAEDecoder, regroup_maps
+
+
+class DDPMScheduler:
+    """DDPMScheduler with SD1.5's config (scaled_linear betas, steps_offset 1, leading spacing, epsilon prediction,
+    fixed_small variance, clip_sample False) — SURVEY.md A.4; forced by training_utils/pipeline.py:50-59."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train_timesteps = num_train_timesteps
+        self.steps_offset = steps_offset
+        self.num_inference_steps = None
+        self.timesteps = []
+
+    def set_timesteps(self, num_inference_steps):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = [i * ratio + self.steps_offset for i in range(num_inference_steps)][::-1]
+        return self.timesteps
+
+    def scale_model_input(self, sample, t):
+        return sample  # identity for DDPM
+
+    def step_coefficients(self, t):
+        """prev_sample = cx * sample + ce * eps + sigma * z (x0 eliminated from DDPMScheduler.step)."""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+        beta_t, beta_prev = 1.0 - a_t, 1.0 - a_prev
+        cur_alpha = a_t / a_prev
+        cur_beta = 1.0 - cur_alpha
+        c_x0 = math.sqrt(a_prev) * cur_beta / beta_t
+        c_xt = math.sqrt(cur_alpha) * beta_prev / beta_t
+        sigma = math.sqrt(max(beta_prev / beta_t * cur_beta, 1e-20)) if t > 0 else 0.0
+        sa, sb = math.sqrt(a_t), math.sqrt(beta_t)
+        return c_xt + c_x0 / sa, -c_x0 * sb / sa, sigma
+
+
+class TrainableSDPipeline:
+    def __init__(self, unet: UNet, vae: VAEDecoder, scheduler: DDPMScheduler | None = None):
+        self.unet, self.vae = unet, vae
+        self.scheduler = scheduler or DDPMScheduler()
+        self.dtype, self.device = unet.dtype, unet.device
+        self.attn_dict = {}
+
+    def prepare_latents(self, batch_size, height, width, generator=None, latents=None):
+        """(bs,4,h/8,w/8) NCHW fp32 -> channels-last tokens [bs*h*w, 4] fp32 on the device."""
+        h, w = height // 8, width // 8
+        if latents is None:
+            latents = torch.randn((batch_size, 4, h, w), generator=generator, dtype=torch.float32)
+        latents = latents.to(self.device, torch.float32)
+        return ops.nchw_to_tokens(latents), h, w
+
+    def forward(self, prompt_embeds, negative_prompt_embeds, height=512, width=512, training_timesteps=(),
+                num_inference_steps=50, guidance_scale=7.5, latents=None, generator=None, noises=None,
+                detach_gradient=True, bp_on_trained=True, early_exit=False, double_laststep=False,
+                fast_training=False, return_latents=False, attrcon_train_steps=(), train_layer_ls=(),
+                attn_reses=(64, 32, 16, 8), output_type="image"):
+        """prompt_embeds / negative_prompt_embeds: (bs, L, cross_dim) text-encoder outputs (the CLIP text encoder is
+        a no-grad preprocessing step outside this path).  Returns image/2+0.5 as (bs,3,H,W) [output_type 'image'] or
+        as channels-last tokens ([bs*H*W,3], H, W) ['tokens'], plus the final latents when `return_latents`."""
+        if early_exit or double_laststep or fast_training or not (detach_gradient and bp_on_trained):
+            raise NotImplementedError("only the trainer's flag set (training_script.py:558-567) is supported")
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("classifier-free guidance is always on in the CoMat trainer")
+        bs, L, _ = prompt_embeds.shape
+        dev, T = self.device, self.dtype
+        ctx = torch.cat([negative_prompt_embeds, prompt_embeds]).to(dev, torch.float32)
+        ctx = ops.cast(ctx.reshape(2 * bs * L, -1).contiguous(), T)
+        timesteps = self.scheduler.set_timesteps(num_inference_steps)
+        lat, h, w = self.prepare_latents(bs, height, width, generator, latents)
+        training_timesteps = list(training_timesteps)
+        tmin = min(training_timesteps) if training_timesteps else 0
+        places = sorted({s.split("_")[0] for s in train_layer_ls})
+        self.attn_dict = {}
+        for i, t in enumerate(timesteps):
+            train = i in training_timesteps
+            with torch.set_grad_enabled(len(training_timesteps) == 0 or i > tmin):
+                x2 = ops.concat_rows(lat, lat)
+            with torch.set_grad_enabled(train):
+                xin = x2 if train else x2.detach()
+                xin = ops.cast_grad(xin, T)
+                cap = places if (train and i in attrcon_train_steps) else ()
+                eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap)
+                if cap:
+                    cond = {p: [m[bs:] for m in lst] for p, lst in maps.items()}
+                    self.attn_dict[str(int(t))] = regroup_maps(cond, reses=attn_reses)
+            if noises is not None:
+                z = ops.nchw_to_tokens(noises[i].to(dev, torch.float32))
+            else:
+                z = torch.randn(lat.shape, generator=generator, dtype=torch.float32,
+                                device=dev if generator is None else generator.device).to(dev)
+            cx, ce, sigma = self.scheduler.step_coefficients(int(t))
+            with torch.set_grad_enabled(len(training_timesteps) == 0 or i >= tmin):
+                lat = ops.cfg_ddpm_step(lat, eps2, z, guidance_scale, cx, ce, sigma)
+        z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), T)
+        img, H, W = self.vae(z0, bs, h, w)
+        img = ops.affine(img, 0.5, 0.5)
+        if output_type == "tokens":
+            out = (img, H, W)
+        else:
+            out = ops.tokens_to_nchw(img, bs, H, W)
+        if return_latents:
+            return out, (lat if output_type == "tokens" else ops.tokens_to_nchw(lat, bs, h, w))
+        return out

@@ -1,0 +1,297 @@
+"""SD UNet (UNet2DConditionModel, SD1.5 topology) and the VAE decoder assembled from the HIP operators.
+
+Replaces the third-party model code behind `self.unet(latent_model_input, t, encoder_hidden_states=...)`
+(TrainableSDPipeline.py:144-150) and `self.vae.decode(...)` (:220).  MI355X-first choices:
+  * activations are channels-last token matrices [B*H*W, C]: 1x1 convs and attention projections are plain GEMMs on
+    the same buffer (the reference's view/transpose between NCHW and tokens disappears), 3x3 convs are implicit
+    GEMMs, skip concat is a column concat;
+  * frozen weights are stored in both orientations (forward + data-gradient) — 288 GB of HBM make the second
+    copy free — so fwd and dgrad of every conv/linear share one k-contiguous MFMA kernel;
+  * time-embedding adds, biases and residual adds ride in GEMM/conv epilogues; GroupNorm+SiLU is one kernel pair;
+  * cross-attention probabilities are written once as [B, heads, N, 77] and handed out as the "captured map"
+    (the reference clones them in AttentionStore.forward, attn_utils/tc_attn_utils.py:60-68);
+  * no activation checkpointing: all K trained UNet calls keep their activations resident (SD1.5, bs 1: < 40 GB).
+Module / parameter names follow the diffusers state dict so that real checkpoints map 1:1.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import UNetConfig, VAEConfig
+from .weights import attention_names
+
+
+def timestep_embedding(t, dim, batch, max_period=10000.0):
+    """[cos | sin] sinusoid (flip_sin_to_cos=True, freq_shift=0), computed on the host: t is a host integer."""
+    half = dim // 2
+    freqs = np.exp(-math.log(max_period) * np.arange(half, dtype=np.float32) / half).astype(np.float32)
+    args = np.float32(t) * freqs
+    emb = np.concatenate([np.cos(args), np.sin(args)]).astype(np.float32)
+    return torch.from_numpy(np.tile(emb[None], (batch, 1)))
+
+
+class LoRABank:
+    """All trainable LoRA factors of one UNet in ONE flat fp32 buffer (+ one flat gradient buffer): each factor is
+    a leaf view whose .grad is a view of the flat gradient, so autograd accumulates straight into the buffer that
+    RCCL all-reduces and the fused AdamW kernel consumes (training_utils/pipeline.py:123-144 collects the same
+    parameters in the same order: q, k, v, out per attention)."""
+
+    def __init__(self, cfg: UNetConfig, lora_sd: dict, dtype, device):
+        self.names = []
+        sizes = []
+        for path, _, _, _ in attention_names(cfg):
+            for proj in ("to_q", "to_k", "to_v", "to_out.0"):
+                for part in ("down", "up"):
+                    n = f"{path}.{proj}.lora.{part}.weight"
+                    self.names.append(n)
+                    sizes.append(tuple(lora_sd[n].shape))
+        total = sum(a * b for a, b in sizes)
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.params = {}
+        off = 0
+        self.flat.copy_(torch.cat([lora_sd[n].reshape(-1).float() for n in self.names]).to(device))
+        for n, shp in zip(self.names, sizes):
+            num = shp[0] * shp[1]
+            p = self.flat[off:off + num].view(shp).requires_grad_(True)
+            p.grad = self.flat_grad[off:off + num].view(shp)
+            self.params[n] = p
+            off += num
+        self.pairs = {}
+        for path, _, _, _ in attention_names(cfg):
+            for proj in ("to_q", "to_k", "to_v", "to_out.0"):
+                base = f"{path}.{proj}"
+                self.pairs[base] = ops.LoRAPair(self.params[base + ".lora.down.weight"],
+                                                self.params[base + ".lora.up.weight"], dtype)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for n, p in self.params.items():  # keep the views bound (autograd then accumulates in place)
+            if p.grad is None or p.grad.data_ptr() == 0:
+                raise RuntimeError("LoRA .grad view was dropped")
+
+    def mark_updated(self):
+        """call after an in-place update of `flat` by the optimizer kernel: drops the cached compute-dtype copies."""
+        for pr in self.pairs.values():
+            pr._cache = None
+
+    def set_requires_grad(self, flag: bool):
+        for p in self.params.values():
+            p.requires_grad_(flag)
+
+    def state_dict(self):
+        return {n: p.detach().clone() for n, p in self.params.items()}
+
+
+class _Mods:
+    """Weight containers built from a diffusers-named state dict."""
+
+    def __init__(self, sd, dtype, device):
+        self.sd, self.dtype, self.device = sd, dtype, device
+
+    def lin(self, name):
+        return ops.FrozenLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device)
+
+    def conv(self, name, stride=1, pad=1):
+        return ops.FrozenConv(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device,
+                              stride=stride, pad=pad)
+
+    def conv1x1(self, name):
+        w = self.sd[name + ".weight"]
+        return ops.FrozenLinear(w.reshape(w.shape[0], w.shape[1]), self.sd.get(name + ".bias"), self.dtype,
+                                self.device)
+
+    def norm(self, name):
+        f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        return f(self.sd[name + ".weight"]), f(self.sd[name + ".bias"])
+
+
+class ResBlock:
+    def __init__(self, m: _Mods, name, groups, eps, has_temb=True):
+        self.n1, self.n2 = m.norm(name + ".norm1"), m.norm(name + ".norm2")
+        self.c1, self.c2 = m.conv(name + ".conv1"), m.conv(name + ".conv2")
+        self.temb = m.lin(name + ".time_emb_proj") if has_temb else None
+        self.short = m.conv1x1(name + ".conv_shortcut") if (name + ".conv_shortcut.weight") in m.sd else None
+        self.groups, self.eps = groups, eps
+
+    def __call__(self, x, B, H, W, temb_act):
+        HW = H * W
+        h = ops.group_norm(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True)
+        b2 = None
+        if self.temb is not None:
+            with torch.no_grad():  # depends on t and frozen weights only
+                b2 = ops.cast(ops.linear(temb_act, self.temb), torch.float32)
+        h = ops.conv2d(h, self.c1, B, H, W, bias2=b2)
+        h = ops.group_norm(h, *self.n2, B, HW, G=self.groups, eps=self.eps, silu=True)
+        sc = x if self.short is None else ops.linear(x, self.short)
+        return ops.conv2d(h, self.c2, B, H, W, residual=sc)
+
+
+class CrossAttnBlock:
+    """Transformer2DModel with one BasicTransformerBlock (self-attn, cross-attn to the text context, GEGLU FFN)."""
+
+    def __init__(self, m: _Mods, name, cfg: UNetConfig, lora: LoRABank | None):
+        self.cfg = cfg
+        self.norm = m.norm(name + ".norm")
+        self.proj_in, self.proj_out = m.conv1x1(name + ".proj_in"), m.conv1x1(name + ".proj_out")
+        b = name + ".transformer_blocks.0"
+        self.ln = [m.norm(f"{b}.norm{i}") for i in (1, 2, 3)]
+        self.att = {}
+        for a in ("attn1", "attn2"):
+            for p in ("to_q", "to_k", "to_v", "to_out.0"):
+                key = f"{b}.{a}.{p}"
+                self.att[(a, p)] = (m.lin(key), lora.pairs[key] if lora is not None else None)
+        self.ff1, self.ff2 = m.lin(f"{b}.ff.net.0.proj"), m.lin(f"{b}.ff.net.2")
+
+    def _attn(self, a, x, src, B, N, L):
+        q = ops.lora_linear(x, *self.att[(a, "to_q")])
+        k = ops.lora_linear(src, *self.att[(a, "to_k")])
+        v = ops.lora_linear(src, *self.att[(a, "to_v")])
+        heads = self.cfg.num_heads
+        return ops.attention(q, k, v, B, N, L, heads, q.shape[1] // heads)
+
+    def __call__(self, x, B, H, W, ctx, L, want_probs):
+        N = H * W
+        h = ops.group_norm(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
+        h = ops.linear(h, self.proj_in)
+        y = ops.layer_norm(h, *self.ln[0])
+        o, _ = self._attn("attn1", y, y, B, N, N)
+        h = ops.lora_linear(o, *self.att[("attn1", "to_out.0")], residual=h)
+        o, probs = self._attn("attn2", ops.layer_norm(h, *self.ln[1]), ctx, B, N, L)
+        h = ops.lora_linear(o, *self.att[("attn2", "to_out.0")], residual=h)
+        f = ops.geglu(ops.linear(ops.layer_norm(h, *self.ln[2]), self.ff1))
+        h = ops.linear(f, self.ff2, residual=h)
+        return ops.linear(h, self.proj_out, residual=x), (probs if want_probs else None)
+
+
+class UNet:
+    def __init__(self, cfg: UNetConfig, sd: dict, dtype=torch.bfloat16, device="cuda", lora: LoRABank | None = None):
+        self.cfg, self.dtype, self.device, self.lora = cfg, dtype, device, lora
+        m = _Mods(sd, dtype, device)
+        g = cfg.norm_groups
+        self.t1, self.t2 = m.lin("time_embedding.linear_1"), m.lin("time_embedding.linear_2")
+        self.conv_in = m.conv("conv_in")
+        nb = len(cfg.block_out_channels)
+        self.down, self.up = [], []
+        for i in range(nb):
+            res = [ResBlock(m, f"down_blocks.{i}.resnets.{j}", g, 1e-5) for j in range(cfg.layers_per_block)]
+            att = [CrossAttnBlock(m, f"down_blocks.{i}.attentions.{j}", cfg, lora)
+                   for j in range(cfg.layers_per_block)] if cfg.down_attn[i] else None
+            ds = m.conv(f"down_blocks.{i}.downsamplers.0.conv", stride=2, pad=1) if i < nb - 1 else None
+            self.down.append((res, att, ds))
+        self.mid = (ResBlock(m, "mid_block.resnets.0", g, 1e-5), CrossAttnBlock(m, "mid_block.attentions.0", cfg, lora),
+                    ResBlock(m, "mid_block.resnets.1", g, 1e-5))
+        for i in range(nb):
+            res = [ResBlock(m, f"up_blocks.{i}.resnets.{j}", g, 1e-5) for j in range(cfg.layers_per_block + 1)]
+            att = [CrossAttnBlock(m, f"up_blocks.{i}.attentions.{j}", cfg, lora)
+                   for j in range(cfg.layers_per_block + 1)] if cfg.up_attn[i] else None
+            us = m.conv(f"up_blocks.{i}.upsamplers.0.conv") if i < nb - 1 else None
+            self.up.append((res, att, us))
+        self.norm_out = m.norm("conv_norm_out")
+        self.conv_out = m.conv("conv_out")
+
+    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=()):
+        """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
+        maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}."""
+        cfg = self.cfg
+        with torch.no_grad():
+            te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
+            te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
+            temb_act = ops.linear(te, self.t2, act=ops.ACT_SILU)  # SiLU(temb): every ResBlock consumes silu(temb)
+        maps = {p: [] for p in capture_places}
+        h = ops.conv2d(x, self.conv_in, B, H, W)
+        skips = [h]
+        hh, ww = H, W
+        for res, att, ds in self.down:
+            for j, r in enumerate(res):
+                h = r(h, B, hh, ww, temb_act)
+                if att is not None:
+                    h, p = att[j](h, B, hh, ww, ctx, L, "down" in maps)
+                    if p is not None:
+                        maps["down"].append(p)
+                skips.append(h)
+            if ds is not None:
+                h = ops.conv2d(h, ds, B, hh, ww)
+                hh, ww = ops.conv_out_hw(ds, hh, ww)
+                skips.append(h)
+        h = self.mid[0](h, B, hh, ww, temb_act)
+        h, p = self.mid[1](h, B, hh, ww, ctx, L, "mid" in maps)
+        if p is not None:
+            maps["mid"].append(p)
+        h = self.mid[2](h, B, hh, ww, temb_act)
+        for res, att, us in self.up:
+            for j, r in enumerate(res):
+                h = ops.concat_cols(h, skips.pop())
+                h = r(h, B, hh, ww, temb_act)
+                if att is not None:
+                    h, p = att[j](h, B, hh, ww, ctx, L, "up" in maps)
+                    if p is not None:
+                        maps["up"].append(p)
+            if us is not None:
+                h = ops.conv2d(h, us, B, hh, ww, ups=2)
+                hh, ww = hh * 2, ww * 2
+        h = ops.group_norm(h, *self.norm_out, B, hh * ww, G=cfg.norm_groups, eps=1e-5, silu=True)
+        return ops.conv2d(h, self.conv_out, B, hh, ww), maps
+
+
+def regroup_maps(maps: dict, reses=(64, 32, 16, 8), poses=("down", "mid", "up")):
+    """Same key/shape schema as the reference's get_cross_attn_map_from_unet (attn_utils/tc_attn_utils.py:198-217):
+    {f"{pos}_{res}": [Tensor(B*heads, res, res, L), ...]} — views of the stored probabilities, no copy."""
+    out = {}
+    for pos in poses:
+        for res in reses:
+            lst = [p.reshape(-1, res, res, p.shape[-1]) for p in maps.get(pos, []) if p.shape[2] == res * res]
+            if lst:
+                out[f"{pos}_{res}"] = lst
+    return out
+
+
+class VAEDecoder:
+    """AutoencoderKL.decode (post_quant_conv + decoder); frozen, gradient flows to the latents only."""
+
+    def __init__(self, cfg: VAEConfig, sd: dict, dtype=torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, device
+        m = _Mods(sd, dtype, device)
+        g = cfg.norm_groups
+        self.pq = m.conv1x1("post_quant_conv")
+        self.conv_in = m.conv("decoder.conv_in")
+        self.mid0 = ResBlock(m, "decoder.mid_block.resnets.0", g, 1e-6, has_temb=False)
+        a = "decoder.mid_block.attentions.0"
+        self.a_norm = m.norm(a + ".group_norm")
+        self.a_q, self.a_k, self.a_v, self.a_o = (m.lin(f"{a}.{n}") for n in ("to_q", "to_k", "to_v", "to_out.0"))
+        self.mid1 = ResBlock(m, "decoder.mid_block.resnets.1", g, 1e-6, has_temb=False)
+        self.up = []
+        nb = len(cfg.block_out_channels)
+        for i in range(nb):
+            res = [ResBlock(m, f"decoder.up_blocks.{i}.resnets.{j}", g, 1e-6, has_temb=False)
+                   for j in range(cfg.layers_per_block + 1)]
+            us = m.conv(f"decoder.up_blocks.{i}.upsamplers.0.conv") if i < nb - 1 else None
+            self.up.append((res, us))
+        self.norm_out = m.norm("decoder.conv_norm_out")
+        self.conv_out = m.conv("decoder.conv_out")
+
+    def __call__(self, z, B, H, W):
+        """z: [B*H*W, 4] latent tokens already divided by the scaling factor -> ([B*H'*W', 3], H', W')."""
+        g = self.cfg.norm_groups
+        h = ops.linear(z, self.pq)
+        h = ops.conv2d(h, self.conv_in, B, H, W)
+        h = self.mid0(h, B, H, W, None)
+        N = H * W
+        hn = ops.group_norm(h, *self.a_norm, B, N, G=g, eps=1e-6, silu=False)
+        q, k, v = ops.linear(hn, self.a_q), ops.linear(hn, self.a_k), ops.linear(hn, self.a_v)
+        o, _ = ops.attention(q, k, v, B, N, N, 1, q.shape[1])
+        h = ops.linear(o, self.a_o, residual=h)
+        h = self.mid1(h, B, H, W, None)
+        hh, ww = H, W
+        for res, us in self.up:
+            for r in res:
+                h = r(h, B, hh, ww, None)
+            if us is not None:
+                h = ops.conv2d(h, us, B, hh, ww, ups=2)
+                hh, ww = hh * 2, ww * 2
+        h = ops.group_norm(h, *self.norm_out, B, hh * ww, G=g, eps=1e-6, silu=True)
+        return ops.conv2d(h, self.conv_out, B, hh, ww), hh, ww

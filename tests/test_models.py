@@ -1,0 +1,141 @@
+"""UNet / VAE / sampler parity on the tiny configuration: comat_amd (HIP kernels, or the ABI simulator for the
+host-logic run) against the CPU oracle (oracle/sd.py) on the same seeded inputs.  fp32: gradients of the LoRA
+parameters within 1e-3 relative; bf16: within the bf16 tolerance of helpers.tol."""
+import pytest
+import torch
+
+from comat_amd import config
+from comat_amd.pipeline import DDPMScheduler, TrainableSDPipeline
+from comat_amd.unet import LoRABank, UNet, VAEDecoder, regroup_maps
+from helpers import check, oracle_cfgs, rel_l2, tiny_weights, tok, untok
+from oracle import sd as O
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(*shape, seed, dtype=torch.float32):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)).to(dtype).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unet_forward_backward(dev, dtype):
+    usd, _, lsd = tiny_weights(dtype)
+    ocfg, _ = oracle_cfgs()
+    B, h, w, L = 2, 8, 8, 7
+    x = rnd(B, 4, h, w, seed=1, dtype=dtype)
+    ctx = rnd(B, L, config.TINY_UNET.cross_attention_dim, seed=2, dtype=dtype)
+    g = rnd(B, 4, h, w, seed=3, dtype=dtype)
+    gmap = 0.05 * rnd(B * 2, 4, 4, L, seed=4, dtype=dtype)
+    # oracle
+    lo = {k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    xo = x.clone().requires_grad_(True)
+    store = O.AttentionStore(["up_4", "mid_2"])
+    eo = O.unet_forward(usd, ocfg, xo, 334, ctx, lo, store)
+    mo = store.maps(reses=(8, 4, 2))
+    ((eo * g).sum() + (mo["up_4"][1] * gmap).sum()).backward()
+    # comat_amd
+    bank = LoRABank(config.TINY_UNET, lsd, dtype, dev)
+    unet = UNet(config.TINY_UNET, usd, dtype, dev, bank)
+    xd = tok(x).to(dev, dtype).requires_grad_(True)
+    e, maps = unet(xd, B, h, w, 334, tok_ctx(ctx, dev, dtype), L, capture_places=("mid", "up"))
+    md = regroup_maps(maps, reses=(8, 4, 2))
+    assert sorted(md.keys()) == sorted(mo.keys())
+    for k in mo:
+        assert len(md[k]) == len(mo[k])
+        for a, b in zip(md[k], mo[k]):
+            check(a, b, dtype, f"map {k}")
+    bank.zero_grad()
+    ((e.float() * tok(g).to(dev)).sum() + (md["up_4"][1].float() * gmap.to(dev)).sum()).backward()
+    check(e, tok(eo), dtype, "eps")
+    check(xd.grad, tok(xo.grad), dtype, "d eps / d x", factor=3)
+    worst = 0.0
+    for n, p in bank.params.items():
+        worst = max(worst, rel_l2(p.grad, lo[n].grad))
+    assert worst < (1e-3 if dtype == torch.float32 else 0.15), f"LoRA grad rel-L2 {worst:.3e}"
+    # the flat gradient buffer IS the parameters' .grad storage
+    assert bank.flat_grad.abs().sum() > 0
+
+
+def tok_ctx(ctx, dev, dtype):
+    return ctx.reshape(-1, ctx.shape[-1]).to(dev, dtype).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vae_decode(dev, dtype):
+    _, vsd, _ = tiny_weights(dtype)
+    _, ovc = oracle_cfgs()
+    B, h, w = 1, 8, 8
+    z = rnd(B, 4, h, w, seed=5, dtype=dtype)
+    zo = z.clone().requires_grad_(True)
+    io = O.vae_decode(vsd, ovc, zo)
+    g = rnd(*io.shape, seed=6, dtype=dtype)
+    (io * g).sum().backward()
+    vae = VAEDecoder(config.TINY_VAE, vsd, dtype, dev)
+    zd = tok(z).to(dev, dtype).requires_grad_(True)
+    img, H, W = vae(zd, B, h, w)
+    assert (H, W) == tuple(io.shape[2:])
+    (img.float() * tok(g).to(dev)).sum().backward()
+    check(img, tok(io), dtype, "vae image")
+    check(zd.grad, tok(zo.grad), dtype, "vae dz", factor=3)
+
+
+def test_scheduler_known_answers():
+    """SURVEY.md §8(c) known answers of the DDPM schedule."""
+    s = DDPMScheduler()
+    ac = s.alphas_cumprod
+    for idx, val in ((0, 0.99914998), (1, 0.99829602), (501, 0.27499884), (981, 0.00577550), (999, 0.00466010)):
+        assert abs(float(ac[idx]) - val) < 2e-7, (idx, float(ac[idx]))
+    assert s.set_timesteps(2) == [501, 1]
+    assert s.set_timesteps(5) == [801, 601, 401, 201, 1]
+    ts = s.set_timesteps(50)
+    assert ts[0] == 981 and ts[-1] == 1 and ts[1] == 961 and len(ts) == 50
+    s.set_timesteps(2)
+    o = O.DDPM()
+    o.set_timesteps(2)
+    c_x0, c_xt, sigma, sa, sb = o.coefficients(501)
+    assert abs(c_x0 - 0.99850076) < 1e-6 and abs(c_xt - 0.00123356) < 1e-6 and abs(sigma ** 2 - 0.00170287) < 1e-7
+    cx, ce, sg = s.step_coefficients(501)
+    assert abs(cx - (c_xt + c_x0 / sa)) < 1e-6 and abs(ce + c_x0 * sb / sa) < 1e-6 and abs(sg - sigma) < 1e-9
+    assert s.step_coefficients(1)[2] > 0.0  # t=1 > 0 still adds noise; only t == 0 would not
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("attrcon", [False, True])
+def test_sampler_k_of_n(dev, dtype, attrcon):
+    """TrainableSDPipeline.forward: N=3 steps, K=2 trained (steps 1,2), CFG 7.5, VAE decode, with the reference's
+    gradient gating; attrcon variant also hands out the cross-attention maps of the trained step."""
+    usd, vsd, lsd = tiny_weights(dtype)
+    ocfg, ovc = oracle_cfgs()
+    bs, h, w, L = 1, 8, 8, 7
+    cd = config.TINY_UNET.cross_attention_dim
+    lat = rnd(bs, 4, h, w, seed=10)
+    cu, cc = rnd(bs, L, cd, seed=11, dtype=dtype), rnd(bs, L, cd, seed=12, dtype=dtype)
+    noises = [rnd(bs, 4, h, w, seed=20 + i) for i in range(3)]
+    layers = ["mid_2", "up_4", "up_8"]
+    kw = dict(attrcon_steps=[2], train_layer_ls=layers, reses=(8, 4, 2)) if attrcon else {}
+    lo = {k: v.clone().requires_grad_(True) for k, v in lsd.items()}
+    img_o, lat_o, ad_o = O.sample_with_grad(usd, ocfg, vsd, ovc, lo, cu, cc, lat, noises, 3, [1, 2], 7.5, **kw)
+    gi = rnd(*img_o.shape, seed=30)
+    loss_o = (img_o * gi).sum()
+    if attrcon:
+        loss_o = loss_o + sum((m * m).sum() for m in ad_o["1"]["up_4"])
+    loss_o.backward()
+
+    bank = LoRABank(config.TINY_UNET, lsd, dtype, dev)
+    pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, dev, bank), VAEDecoder(config.TINY_VAE, vsd, dtype, dev))
+    kw2 = dict(attrcon_train_steps=[2], train_layer_ls=layers, attn_reses=(8, 4, 2)) if attrcon else {}
+    img, latf = pipe.forward(cc, cu, height=8 * h, width=8 * w, training_timesteps=[1, 2], num_inference_steps=3,
+                             guidance_scale=7.5, latents=lat, noises=noises, return_latents=True, **kw2)
+    bank.zero_grad()
+    loss = (img.float() * gi.to(dev)).sum()
+    if attrcon:
+        assert list(pipe.attn_dict.keys()) == ["1"] and sorted(pipe.attn_dict["1"]) == sorted(ad_o["1"])
+        for k in ad_o["1"]:
+            for a, b in zip(pipe.attn_dict["1"][k], ad_o["1"][k]):
+                check(a, b, dtype, f"attn_dict {k}", factor=2)
+        loss = loss + sum((m.float() * m.float()).sum() for m in pipe.attn_dict["1"]["up_4"])
+    loss.backward()
+    check(latf, lat_o, dtype, "final latents", factor=3)
+    check(img, img_o, dtype, "image", factor=3)
+    worst = max(rel_l2(p.grad, lo[n].grad) for n, p in bank.params.items())
+    assert worst < (1e-3 if dtype == torch.float32 else 0.15), f"LoRA grad rel-L2 {worst:.3e}"
