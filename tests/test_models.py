@@ -138,4 +138,6 @@ def test_sampler_k_of_n(dev, dtype, attrcon):
     check(latf, lat_o, dtype, "final latents", factor=3)
     check(img, img_o, dtype, "image", factor=3)
     worst = max(rel_l2(p.grad, lo[n].grad) for n, p in bank.params.items())
-    assert worst < (1e-3 if dtype == torch.float32 else 0.15), f"LoRA grad rel-L2 {worst:.3e}"
+    total = rel_l2(bank.flat_grad, torch.cat([lo[n].grad.reshape(-1) for n in bank.names]))
+    assert worst < (1e-3 if dtype == torch.float32 else 0.3), f"LoRA grad rel-L2 (worst tensor) {worst:.3e}"
+    assert total < (1e-3 if dtype == torch.float32 else 0.1), f"LoRA grad rel-L2 (flat buffer) {total:.3e}"
