@@ -62,6 +62,6 @@ BLIP_LARGE = BlipConfig()
 
 TINY_UNET = UNetConfig(block_out_channels=(32, 64, 64), down_attn=(True, True, False), layers_per_block=1,
                        num_heads=2, cross_attention_dim=24, norm_groups=8, lora_rank=4)
-TINY_VAE = VAEConfig(block_out_channels=(16, 32), layers_per_block=1, norm_groups=8)
+TINY_VAE = VAEConfig(block_out_channels=(8, 16, 16, 32), layers_per_block=1, norm_groups=8)
 TINY_BLIP = BlipConfig(image_size=32, patch_size=8, v_hidden=32, v_layers=2, v_heads=2, v_mlp=64, vocab_size=97,
                        t_hidden=24, t_layers=2, t_heads=2, t_mlp=48, max_pos=32)

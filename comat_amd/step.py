@@ -1,0 +1,180 @@
+"""One CoMat optimisation step on MI355X — the counterpart of the step body `training_script.py:556-694`:
+
+    sample K trained steps -> K-of-N differentiable denoise -> VAE decode -> random 510^2 crop -> BLIP reward
+    [-> + w_g * G_loss] [-> + 1e-3 * token_loss + 5e-5 * pixel_loss] -> backward -> all-reduce(mean) of the flat LoRA
+    gradient -> clip(0.1) + AdamW (one fused pass)  ||  D step: D_loss on [fake.detach(); real] -> backward ->
+    all-reduce -> clip(1.0) + AdamW.
+
+MI355X-first scheduling: the G-gradient all-reduce (RCCL over xGMI) is launched asynchronously right after
+G-backward and overlaps the whole D forward/backward; the per-step barrier of the reference
+(training_script.py:716) is dropped.  Optimizer state lives in flat fp32 buffers next to the flat parameter and
+gradient buffers, so clip + AdamW is one HBM pass per buffer.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from .blip import Blip
+from .dist import GradReducer
+from .gan import D_sd
+from .losses import mask_loss
+from .pipeline import TrainableSDPipeline
+from .unet import LoRABank
+
+
+@dataclass
+class StepConfig:
+    """Path-relevant flags of training_utils/arguments.py with the values of scripts/sd15.sh."""
+    resolution: int = 512
+    total_step: int = 50
+    K: int = 5
+    cfg_scale: float = 7.5
+    gan_loss: bool = True
+    gan_loss_weight: float = 1.0
+    attrcon: bool = False
+    attrcon_train_steps: int = 2
+    train_layer_ls: tuple = ("mid_8", "up_16", "up_32", "up_64")
+    attn_reses: tuple = (64, 32, 16, 8)
+    mask_token_loss_weight: float = 1e-3
+    mask_pixel_loss_weight: float = 5e-5
+    lr: float = 5e-5
+    lr_D: float = 5e-5
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_beta1_D: float = 0.0
+    adam_beta2_D: float = 0.999
+    adam_weight_decay: float = 1e-2
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 0.1
+    max_grad_norm_D: float = 1.0
+    label_smoothing: float = 0.1
+
+
+class FlatAdamW:
+    """clip_grad_norm_ + AdamW over flat fp32 buffers (one or more segments sharing the global norm)."""
+
+    def __init__(self, segments, lr, betas, eps, weight_decay, max_norm):
+        self.segments = segments  # list of (param_flat, grad_flat)
+        self.m = [torch.zeros_like(p) for p, _ in segments]
+        self.v = [torch.zeros_like(p) for p, _ in segments]
+        self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
+        self.t = 0
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=segments[0][0].device)
+
+    def step(self):
+        k = ops.kernels()
+        self.t += 1
+        self.gnorm_sq.zero_()
+        for _, g in self.segments:
+            k.sumsq(g, g.numel(), self.gnorm_sq)
+        for (p, g), m, v in zip(self.segments, self.m, self.v):
+            k.adamw(p, g, m, v, p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                    self.gnorm_sq, self.max_norm)
+
+
+def sample_training_steps(total_step, K, rng: random.Random):
+    """training_script.py:563-566"""
+    interval = total_step // K
+    max_start = total_step - interval * (K - 1) - 1
+    start = rng.randint(0, max_start)
+    return list(range(start, total_step, interval))
+
+
+def sample_crop(resolution, rng: random.Random):
+    """training_script.py:606-609: offsets in [0, resolution // 224], crop size resolution - offset_range."""
+    offset_range = resolution // 224
+    ox, oy = rng.randint(0, offset_range), rng.randint(0, offset_range)
+    size = resolution - offset_range
+    return (ox, oy, size, size)  # the reference slices dim 2 with x and dim 3 with y: (row0, col0, h, w)
+
+
+class CoMatTrainer:
+    def __init__(self, pipeline: TrainableSDPipeline, bank: LoRABank, blip: Blip, disc: D_sd | None,
+                 cfg: StepConfig, seed=0):
+        self.pipe, self.bank, self.blip, self.D, self.cfg = pipeline, bank, blip, disc, cfg
+        self.opt = FlatAdamW([(bank.flat, bank.flat_grad)], cfg.lr, (cfg.adam_beta1, cfg.adam_beta2),
+                             cfg.adam_epsilon, cfg.adam_weight_decay, cfg.max_grad_norm)
+        self.opt_D = None
+        if disc is not None:
+            self.opt_D = FlatAdamW([(disc.bank.flat, disc.bank.flat_grad), (disc.head, disc.head_grad)], cfg.lr_D,
+                                   (cfg.adam_beta1_D, cfg.adam_beta2_D), cfg.adam_epsilon, cfg.adam_weight_decay,
+                                   cfg.max_grad_norm_D)
+        self.rng = random.Random(seed)
+        self.reducer = GradReducer()
+        self.device = pipeline.device
+
+    def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
+        """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
+        (bs,L,C); blip_input_ids, blip_attention_mask (bs,T); optional latents (bs,4,h,w), noises [N x (bs,4,h,w)],
+        gan_null_embeds (bs,L,C), real_latents (bs,4,h,w), masks (list of [n_obj,H,W] bool arrays), attributes."""
+        cfg = self.cfg
+        res = cfg.resolution
+        if training_steps is None:
+            training_steps = sample_training_steps(cfg.total_step, cfg.K, self.rng)
+        kw = {}
+        if cfg.attrcon:
+            if attrcon_steps is None:  # random.choices samples WITH replacement (training_script.py:590)
+                attrcon_steps = self.rng.choices(training_steps, k=min(cfg.attrcon_train_steps, len(training_steps)))
+            kw = dict(attrcon_train_steps=attrcon_steps, train_layer_ls=cfg.train_layer_ls, attn_reses=cfg.attn_reses)
+        (img, H, W), lat = self.pipe.forward(
+            batch["prompt_embeds"], batch["negative_prompt_embeds"], height=res, width=res,
+            training_timesteps=training_steps, num_inference_steps=cfg.total_step, guidance_scale=cfg.cfg_scale,
+            latents=batch.get("latents"), noises=batch.get("noises"), return_latents=True, output_type="tokens", **kw)
+        bs = batch["prompt_embeds"].shape[0]
+        if crop is None:
+            crop = sample_crop(res, self.rng)
+        reward, logp = self.blip.score(img, bs, H, W, batch["blip_input_ids"], batch["blip_attention_mask"], crop=crop,
+                                       label_smoothing=cfg.label_smoothing)
+        out = dict(Blip=reward.detach(), token_logp=logp, training_steps=training_steps, crop=crop)
+        loss = -reward
+        h, w = res // 8, res // 8
+        if cfg.gan_loss:
+            G_loss = self.D.D_sd_pipeline_forward(lat, "G", negative_prompt_embeds=batch["gan_null_embeds"],
+                                                  num_inference_steps=cfg.total_step, h=h, w=w)
+            loss = loss + cfg.gan_loss_weight * G_loss
+            out["G_loss"] = G_loss.detach()
+        if cfg.attrcon:
+            tl, pl = mask_loss(self.pipe.attn_dict, batch["masks"], batch["attributes"], cfg.train_layer_ls, bs,
+                               self.device)
+            loss = loss + cfg.mask_token_loss_weight * tl + cfg.mask_pixel_loss_weight * pl
+            out["token_loss"], out["pixel_loss"] = tl.detach(), pl.detach()
+            self.pipe.attn_dict = {}
+        out["loss"] = loss
+        out["training_latents"] = lat
+        out["image"] = (img, H, W)
+        return out
+
+    def train_step(self, batch, **fixed):
+        """Full step: G forward/backward/update, then the D step.  Returns a dict of detached scalars (tensors: no
+        host sync here) plus `training_steps` / `crop`."""
+        cfg = self.cfg
+        self.bank.set_requires_grad(True)
+        self.bank.zero_grad()
+        out = self.compute_losses(batch, **fixed)
+        out["loss"].backward()
+        self.reducer.start(self.bank.flat_grad)  # async RCCL all-reduce; overlaps the D step below
+        logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
+        logs["step_loss"] = out["loss"].detach()
+        logs["training_steps"], logs["crop"] = out["training_steps"], out["crop"]
+        if cfg.gan_loss:
+            h = w = cfg.resolution // 8
+            self.D.zero_grad()
+            real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
+            D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
+                                                  negative_prompt_embeds=batch["gan_null_embeds"],
+                                                  num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
+            D_loss.backward()
+            logs["D_loss"] = D_loss.detach()
+        self.reducer.finish()
+        self.opt.step()
+        self.bank.mark_updated()
+        if cfg.gan_loss:
+            self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
+            self.reducer.finish()
+            self.opt_D.step()
+            self.D.bank.mark_updated()
+        return logs

@@ -61,7 +61,7 @@ SD15_UNET = UNetConfig()
 SD15_VAE = VAEConfig()
 TINY_UNET = UNetConfig(block_out_channels=(32, 64, 64), down_attn=(True, True, False), layers_per_block=1,
                        num_heads=2, cross_attention_dim=24, norm_groups=8, lora_rank=4)
-TINY_VAE = VAEConfig(block_out_channels=(16, 32), layers_per_block=1, norm_groups=8)
+TINY_VAE = VAEConfig(block_out_channels=(8, 16, 16, 32), layers_per_block=1, norm_groups=8)
 
 
 # ----------------------------------------------------------------------------------------------------------------

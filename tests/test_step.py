@@ -1,0 +1,118 @@
+"""Whole-step parity on the tiny configuration: comat_amd.step.CoMatTrainer (HIP kernels / ABI simulator) against the
+CPU oracle step (oracle/step.py): loss terms, token-level concept scores, generator-LoRA gradients (fp32: 1e-3
+relative), discriminator gradients, and the parameters after clip + AdamW."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from comat_amd import config, weights
+from comat_amd.blip import Blip
+from comat_amd.gan import D_sd
+from comat_amd.pipeline import TrainableSDPipeline
+from comat_amd.step import CoMatTrainer, StepConfig, sample_crop, sample_training_steps
+from comat_amd.unet import LoRABank, UNet, VAEDecoder
+from helpers import check, oracle_cfgs, rel_l2, tiny_weights
+from oracle import blip as OB
+from oracle import step as OS
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def make_world(dtype, dev, attrcon):
+    usd, vsd, lsd = tiny_weights(dtype)
+    q = lambda d: {k: v.to(dtype).float() for k, v in d.items()}
+    bsd = q(weights.make_blip_weights(config.TINY_BLIP, perturb_norms=True))
+    dsd = q(weights.make_unet_weights(config.TINY_UNET, seed=77, perturb_norms=True))
+    dl = q({k: (v * 5 if k.endswith("up.weight") else v) for k, v in weights.make_lora_weights(config.TINY_UNET, seed=78).items()})
+    g = torch.Generator().manual_seed(5)
+    head_w, head_b = torch.randn(4, generator=g) * 0.5, torch.randn(1, generator=g) * 0.1
+    cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=attrcon, attrcon_train_steps=1,
+                     train_layer_ls=("mid_2", "up_4", "up_8"), attn_reses=(8, 4, 2), lr=1e-2, lr_D=1e-2,
+                     mask_token_loss_weight=0.5, mask_pixel_loss_weight=0.1)
+    bs, L, cd, T = 2, 7, config.TINY_UNET.cross_attention_dim, 9
+    r = lambda *s: torch.randn(*s, generator=g)
+    ids = torch.randint(1, config.TINY_BLIP.vocab_size, (bs, T), generator=g)
+    ids[1, 7:] = 0
+    masks = []
+    for b in range(bs):
+        m = np.zeros((2, 64, 64), dtype=bool)
+        m[0, 5:30, 8:40] = True
+        m[1, 34:60, 20:64] = True
+        masks.append(m)
+    batch = dict(prompt_embeds=r(bs, L, cd).to(dtype).float(), negative_prompt_embeds=r(bs, L, cd).to(dtype).float(),
+                 gan_null_embeds=r(bs, L, cd).to(dtype).float(), latents=r(bs, 4, 8, 8),
+                 noises=[r(bs, 4, 8, 8) for _ in range(3)], real_latents=r(bs, 4, 8, 8),
+                 blip_input_ids=ids, blip_attention_mask=(ids != 0).long(), masks=masks,
+                 attributes=[[[2, 3], [5]], [[1], [4, 6]]])
+    # oracle world
+    ucfg, vcfg = oracle_cfgs()
+    W = dict(unet=usd, vae=vsd, blip=bsd, d_unet=dsd, ucfg=ucfg, vcfg=vcfg,
+             bcfg=OB.BlipConfig(**dataclasses.asdict(config.TINY_BLIP)),
+             lora={k: v.clone().requires_grad_(True) for k, v in lsd.items()},
+             d_lora={k: v.clone().requires_grad_(True) for k, v in dl.items()},
+             head_w=head_w.clone().requires_grad_(True), head_b=head_b.clone().requires_grad_(True))
+    # product world
+    bank = LoRABank(config.TINY_UNET, lsd, dtype, dev)
+    pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, dev, bank), VAEDecoder(config.TINY_VAE, vsd, dtype, dev))
+    dbank = LoRABank(config.TINY_UNET, dl, dtype, dev)
+    disc = D_sd(UNet(config.TINY_UNET, dsd, dtype, dev, dbank), dbank, head_w, head_b)
+    trainer = CoMatTrainer(pipe, bank, Blip(config.TINY_BLIP, bsd, dtype, dev), disc, cfg, seed=0)
+    return cfg, batch, W, trainer
+
+
+def test_step_sampling_rules():
+    import random
+    rng = random.Random(0)
+    for _ in range(50):
+        ts = sample_training_steps(50, 5, rng)
+        assert len(ts) == 5 and ts[1] - ts[0] == 10 and 0 <= ts[0] <= 9 and ts[-1] < 50
+        y, x, h, w = sample_crop(512, rng)
+        assert h == w == 510 and 0 <= y <= 2 and 0 <= x <= 2
+    assert sample_training_steps(5, 5, rng) == [0, 1, 2, 3, 4]
+    assert sample_training_steps(2, 2, rng) == [0, 1]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("attrcon", [False, True])
+def test_train_step_matches_oracle(dev, dtype, attrcon):
+    cfg, batch, W, trainer = make_world(dtype, dev, attrcon)
+    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
+    opt = torch.optim.AdamW(list(W["lora"].values()), lr=cfg.lr, betas=(cfg.adam_beta1, cfg.adam_beta2),
+                            eps=cfg.adam_epsilon, weight_decay=cfg.adam_weight_decay)
+    d_params = list(W["d_lora"].values()) + [W["head_w"], W["head_b"]]
+    opt_D = torch.optim.AdamW(d_params, lr=cfg.lr_D, betas=(cfg.adam_beta1_D, cfg.adam_beta2_D), eps=cfg.adam_epsilon,
+                              weight_decay=cfg.adam_weight_decay)
+    ref = OS.train_step(W, batch, cfg, ts, crop, acs, opt, opt_D)
+    logs = trainer.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    f = 1.0 if dtype == torch.float32 else 4.0
+    check(logs["Blip"], ref["Blip"], dtype, "Blip reward", factor=f)
+    check(logs["G_loss"], ref["G_loss"], dtype, "G_loss", factor=f)
+    check(logs["D_loss"], ref["D_loss"], dtype, "D_loss", factor=f)
+    check(logs["step_loss"], ref["loss"], dtype, "step loss", factor=f)
+    if attrcon:
+        check(logs["token_loss"], ref["token_loss"], dtype, "token_loss", factor=f)
+        check(logs["pixel_loss"], ref["pixel_loss"], dtype, "pixel_loss", factor=f)
+    # gradients as left in the flat buffers by backward (before the optimizer consumed them)
+    bank, dbank = trainer.bank, trainer.D.bank
+    g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
+    d_ref = torch.cat([ref["d_grads"][n].reshape(-1) for n in dbank.names])
+    lim = 1e-3 if dtype == torch.float32 else 0.12
+    assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
+    assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
+    hg = torch.cat([ref["head_grads"][0].reshape(-1), ref["head_grads"][1].reshape(-1)])
+    assert rel_l2(trainer.D.head_grad, hg) < lim * 3
+    # parameters after clip + AdamW (the update is sign-like at step 1: compare the update direction/size)
+    p_ref = torch.cat([W["lora"][n].detach().reshape(-1) for n in bank.names])
+    assert rel_l2(bank.flat, p_ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+    pd_ref = torch.cat([W["d_lora"][n].detach().reshape(-1) for n in dbank.names])
+    assert rel_l2(dbank.flat, pd_ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_second_step_uses_updated_lora(sim):
+    """the cached compute-dtype LoRA copies must be refreshed after the optimizer kernel updated the flat buffer."""
+    cfg, batch, W, trainer = make_world(torch.bfloat16, sim, False)
+    l1 = trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    l2 = trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    assert abs(float(l1["step_loss"]) - float(l2["step_loss"])) > 1e-6
