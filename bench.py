@@ -1,0 +1,255 @@
+"""bench.py — CoMat train-step throughput on MI355X (BASELINE.json metric: train-step images/sec, SD1.5 512^2, bs=1/GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload: SD1.5 UNet (859.5 M params, LoRA r=128 on all 32 attentions), 512x512
+(latent 64x64), 1 prompt per GPU, N=5 denoise steps all 5 with gradient, CFG 7.5, VAE decode, 510^2 crop ->
+BLIP-large caption CE (concept matching) + GAN fidelity loss (second SD1.5 UNet discriminator, G side and D side),
+backward, all-reduce(mean) of the flat LoRA gradients, clip + AdamW for G and D.  bf16 storage / fp32 accumulate.
+Synthetic, seeded weights and inputs (no checkpoints or tokenizer offline).  One "step" = one such optimisation step;
+value = total images/s over all ranks (weak scaling: one prompt per GPU).
+
+Extra objects on the JSON line:
+  roofline     — the dominant kernel family (MFMA implicit-GEMM conv / GEMM), algorithmic FLOPs of its launches in one
+                 step divided by their HIP-event time (one extra instrumented step, events on the launch stream);
+                 peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).  `step_frac` = whole-step algorithmic FLOPs
+                 (27.7 TFLOP) / step time / peak.
+  cpu_baseline — the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample and
+                 extrapolated by algorithmic FLOPs; rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic TFLOP per step per prompt: UNet fwd 0.839 (incl. LoRA), VAE 2.515, BLIP 0.408
+F_UNET, F_VAE, F_BLIP = 0.839, 2.515, 0.408
+
+
+def step_tflop(total_step, K, gan):
+    nograd = (total_step - K) * 2 * F_UNET
+    train = K * 2 * F_UNET * 2
+    f = nograd + train + F_VAE * 2 + F_BLIP * 2
+    if gan:
+        f += F_UNET * 2 + 2 * F_UNET * 2
+    return f
+
+
+class TimedKernels:
+    """Wraps the kernel backend for ONE instrumented step: brackets every launch with HIP events on the launch stream
+    (torch's current stream, the one the C ABI enqueues on) and tallies algorithmic FLOPs / bytes per kernel family."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.records = []
+
+    def __getattr__(self, name):
+        fn = getattr(self.inner, name)
+        if not callable(fn):
+            return fn
+
+        def wrapped(*a, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **kw)
+            e.record()
+            self.records.append((name, self._flops(name, a, kw), s, e))
+            return r
+        return wrapped
+
+    @staticmethod
+    def _flops(name, a, kw):
+        if name == "gemm":
+            M, N, K = a[3], a[4], a[5]
+            b = kw.get("batch", (1, 1))
+            return 2.0 * M * N * K * b[0] * b[1]
+        if name == "conv2d":
+            B, Cin, Hout, Wout, Cout, KH, KW, stride = a[3], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
+            f = 2.0 * B * Hout * Wout * Cout * KH * KW * Cin
+            return f / (stride * stride) if kw.get("mode", 0) == 1 else f
+        return 0.0
+
+    def summary(self):
+        torch.cuda.synchronize()
+        fam = {}
+        for name, fl, s, e in self.records:
+            d = fam.setdefault(name, [0.0, 0.0, 0])
+            d[0] += s.elapsed_time(e) * 1e-3
+            d[1] += fl
+            d[2] += 1
+        return fam
+
+
+def build_world(device, dtype, rank, cfg_name):
+    from comat_amd import config, weights
+    from comat_amd.blip import Blip
+    from comat_amd.gan import D_sd
+    from comat_amd.pipeline import TrainableSDPipeline
+    from comat_amd.step import CoMatTrainer, StepConfig
+    from comat_amd.unet import LoRABank, UNet, VAEDecoder
+
+    ucfg, vcfg, bcfg = config.SD15_UNET, config.SD15_VAE, config.BLIP_LARGE
+    if cfg_name == "c2":
+        scfg = StepConfig(resolution=512, total_step=5, K=5, gan_loss=True, attrcon=False)
+    elif cfg_name == "c3":
+        scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True)
+    else:
+        raise ValueError(cfg_name)
+    t0 = time.time()
+    usd = weights.make_unet_weights(ucfg, seed=1234)
+    lsd = weights.make_lora_weights(ucfg, seed=4321)
+    bank = LoRABank(ucfg, lsd, dtype, device)
+    unet = UNet(ucfg, usd, dtype, device, bank)
+    keep_for_cpu = usd if (rank == 0) else None
+    vae = VAEDecoder(vcfg, weights.make_vae_weights(vcfg, seed=2345), dtype, device)
+    blip = Blip(bcfg, weights.make_blip_weights(bcfg, seed=3456), dtype, device)
+    dsd = weights.make_unet_weights(ucfg, seed=1235)
+    dbank = LoRABank(ucfg, weights.make_lora_weights(ucfg, seed=4322), dtype, device)
+    g = torch.Generator().manual_seed(99)
+    disc = D_sd(UNet(ucfg, dsd, dtype, device, dbank), dbank, torch.randn(4, generator=g) * 0.5,
+                torch.randn(1, generator=g) * 0.1)
+    del dsd
+    trainer = CoMatTrainer(TrainableSDPipeline(unet, vae), bank, blip, disc, scfg, seed=rank)
+    # synthetic batch; per-rank seeds differ (each rank has its own prompt)
+    g = torch.Generator().manual_seed(1000 + rank)
+    L, T = 77, 16
+    ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
+                     torch.tensor([102])]).reshape(1, T)
+    batch = dict(
+        prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
+        negative_prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
+        gan_null_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
+        latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42 + rank)),
+        noises=[torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(100 + i)).to(device)
+                for i in range(scfg.total_step)],
+        real_latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
+        blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids))
+    if scfg.attrcon:
+        import numpy as np
+        m = np.zeros((2, 512, 512), dtype=bool)
+        m[0, 60:250, 40:230] = True
+        m[1, 280:480, 260:500] = True
+        batch["masks"] = [m]
+        batch["attributes"] = [[[2, 3], [6, 7]]]
+    fixed = dict(crop=(1, 1, 510, 510))
+    if cfg_name == "c2":
+        fixed["training_steps"] = [0, 1, 2, 3, 4]
+    return trainer, batch, fixed, scfg, keep_for_cpu, time.time() - t0
+
+
+def cpu_baseline(usd, scfg):
+    """Oracle (CPU fp32 port) on a bounded sample: one no-grad SD1.5 UNet forward at CFG batch 2 (1.68 TFLOP of the
+    step's algorithmic FLOPs), extrapolated to the whole step by algorithmic FLOPs."""
+    from oracle import sd as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ocfg = O.UNetConfig()
+    g = torch.Generator().manual_seed(0)
+    x, ctx = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
+        dt = time.time() - t0
+    sample_tflop = 2 * 0.803  # no LoRA in the sample
+    total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
+    est_step_s = dt * total / sample_tflop
+    return {"value": 1.0 / est_step_s, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/sd.py unet_forward, SD1.5 fp32, batch 2 @64x64 latent, 1 call = {sample_tflop:.2f} "
+                      f"TFLOP in {dt:.1f} s ({sample_tflop / dt:.3f} TFLOP/s on {cores} threads); step time "
+                      f"extrapolated by algorithmic FLOPs ({total:.1f} TFLOP/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from comat_amd import _hip, dist, ops
+    rank, world, device = dist.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ops.set_kernel_backend(_hip.HipKernels())
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank, args.config)
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch, **fixed)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        trainer.train_step(batch, **fixed)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt  # one image (prompt) per rank per step
+
+    roofline = None
+    if rank == 0 and not args.no_kernel_timing:
+        timed = TimedKernels(ops.kernels())
+        ops.set_kernel_backend(timed)
+        trainer.train_step(batch, **fixed)
+        fam = timed.summary()
+        ops.set_kernel_backend(timed.inner)
+        tot_t = sum(v[0] for v in fam.values())
+        dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
+        t_dom, f_dom, n_dom = fam[dom]
+        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
+        roofline = {
+            "bound": "mfma", "kernel": {"gemm": "gemm_kernel<bf16>", "conv2d": "conv_kernel<bf16> (implicit GEMM)"}.get(dom, dom),
+            "achieved": f_dom / t_dom / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": f_dom / t_dom / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+            "launches_per_step": n_dom, "avg_launch_ms": t_dom / n_dom * 1e3,
+            "algorithmic_tflop_per_step_in_kernel": f_dom / 1e12,
+            "step_algorithmic_tflop": total, "step_frac": total / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS,
+            "families": {k: {"ms": round(v[0] * 1e3, 2), "tflop": round(v[1] / 1e12, 3), "launches": v[2],
+                             "share_of_kernel_time": round(v[0] / tot_t, 4)}
+                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]},
+        }
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(usd_cpu, scfg)
+    if rank == 0:
+        out = {
+            "metric": "CoMat train-step images/sec (SD1.5 512^2, bs=1/GPU)", "value": value, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config.upper()}: SD1.5 512x512 bs=1/GPU, N={scfg.total_step} denoise steps "
+                                   f"(K={scfg.K} with grad), CFG 7.5, LoRA r=128, concept-matching (BLIP-large) + GAN "
+                                   f"fidelity (G+D step)" + (" + attribute concentration" if scfg.attrcon else "") +
+                                   ", clip+AdamW for G and D",
+                       "parallelism": f"dp{world}", "build_s": round(t_build, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
