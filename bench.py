@@ -65,9 +65,19 @@ class TimedKernels:
             s.record()
             r = fn(*a, **kw)
             e.record()
-            self.records.append((name, self._flops(name, a, kw), s, e))
+            self.records.append((name, self._flops(name, a, kw), s, e, self._sig(name, a, kw)))
             return r
         return wrapped
+
+    @staticmethod
+    def _sig(name, a, kw):
+        if name == "gemm":
+            return (f"gemm M={a[3]} N={a[4]} K={a[5]} tA={int(kw.get('transA', False))} tB={int(kw.get('transB', False))} "
+                    f"b={kw.get('batch', (1, 1))} in={a[0].dtype} out={a[2].dtype}")
+        if name == "conv2d":
+            return (f"conv B={a[3]} HWin={a[4]}x{a[5]} Cin={a[6]} HWout={a[7]}x{a[8]} Cout={a[9]} k={a[10]} s={a[12]} "
+                    f"mode={kw.get('mode', 0)} ups={kw.get('ups', 1)}")
+        return name
 
     @staticmethod
     def _flops(name, a, kw):
@@ -84,11 +94,23 @@ class TimedKernels:
     def summary(self):
         torch.cuda.synchronize()
         fam = {}
-        for name, fl, s, e in self.records:
+        shapes = {}
+        for name, fl, s, e, sig in self.records:
+            ms = s.elapsed_time(e)
             d = fam.setdefault(name, [0.0, 0.0, 0])
-            d[0] += s.elapsed_time(e) * 1e-3
+            d[0] += ms * 1e-3
             d[1] += fl
             d[2] += 1
+            q = shapes.setdefault(sig, [0.0, 0.0, 0])
+            q[0] += ms
+            q[1] += fl
+            q[2] += 1
+        dump = os.environ.get("COMAT_BENCH_DUMP")
+        if dump:
+            with open(dump, "w") as f:
+                for sig, (ms, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+                    f.write(f"{ms:9.2f} ms  n={n:5d}  {tf:8.1f} TF/s  {sig}\n")
         return fam
 
 
@@ -150,24 +172,29 @@ def build_world(device, dtype, rank, cfg_name):
 
 
 def cpu_baseline(usd, scfg):
-    """Oracle (CPU fp32 port) on a bounded sample: one no-grad SD1.5 UNet forward at CFG batch 2 (1.68 TFLOP of the
-    step's algorithmic FLOPs), extrapolated to the whole step by algorithmic FLOPs."""
+    """Oracle (CPU fp32 port) on a bounded sample: one no-grad SD1.5 UNet forward of the oracle at CFG batch 2 on a
+    32x32 latent (a quarter of the tokens), FLOPs counted by torch's FlopCounterMode, extrapolated to the whole step
+    by algorithmic FLOPs."""
+    from torch.utils.flop_counter import FlopCounterMode
+
     from oracle import sd as O
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
     ocfg = O.UNetConfig()
     g = torch.Generator().manual_seed(0)
-    x, ctx = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g)
+    x, ctx = torch.randn(2, 4, 32, 32, generator=g), torch.randn(2, 77, 768, generator=g)
     with torch.no_grad():
-        t0 = time.time()
-        O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
-        dt = time.time() - t0
-    sample_tflop = 2 * 0.803  # no LoRA in the sample
+        with FlopCounterMode(display=False) as fc:
+            t0 = time.time()
+            O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
+            dt = time.time() - t0
+    sample_tflop = fc.get_total_flops() / 1e12
     total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
     est_step_s = dt * total / sample_tflop
-    return {"value": 1.0 / est_step_s, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/sd.py unet_forward, SD1.5 fp32, batch 2 @64x64 latent, 1 call = {sample_tflop:.2f} "
-                      f"TFLOP in {dt:.1f} s ({sample_tflop / dt:.3f} TFLOP/s on {cores} threads); step time "
+    return {"value": 1.0 / est_step_s, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle/sd.py unet_forward (SD1.5, fp32, CFG batch 2, 32x32 latent): {sample_tflop:.3f} TFLOP in "
+                      f"{dt:.1f} s = {sample_tflop / dt:.3f} TFLOP/s on {threads} of {cores} host threads; step time "
                       f"extrapolated by algorithmic FLOPs ({total:.1f} TFLOP/step)"}
 
 
