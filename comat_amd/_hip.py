@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float),
         ("transA", C.c_int32), ("transB", C.c_int32), ("act", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -44,6 +45,7 @@ class ConvParams(C.Structure):
         ("mode", C.c_int32), ("ups", C.c_int32),
         ("alpha", C.c_float), ("beta", C.c_float),
         ("act", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -141,8 +143,17 @@ class HipKernels:
 
     name = "hip"
 
+    WS_BYTES = 256 << 20  # split-K slab workspace per device (stream-ordered reuse)
+
     def __init__(self):
         load_library()
+        self._ws = {}
+
+    def _workspace(self, dev):
+        ws = self._ws.get(dev)
+        if ws is None:
+            ws = self._ws[dev] = torch.empty(self.WS_BYTES // 4, dtype=torch.float32, device=dev)
+        return ws
 
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
@@ -168,6 +179,8 @@ class HipKernels:
         assert A.dtype == B.dtype
         p.in_dtype, p.out_dtype = dt(A), dt(Cout)
         p.r_dtype = dt(R) if R is not None else 0
+        ws = self._workspace(A.device)
+        p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_gemm(C.byref(p), _stream()), "comat_gemm")
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
@@ -185,6 +198,8 @@ class HipKernels:
         assert X.dtype == W.dtype
         p.in_dtype, p.out_dtype = dt(X), dt(Y)
         p.r_dtype = dt(R) if R is not None else 0
+        ws = self._workspace(X.device)
+        p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_conv2d(C.byref(p), _stream()), "comat_conv2d")
 
     # ---- normalisation -------------------------------------------------------------------------------------

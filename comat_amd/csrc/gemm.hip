@@ -13,12 +13,16 @@
 // for A and B alike, so any k-permutation inside the MFMA cancels (sum over k).  C/D mapping of the 32x32 MFMA:
 // col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int ROWB = 80;             // bytes per LDS row, k-contiguous image
-constexpr int LDS_OP_BYTES = 10240;  // per operand per stage (128 rows * 80 B >= any k-major image)
+constexpr int KTB = 64;              // bytes of k per row per k-tile (128 measured slower: LDS footprint halves occupancy)
+constexpr int ROWB = KTB + 16;       // bytes per LDS row, k-contiguous image (36 dwords: conflict-free b128 reads)
+constexpr int CPR = KTB / 16;        // 16-byte chunks per row
+constexpr int PF = 4;  // k-tiles kept in flight per thread (register prefetch ring): hides HBM/L2 latency when few
+                        // workgroups share a CU
 
 struct Epi {
     void* C;
@@ -43,74 +47,92 @@ union Vec16 {
 // ---------------------------------------------------------------------------------------------------------------
 // Operand loaders: global -> registers (issued before the MFMA phase) -> LDS (after it).
 // ---------------------------------------------------------------------------------------------------------------
+// All index arithmetic that does not change along k is done once in init(); load() only advances running
+// pointers / tap counters by one k-tile (the k-loop of the small tiles is otherwise VALU-bound on address math).
 template <typename T, int ROWS, bool TRANS> struct PlainLoader {
     static constexpr bool kTrans = TRANS;
     static constexpr int EPV = 16 / sizeof(T);
-    static constexpr int NCH = ROWS * 4 / NT;
+    static constexpr int BKE = KTB / sizeof(T);
+    static constexpr int NCH = ROWS * CPR / NT;
     static constexpr int VPR = ROWS / EPV;               // 16-byte vectors per k-row (k-major image)
     static constexpr int RS = ROWS * (int)sizeof(T) + 16;  // k-major LDS row stride in bytes
-    const T* P;
-    int64_t ld, R0, Rmax, K;
+    const T* ptr[NCH];   // running source pointer of each 16-byte chunk
+    int kpos[NCH];       // k index of the chunk's first element
+    int rleft[NCH];      // non-trans: 1 if the row exists; trans: number of valid m-elements in the vector (0..EPV)
+    int lds_off[NCH];
+    int K;
+    int64_t step;        // pointer advance per k-tile (elements)
     bool vec_ok;
-    uint4 regs[NCH];
+    uint4 regs[PF][NCH];
 
-    __device__ __forceinline__ void init(const void* p, int64_t ld_, int64_t r0, int64_t rmax, int64_t k_) {
-        P = (const T*)p;
-        ld = ld_;
-        R0 = r0;
-        Rmax = rmax;
-        K = k_;
+    __device__ __forceinline__ void init(const void* p, int64_t ld, int64_t r0, int64_t rmax, int64_t k_, int64_t kt0) {
+        const T* P = (const T*)p;
+        K = (int)k_;
         vec_ok = ((ld % EPV) == 0) && ((((uintptr_t)p) & 15) == 0);
-    }
-    __device__ __forceinline__ void load(int64_t k0) {
+        step = TRANS ? (int64_t)BKE * ld : (int64_t)BKE;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NT;
+            if (!TRANS) {
+                const int row = c / CPR, kv = c % CPR;
+                const int64_t gr = r0 + row;
+                kpos[i] = (int)(kt0 * BKE) + kv * EPV;
+                rleft[i] = gr < rmax ? 1 : 0;
+                ptr[i] = P + (gr < rmax ? gr : 0) * ld + kpos[i];
+                lds_off[i] = row * ROWB + kv * 16;
+            } else {
+                const int kk = c / VPR, mv = c % VPR;
+                const int64_t gr = r0 + (int64_t)mv * EPV;
+                kpos[i] = (int)(kt0 * BKE) + kk;
+                const int64_t left = rmax - gr;
+                rleft[i] = left <= 0 ? 0 : (left >= EPV ? EPV : (int)left);
+                ptr[i] = P + (int64_t)kpos[i] * ld + (left > 0 ? gr : 0);
+                lds_off[i] = kk * RS + mv * 16;
+            }
+        }
+    }
+    // loads the current k-tile into register slot `slot`, then advances to the next k-tile
+    __device__ __forceinline__ void load(int slot) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
             Vec16 v;
             v.u = make_uint4(0, 0, 0, 0);
+            const T* src = ptr[i];
             if (!TRANS) {
-                const int row = c >> 2, kv = c & 3;
-                const int64_t gk = k0 + kv * EPV, gr = R0 + row;
-                if (gr < Rmax && gk < K) {
-                    const T* src = P + gr * ld + gk;
-                    if (vec_ok && gk + EPV <= K) {
+                if (rleft[i] && kpos[i] < K) {
+                    if (vec_ok && kpos[i] + EPV <= K) {
                         v.u = *(const uint4*)src;
                     } else {
 #pragma unroll
                         for (int e = 0; e < EPV; ++e)
-                            if (gk + e < K) {
+                            if (kpos[i] + e < K) {
                                 if (sizeof(T) == 2) v.h[e] = ((const bf16_t*)src)[e];
                                 else v.f[e] = ((const float*)src)[e];
                             }
                     }
                 }
             } else {
-                const int kk = c / VPR, mv = c % VPR;
-                const int64_t gk = k0 + kk, gr = R0 + (int64_t)mv * EPV;
-                if (gk < K && gr < Rmax) {
-                    const T* src = P + gk * ld + gr;
-                    if (vec_ok && gr + EPV <= Rmax) {
+                if (rleft[i] > 0 && kpos[i] < K) {
+                    if (vec_ok && rleft[i] == EPV) {
                         v.u = *(const uint4*)src;
                     } else {
 #pragma unroll
                         for (int e = 0; e < EPV; ++e)
-                            if (gr + e < Rmax) {
+                            if (e < rleft[i]) {
                                 if (sizeof(T) == 2) v.h[e] = ((const bf16_t*)src)[e];
                                 else v.f[e] = ((const float*)src)[e];
                             }
                     }
                 }
             }
-            regs[i] = v.u;
+            regs[slot][i] = v.u;
+            ptr[i] += step;
+            kpos[i] += BKE;
         }
     }
-    __device__ __forceinline__ void store(char* lds) const {
+    __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
-            if (!TRANS) *(uint4*)(lds + (c >> 2) * ROWB + (c & 3) * 16) = regs[i];
-            else *(uint4*)(lds + (c / VPR) * RS + (c % VPR) * 16) = regs[i];
-        }
+        for (int i = 0; i < NCH; ++i) *(uint4*)(lds + lds_off[i]) = regs[slot][i];
     }
 };
 
@@ -118,94 +140,113 @@ struct ConvGeom {
     int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, mode, ups;
 };
 
-// im2col gather of a channels-last activation: row m = (b, oy, ox), k = (ky, kx, ci).
+// im2col gather of a channels-last activation: row m = (b, oy, ox), k = (ky, kx, ci).  Per chunk the output position
+// is decoded once; along k a running (ky, kx, ci) counter replaces the divisions.
 template <typename T, int ROWS> struct ConvLoader {
     static constexpr bool kTrans = false;
     static constexpr int EPV = 16 / sizeof(T);
-    static constexpr int NCH = ROWS * 4 / NT;
+    static constexpr int BKE = KTB / sizeof(T);
+    static constexpr int NCH = ROWS * CPR / NT;
     const T* X;
     ConvGeom g;
-    int64_t K;
     bool vec_ok;
-    int rb[NCH], roy[NCH], rox[NCH];
+    int base_y[NCH], base_x[NCH], brow[NCH];  // oy*stride - pad (mode 0) or oy - pad (mode 1); b*Hin
+    int ky[NCH], kx[NCH], ci[NCH];            // running tap / channel of the chunk's first element
     bool rvalid[NCH];
-    uint4 regs[NCH];
+    uint4 regs[PF][NCH];
 
-    __device__ __forceinline__ void init(const void* x, const ConvGeom& g_, int64_t r0, int64_t M) {
+    __device__ __forceinline__ void init(const void* x, const ConvGeom& g_, int64_t r0, int64_t M, int64_t kt0) {
         X = (const T*)x;
         g = g_;
-        K = (int64_t)g.KH * g.KW * g.Cin;
         vec_ok = ((g.Cin % EPV) == 0) && ((((uintptr_t)x) & 15) == 0);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NT;
-            const int64_t gm = r0 + (c >> 2);
+            const int64_t gm = r0 + (c / CPR);
             rvalid[i] = gm < M;
-            const int64_t hw = (int64_t)g.Hout * g.Wout;
-            const int64_t b = gm / hw, rem = gm - b * hw;
-            rb[i] = (int)b;
-            roy[i] = (int)(rem / g.Wout);
-            rox[i] = (int)(rem - (int64_t)roy[i] * g.Wout);
+            const int hw = g.Hout * g.Wout;
+            const int b = (int)(gm / hw), rem = (int)(gm - (int64_t)b * hw);
+            const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
+            brow[i] = b * g.Hin;
+            base_y[i] = (g.mode == 0 ? oy * g.stride : oy) - g.pad;
+            base_x[i] = (g.mode == 0 ? ox * g.stride : ox) - g.pad;
+            const int64_t k = kt0 * BKE + (c % CPR) * EPV;
+            const int tap = (int)(k / g.Cin);
+            ci[i] = (int)(k - (int64_t)tap * g.Cin);
+            ky[i] = tap / g.KW;
+            kx[i] = tap - ky[i] * g.KW;
         }
     }
-    // pointer to X[b, sy, sx, ci] for output position (oy, ox) and tap, or nullptr when the tap falls in padding
-    __device__ __forceinline__ const T* src_ptr(int b, int oy, int ox, int tap, int ci) const {
-        const int ky = tap / g.KW, kx = tap - ky * g.KW;
-        int sy, sx;
+    // element offset of X[b, sy, sx, ci] for the tap, or -1 when it falls into padding / between strided samples
+    __device__ __forceinline__ int src_off(int i, int kyy, int kxx, int cii) const {
+        int sy = base_y[i] + kyy, sx = base_x[i] + kxx;
         if (g.mode == 0) {
-            sy = oy * g.stride + ky - g.pad;
-            sx = ox * g.stride + kx - g.pad;
-            if (sy < 0 || sx < 0 || sy >= g.Hin * g.ups || sx >= g.Win * g.ups) return nullptr;
+            if (sy < 0 || sx < 0 || sy >= g.Hin * g.ups || sx >= g.Win * g.ups) return -1;
             if (g.ups == 2) {
                 sy >>= 1;
                 sx >>= 1;
             }
         } else {
-            const int ty = oy + ky - g.pad, tx = ox + kx - g.pad;
-            if (ty < 0 || tx < 0) return nullptr;
-            if ((ty % g.stride) != 0 || (tx % g.stride) != 0) return nullptr;
-            sy = ty / g.stride;
-            sx = tx / g.stride;
-            if (sy >= g.Hin || sx >= g.Win) return nullptr;
+            if (sy < 0 || sx < 0) return -1;
+            if (g.stride == 2) {
+                if ((sy | sx) & 1) return -1;
+                sy >>= 1;
+                sx >>= 1;
+            } else if (g.stride > 1) {
+                if ((sy % g.stride) != 0 || (sx % g.stride) != 0) return -1;
+                sy /= g.stride;
+                sx /= g.stride;
+            }
+            if (sy >= g.Hin || sx >= g.Win) return -1;
         }
-        return X + (((int64_t)b * g.Hin + sy) * g.Win + sx) * g.Cin + ci;
+        return ((brow[i] + sy) * g.Win + sx) * g.Cin + cii;
     }
-    __device__ __forceinline__ void load(int64_t k0) {
+    __device__ __forceinline__ void load(int slot) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
-            const int kv = c & 3;
-            const int64_t gk = k0 + kv * EPV;
             Vec16 v;
             v.u = make_uint4(0, 0, 0, 0);
-            if (rvalid[i] && gk < K) {
+            if (rvalid[i] && ky[i] < g.KH) {
                 if (vec_ok) {
-                    const int tap = (int)(gk / g.Cin), ci = (int)(gk - (int64_t)tap * g.Cin);
-                    const T* src = src_ptr(rb[i], roy[i], rox[i], tap, ci);
-                    if (src) v.u = *(const uint4*)src;
+                    const int off = src_off(i, ky[i], kx[i], ci[i]);
+                    if (off >= 0) v.u = *(const uint4*)(X + off);
                 } else {
+                    int ky2 = ky[i], kx2 = kx[i], ci2 = ci[i];
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
-                        const int64_t k = gk + e;
-                        if (k < K) {
-                            const int tap = (int)(k / g.Cin), ci = (int)(k - (int64_t)tap * g.Cin);
-                            const T* src = src_ptr(rb[i], roy[i], rox[i], tap, ci);
-                            if (src) {
-                                if (sizeof(T) == 2) v.h[e] = *(const bf16_t*)src;
-                                else v.f[e] = *(const float*)src;
+                        if (ky2 < g.KH) {
+                            const int off = src_off(i, ky2, kx2, ci2);
+                            if (off >= 0) {
+                                if (sizeof(T) == 2) v.h[e] = ((const bf16_t*)X)[off];
+                                else v.f[e] = ((const float*)X)[off];
+                            }
+                        }
+                        if (++ci2 == g.Cin) {
+                            ci2 = 0;
+                            if (++kx2 == g.KW) {
+                                kx2 = 0;
+                                ++ky2;
                             }
                         }
                     }
                 }
             }
-            regs[i] = v.u;
+            regs[slot][i] = v.u;
+            ci[i] += BKE;  // advance one k-tile
+            while (ci[i] >= g.Cin) {
+                ci[i] -= g.Cin;
+                if (++kx[i] == g.KW) {
+                    kx[i] = 0;
+                    ++ky[i];
+                }
+            }
         }
     }
-    __device__ __forceinline__ void store(char* lds) const {
+    __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NT;
-            *(uint4*)(lds + (c >> 2) * ROWB + (c & 3) * 16) = regs[i];
+            *(uint4*)(lds + (c / CPR) * ROWB + (c % CPR) * 16) = regs[slot][i];
         }
     }
 };
@@ -221,7 +262,7 @@ __device__ __forceinline__ typename FragOf<T>::type read_frag(const char* lds, i
     } else {
         constexpr int EPV = 16 / sizeof(T);
         constexpr int RS = ROWS * (int)sizeof(T) + 16;
-        const int ke0 = s * (32 / (int)sizeof(T)) + h * EPV;
+        const int ke0 = s * (32 / (int)sizeof(T)) + h * EPV;  // k-step s covers 32 bytes of k
         Vec16 v;
 #pragma unroll
         for (int j = 0; j < EPV; ++j) {
@@ -250,12 +291,12 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const f32x4_t& a, const f32x4
 // Block-level main loop + fused epilogue
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, typename AL, typename BL>
-__device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t K, int64_t m0, int64_t n0, int64_t M, int64_t N,
-                                           const Epi& ep) {
-    constexpr int BKE = 64 / sizeof(T);
+__device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t kt1, int64_t m0, int64_t n0, int64_t M,
+                                           int64_t N, const Epi& ep, float* slab) {
     constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2][2][LDS_OP_BYTES];
+    constexpr int OPB = (BM > 64 || BN > 64) ? 128 * ROWB : 64 * ROWB;  // bytes per operand per stage (>= any image)
+    __shared__ __attribute__((aligned(16))) char smem[2][2][OPB];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -269,40 +310,65 @@ __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t K, int64_t m0
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-    const int64_t nk = (K + BKE - 1) / BKE;
-    al.load(0);
-    bl.load(0);
-    al.store(smem[0][0]);
-    bl.store(smem[0][1]);
+    // prologue: PF k-tiles in flight, the first one staged to LDS
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (kt0 + u < kt1) {
+            al.load(u);
+            bl.load(u);
+        }
+    al.store(smem[0][0], 0);
+    bl.store(smem[0][1], 0);
     __syncthreads();
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const int cur = (int)(kt & 1);
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            al.load((kt + 1) * BKE);
-            bl.load((kt + 1) * BKE);
+    int cur = 0;
+    for (int64_t kt = kt0; kt < kt1; kt += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int64_t t = kt + u;  // tile t sits in LDS[cur]; register slot u (its old home) is free
+            if (t < kt1) {
+                if (t + PF < kt1) {
+                    al.load(u);
+                    bl.load(u);
+                }
+                const char* la = smem[cur][0];
+                const char* lb = smem[cur][1];
+#pragma unroll
+                for (int s = 0; s < KTB / 32; ++s) {
+                    F af[TM], bfr[TN];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) af[a] = read_frag<T, BM, AL::kTrans>(la, wr * WTM + a * 32 + r, s, h);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        bfr[b] = read_frag<T, BN, BL::kTrans>(lb, wc * WTN + b * 32 + r, s, h);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) mma(acc[a][b], af[a], bfr[b]);
+                }
+                if (t + 1 < kt1) {
+                    al.store(smem[cur ^ 1][0], (u + 1) % PF);
+                    bl.store(smem[cur ^ 1][1], (u + 1) % PF);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
         }
-        const char* la = smem[cur][0];
-        const char* lb = smem[cur][1];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            F af[TM], bfr[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = read_frag<T, BM, AL::kTrans>(la, wr * WTM + a * 32 + r, s, h);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bfr[b] = read_frag<T, BN, BL::kTrans>(lb, wc * WTN + b * 32 + r, s, h);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) mma(acc[a][b], af[a], bfr[b]);
-        }
-        if (more) {
-            al.store(smem[cur ^ 1][0]);
-            bl.store(smem[cur ^ 1][1]);
-        }
-        __syncthreads();
     }
 
+    if (slab) {  // split-K: raw fp32 partial sums, reduced + finished by splitk_reduce_kernel
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int64_t col = n0 + wc * WTN + b * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t row = m0 + wr * WTM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (row < M && col < N) slab[row * N + col] = acc[a][b][i];
+                }
+            }
+        return;
+    }
     // epilogue: v = act(alpha*acc + bias + bias2) + beta*R
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -330,13 +396,43 @@ struct GemmArgs {
     const void* B;
     int64_t M, N, K, lda, ldb;
     int64_t batch2, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
-    int tiles_m;
+    int tiles_m, tiles_n;
+    int splits;
+    float* ws;
     Epi ep;
 };
 
+// XCD-aware workgroup -> work-item map.  Workgroup b is dispatched to XCD b % 8 (MI355X: 8 XCDs, a private 4 MiB L2
+// each).  Give every XCD one CONTIGUOUS chunk of the linear work list, ordered so that neighbours share the same
+// activation rows and stream the (small) weight panel: the chunk's operands then stay resident in that XCD's L2
+// instead of every XCD thrashing over the whole problem.  Bijective for any count; affects speed only.
+__device__ __forceinline__ int64_t xcd_chunk_map(int64_t bid, int64_t n) {
+    const int64_t q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    const int64_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + idx;
+}
+
+// k-tile range of split s
+__device__ __forceinline__ void split_range(int64_t K, int bke, int splits, int s, int64_t& kt0, int64_t& kt1) {
+    const int64_t nk = (K + bke - 1) / bke;
+    const int64_t per = (nk + splits - 1) / splits;
+    kt0 = (int64_t)s * per;
+    kt1 = kt0 + per < nk ? kt0 + per : nk;
+    if (kt0 > nk) kt0 = nk;
+}
+
 template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
-    const int64_t z = blockIdx.z, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
-    const int tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;
+    // linear work id = ((z * tiles_m + tm) * tiles_n + tn) * splits + split
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n);
+    lin /= g.tiles_n;
+    const int tm = (int)(lin % g.tiles_m);
+    const int64_t z = lin / g.tiles_m, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
+    int64_t kt0, kt1;
+    split_range(g.K, KTB / (int)sizeof(T), g.splits, sp, kt0, kt1);
+    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const T* A = (const T*)g.A + b1 * g.sA1 + b2 * g.sA2;
     const T* B = (const T*)g.B + b1 * g.sB1 + b2 * g.sB2;
@@ -346,9 +442,35 @@ template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_boun
     if (ep.R) ep.R = (const char*)ep.R + roff * (ep.r_dt == COMAT_F32 ? 4 : 2);
     PlainLoader<T, BM, TA> al;
     PlainLoader<T, BN, TB> bl;
-    al.init(A, g.lda, m0, g.M, g.K);
-    bl.init(B, g.ldb, n0, g.N, g.K);
-    gemm_block<T, BM, BN>(al, bl, g.K, m0, n0, g.M, g.N, ep);
+    al.init(A, g.lda, m0, g.M, g.K, kt0);
+    bl.init(B, g.ldb, n0, g.N, g.K, kt0);
+    gemm_block<T, BM, BN>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
+}
+
+// sums the split-K slabs and applies the fused epilogue: C = act(alpha*sum + bias + bias2) + beta*R
+struct ReduceArgs {
+    const float* ws;
+    int64_t M, N, batch2, sC1, sC2, sR1, sR2;
+    int splits;
+    Epi ep;
+};
+__global__ __launch_bounds__(NT) void splitk_reduce_kernel(ReduceArgs g) {
+    const int64_t mn = g.M * g.N;
+    const int64_t z = blockIdx.y, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
+    const float* base = g.ws + z * g.splits * mn;
+    const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < mn; i += (int64_t)gridDim.x * NT) {
+        float v = 0.f;
+        for (int s = 0; s < g.splits; ++s) v += base[s * mn + i];
+        const int64_t row = i / g.N, col = i - row * g.N;
+        v *= g.ep.alpha;
+        if (g.ep.bias) v += g.ep.bias[col];
+        if (g.ep.bias2) v += g.ep.bias2[(row / g.ep.rows_per_b2) * g.N + col];
+        if (g.ep.act == COMAT_ACT_SILU) v = silu_f(v);
+        else if (g.ep.act == COMAT_ACT_GELU) v = gelu_f(v);
+        if (g.ep.R) v += g.ep.beta * ld_dt(g.ep.R, roff + row * g.ep.ldr + col, g.ep.r_dt);
+        st_dt(g.ep.C, coff + row * g.ep.ldc + col, v, g.ep.out_dt);
+    }
 }
 
 struct ConvArgs {
@@ -356,18 +478,26 @@ struct ConvArgs {
     const void* W;
     ConvGeom geo;
     int64_t M, N, K;
-    int tiles_m;
+    int tiles_m, tiles_n;
+    int splits;
+    float* ws;
     Epi ep;
 };
 
 template <typename T, int BM, int BN> __global__ __launch_bounds__(NT) void conv_kernel(ConvArgs g) {
-    const int tm = blockIdx.x % g.tiles_m, tn = blockIdx.x / g.tiles_m;
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    int64_t kt0, kt1;
+    split_range(g.K, KTB / (int)sizeof(T), g.splits, sp, kt0, kt1);
+    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
     ConvLoader<T, BM> al;
     PlainLoader<T, BN, false> bl;
-    al.init(g.X, g.geo, m0, g.M);
-    bl.init(g.W, g.K, n0, g.N, g.K);
-    gemm_block<T, BM, BN>(al, bl, g.K, m0, n0, g.M, g.N, g.ep);
+    al.init(g.X, g.geo, m0, g.M, kt0);
+    bl.init(g.W, g.K, n0, g.N, g.K, kt0);
+    gemm_block<T, BM, BN>(al, bl, kt0, kt1, m0, n0, g.M, g.N, g.ep, slab);
 }
 
 template <typename T, int BM, int BN> int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
@@ -380,10 +510,52 @@ template <typename T, int BM, int BN> int launch_gemm_t(const GemmArgs& g, int t
     return 0;
 }
 
-bool pick_big_tile(int64_t M, int64_t N, int64_t batch) {
-    if (M <= 64 || N <= 64) return false;
-    const int64_t tiles = cdiv64(M, 128) * cdiv64(N, 128) * batch;
-    return tiles >= 192;
+// Tile and split-K choice.  These problems are short on tiles (M <= 16384, N <= 1280): prefer enough workgroups to
+// put several on every CU (the k-loop is latency-bound otherwise) — first through the tile size, then through
+// split-K with fp32 slabs in the caller's workspace (>= 8 k-tiles per split so the slab traffic stays small).
+struct TilePlan {
+    bool big;
+    int splits;
+};
+TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
+    TilePlan p;
+    const int64_t t128 = cdiv64(M, 128) * cdiv64(N, 128) * batch;
+    const int64_t t64 = cdiv64(M, 64) * cdiv64(N, 64) * batch;
+    p.big = false;  // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128
+    (void)t128;     // (2/CU) on every shape of this workload; the big tile is kept for COMAT_FORCE_TILE experiments
+    const int64_t blocks = p.big ? t128 : t64;
+    const int64_t nk = cdiv64(K, bke);
+    p.splits = 1;
+    static const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py)
+    static const char* force_split = getenv("COMAT_FORCE_SPLITS");
+    if (force_tile) p.big = atoi(force_tile) >= 128 && M > 0;
+    if (force_split) {
+        int64_t s = atoi(force_split);
+        const int64_t cap = ws_bytes > 0 ? ws_bytes / (batch * M * N * 4) : 1;
+        if (s > cap) s = cap;
+        if (s > nk) s = nk;
+        p.splits = s < 1 ? 1 : (int)s;
+        return p;
+    }
+    if (ws_bytes > 0 && blocks < 512 && nk >= 8) {
+        int64_t s = cdiv64(768, blocks);
+        if (s > nk / 4) s = nk / 4;
+        const int64_t cap = ws_bytes / (batch * M * N * 4);
+        if (s > cap) s = cap;
+        if (s > 64) s = 64;
+        if (s >= 2) p.splits = (int)s;
+    }
+    return p;
+}
+
+void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t batch2, int64_t sC1, int64_t sC2,
+                   int64_t sR1, int64_t sR2, int splits, const Epi& ep, hipStream_t st) {
+    ReduceArgs r;
+    r.ws = ws; r.M = M; r.N = N; r.batch2 = batch2; r.sC1 = sC1; r.sC2 = sC2; r.sR1 = sR1; r.sR2 = sR2;
+    r.splits = splits; r.ep = ep;
+    int gx = (int)cdiv64(M * N, NT);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)batch), dim3(NT), 0, st, r);
 }
 
 }  // namespace
@@ -397,6 +569,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_gemm: bad residual dtype");
     COMAT_REQUIRE(p->batch1 >= 1 && p->batch2 >= 1 && p->batch1 * p->batch2 <= 65535, "comat_gemm: bad batch");
     COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm: bias2 needs rows_per_bias2");
+    COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
     GemmArgs g;
@@ -410,12 +583,17 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
     const int64_t batch = p->batch1 * p->batch2;
-    const bool big = pick_big_tile(p->M, p->N, batch);
+    const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
+    const TilePlan plan = plan_tiles(p->M, p->N, p->K, bke, batch, p->ws ? p->ws_bytes : 0);
+    const bool big = plan.big;
     const int bm = big ? 128 : 64;
     g.tiles_m = (int)cdiv64(p->M, bm);
-    const int64_t tiles = (int64_t)g.tiles_m * cdiv64(p->N, bm);
+    g.tiles_n = (int)cdiv64(p->N, bm);
+    g.splits = plan.splits;
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
-    dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+    g.ws = (float*)p->ws;
+    dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
     if (p->in_dtype == COMAT_BF16) {
@@ -425,6 +603,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
         if (big) launch_gemm_t<float, 128, 128>(g, trans, grid, st);
         else launch_gemm_t<float, 64, 64>(g, trans, grid, st);
     }
+    if (g.splits > 1)
+        launch_reduce(g.ws, p->M, p->N, batch, p->batch2, p->sC1, p->sC2, p->sR1, p->sR2, g.splits, g.ep, st);
     return comat_check_launch("comat_gemm");
 }
 
@@ -435,6 +615,9 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
                   "comat_conv2d: bad shape");
     COMAT_REQUIRE(p->KH > 0 && p->KW > 0 && p->stride >= 1 && p->pad >= 0, "comat_conv2d: bad kernel geometry");
     COMAT_REQUIRE(p->mode == 0 || p->mode == 1, "comat_conv2d: mode must be 0 or 1");
+    COMAT_REQUIRE((int64_t)p->B * p->Hin * p->Win * p->Cin < (1ll << 31) &&
+                      (int64_t)p->KH * p->KW * p->Cin < (1ll << 30),
+                  "comat_conv2d: input tensor too large for 32-bit gather offsets");
     COMAT_REQUIRE(p->ups == 1 || (p->ups == 2 && p->mode == 0), "comat_conv2d: ups must be 1, or 2 with mode 0");
     COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_conv2d: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_conv2d: bad residual dtype");
@@ -450,11 +633,16 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     g.ep.ldc = p->Cout; g.ep.ldr = p->Cout; g.ep.rows_per_b2 = (int64_t)p->Hout * p->Wout;
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
-    const bool big = pick_big_tile(g.M, g.N, 1);
+    const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
+    const TilePlan plan = plan_tiles(g.M, g.N, g.K, bke, 1, p->ws ? p->ws_bytes : 0);
+    const bool big = plan.big;
     const int bm = big ? 128 : 64;
     g.tiles_m = (int)cdiv64(g.M, bm);
-    const int64_t tiles = (int64_t)g.tiles_m * cdiv64(g.N, bm);
+    g.tiles_n = (int)cdiv64(g.N, bm);
+    g.splits = plan.splits;
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
+    g.ws = (float*)p->ws;
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     if (p->in_dtype == COMAT_BF16) {
@@ -464,5 +652,6 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
         if (big) hipLaunchKernelGGL((conv_kernel<float, 128, 128>), grid, dim3(NT), 0, st, g);
         else hipLaunchKernelGGL((conv_kernel<float, 64, 64>), grid, dim3(NT), 0, st, g);
     }
+    if (g.splits > 1) launch_reduce(g.ws, g.M, g.N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
     return comat_check_launch("comat_conv2d");
 }

@@ -154,6 +154,184 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
     }
 }
 
+// ---- vectorised GroupNorm (C % (16/sizeof(T)) == 0): 16-byte accesses, fixed channel vector per thread -----------
+union GV16 {
+    uint4 u;
+    float f[4];
+    bf16_t h[8];
+};
+template <typename T> __device__ __forceinline__ float gv_get(const GV16& v, int e) {
+    return sizeof(T) == 2 ? bf16_to_f32(v.h[e]) : v.f[e];
+}
+template <typename T> __device__ __forceinline__ void gv_set(GV16& v, int e, float x) {
+    if (sizeof(T) == 2) v.h[e] = f32_to_bf16(x);
+    else v.f[e] = x;
+}
+
+constexpr int VSLOTS = 2;  // channel vectors per thread: C <= 256 * 2 * EPV
+
+// MODE 0: sum x, sum x^2.   MODE 1 (backward): s1 = sum gy*gamma, s2 = sum gy*gamma*xhat
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ stats, double* __restrict__ ws,
+                                                       int HW, int C, int G, int silu, int rows_per_block) {
+    constexpr int EPV = 16 / sizeof(T);
+    __shared__ float s_a[MAX_G], s_b[MAX_G];
+    const int b = blockIdx.y;
+    const int VPR = C / EPV;
+    const int R = VPR >= NT ? 1 : NT / VPR;  // rows processed in parallel
+    const int cpg = C / G;
+    if (threadIdx.x < MAX_G) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, HW);
+    const int64_t base = (int64_t)b * HW * C;
+#pragma unroll
+    for (int sl = 0; sl < VSLOTS; ++sl) {
+        int v, rsub;
+        if (VPR >= NT) { v = threadIdx.x + sl * NT; rsub = 0; }
+        else { v = threadIdx.x % VPR; rsub = threadIdx.x / VPR; if (sl > 0 || rsub >= R) v = VPR; }
+        if (v >= VPR) continue;
+        const int c0 = v * EPV;
+        float a1[EPV], a2[EPV], gm[EPV], bt[EPV], mu[EPV], rs[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            a1[e] = 0.f; a2[e] = 0.f;
+            if (MODE == 1) {
+                gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e];
+                const float* st = stats + ((int64_t)b * G + (c0 + e) / cpg) * 2;
+                mu[e] = st[0]; rs[e] = st[1];
+            }
+        }
+        for (int r = r0 + rsub; r < r1; r += R) {
+            GV16 xv, gv;
+            xv.u = *(const uint4*)(x + base + (int64_t)r * C + c0);
+            if (MODE == 1) gv.u = *(const uint4*)(dy + base + (int64_t)r * C + c0);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float xe = gv_get<T>(xv, e);
+                if (MODE == 0) {
+                    a1[e] += xe;
+                    a2[e] += xe * xe;
+                } else {
+                    const float xh = (xe - mu[e]) * rs[e];
+                    float g = gv_get<T>(gv, e);
+                    if (silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
+                    g *= gm[e];
+                    a1[e] += g;
+                    a2[e] += g * xh;
+                }
+            }
+        }
+        // fold the EPV channels into their groups (consecutive channels mostly share a group)
+        int gcur = c0 / cpg;
+        float f1 = 0.f, f2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int ge = (c0 + e) / cpg;
+            if (ge != gcur) {
+                atomicAdd(&s_a[gcur], f1);
+                atomicAdd(&s_b[gcur], f2);
+                gcur = ge; f1 = 0.f; f2 = 0.f;
+            }
+            f1 += a1[e];
+            f2 += a2[e];
+        }
+        atomicAdd(&s_a[gcur], f1);
+        atomicAdd(&s_b[gcur], f2);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_a[threadIdx.x]);
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_b[threadIdx.x]);
+    }
+}
+
+// MODE 0: y = silu?(xhat*gamma+beta).   MODE 1: dx = rstd * (g - (s1 + xhat*s2)/n)
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void gn_vapply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ stats, const double* __restrict__ ws,
+                                                       T* __restrict__ out, int HW, int C, int G, int silu,
+                                                       int64_t nvec) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int VPR = C / EPV;
+    const int cpg = C / G;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * NT) {
+        const int64_t row = i / VPR;
+        const int c0 = (int)(i - row * VPR) * EPV;
+        const int b = (int)(row / HW);
+        GV16 xv, gv, ov;
+        xv.u = *(const uint4*)(x + i * EPV);
+        if (MODE == 1) gv.u = *(const uint4*)(dy + i * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = c0 + e;
+            const int64_t sg = (int64_t)b * G + c / cpg;
+            const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
+            const float xh = (gv_get<T>(xv, e) - mean) * rstd;
+            if (MODE == 0) {
+                float v = xh * gamma[c] + beta[c];
+                if (silu) v = silu_f(v);
+                gv_set<T>(ov, e, v);
+            } else {
+                float g = gv_get<T>(gv, e);
+                if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
+                g *= gamma[c];
+                const float s1 = (float)ws[2 * sg], s2 = (float)ws[2 * sg + 1];
+                gv_set<T>(ov, e, rstd * (g - (s1 + xh * s2) * inv_n));
+            }
+        }
+        *(uint4*)(out + i * EPV) = ov.u;
+    }
+}
+
+static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
+    const int vpr = C / epv;
+    const int R = vpr >= NT ? 1 : NT / vpr;
+    int64_t rpb = cdiv64((int64_t)B * HW, 1024);  // ~4 blocks per CU
+    if (rpb < 4 * R) rpb = 4 * R;
+    if (rpb > HW) rpb = HW;
+    return (int)rpb;
+}
+
+template <typename T>
+static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int B,
+                       int64_t HW, int C, int G, float eps, int silu, hipStream_t st) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int rpb = gn_rows_per_block(B, HW, C, EPV);
+    dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
+    hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
+                       (const float*)nullptr, ws, (int)HW, C, G, silu, rpb);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, (const double*)ws, stats, B * G,
+                       (double)HW * (C / G), eps);
+    const int64_t nvec = (int64_t)B * HW * C / EPV;
+    hipLaunchKernelGGL((gn_vapply_kernel<T, 0>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
+                       (const T*)nullptr, gamma, beta, (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G,
+                       silu, nvec);
+}
+
+template <typename T>
+static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
+                       double* ws, int B, int64_t HW, int C, int G, int silu, hipStream_t st) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int rpb = gn_rows_per_block(B, HW, C, EPV);
+    dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
+    hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
+                       (int)HW, C, G, silu, rpb);
+    const int64_t nvec = (int64_t)B * HW * C / EPV;
+    hipLaunchKernelGGL((gn_vapply_kernel<T, 1>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
+                       (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, nvec);
+}
+
+static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int64_t HW) {
+    const int epv = dtype == COMAT_BF16 ? 8 : 4;
+    return (C % epv) == 0 && C / epv <= NT * VSLOTS && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 &&
+           HW < (1ll << 31);
+}
+
 // ---- LayerNorm: one wave per row ----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
@@ -221,6 +399,11 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
         comat_set_error("comat_groupnorm_fwd: memset failed");
         return COMAT_ELAUNCH;
     }
+    if (gn_vec_ok(x, y, C, dtype, HW)) {
+        if (dtype == COMAT_BF16) gn_fwd_vec<bf16_t>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
+        else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
+        return comat_check_launch("comat_groupnorm_fwd");
+    }
     dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
     const int64_t total = (int64_t)B * HW * C;
     if (dtype == COMAT_BF16)
@@ -250,6 +433,11 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
         comat_set_error("comat_groupnorm_bwd: memset failed");
         return COMAT_ELAUNCH;
+    }
+    if (gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0) {
+        if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
+        else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
+        return comat_check_launch("comat_groupnorm_bwd");
     }
     dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
     const int64_t total = (int64_t)B * HW * C;

@@ -515,6 +515,7 @@ class _Attention(Function):
                sB=(Nk * HD, d), sC=(Nq * HD, d))
         ctx.save_for_backward(q, k_, v, P)
         ctx.cfg = (B, Nq, Nk, H, d, scale)
+        ctx.set_materialize_grads(False)  # an unused probability output must not cost a zero-filled gradient
         return O, P
 
     @staticmethod
@@ -526,6 +527,8 @@ class _Attention(Function):
         HD = H * d
         sP = (H * Nq * Nk, Nq * Nk)
         dV = dQ = dK = None
+        if gO is None and gP is None:
+            return (None,) * 11
         if gO is None:
             gO = torch.zeros((B * Nq, HD), dtype=q.dtype, device=dev)
         gO = _c(gO)

@@ -59,6 +59,8 @@ typedef struct {
     int32_t in_dtype;   /* dtype of A and B */
     int32_t out_dtype;  /* dtype of C */
     int32_t r_dtype;    /* dtype of R */
+    void* ws;           /* optional caller-owned fp32 workspace for split-K partial slabs (NULL: never split) */
+    int64_t ws_bytes;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 
@@ -81,6 +83,8 @@ typedef struct {
     float alpha, beta;
     int32_t act;
     int32_t in_dtype, out_dtype, r_dtype;
+    void* ws;           /* optional caller-owned fp32 split-K workspace */
+    int64_t ws_bytes;
 } comat_conv_params;
 int comat_conv2d(const comat_conv_params* p, void* stream);
 
