@@ -1,0 +1,66 @@
+"""N>1 data-parallel path on CPU: 2 ranks over gloo, kernels simulated (tests/sim_backend.py).  Checks the DDP
+semantics the reference gets from accelerate (training_script.py:659): after the step every rank holds the MEAN of
+the ranks' LoRA gradients and identical updated parameters, although each rank saw a different prompt/latents."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from comat_amd import dist as cdist
+    from comat_amd import ops
+    from sim_backend import SimKernels
+    from test_step import make_world
+    ops.set_kernel_backend(SimKernels())
+    r, w, dev = cdist.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg, batch, W, trainer = make_world(torch.float32, dev, False)
+    g = torch.Generator().manual_seed(100 + rank)  # each rank: its own prompt / latents
+    batch["latents"] = torch.randn(batch["latents"].shape, generator=g)
+    batch["prompt_embeds"] = torch.randn(batch["prompt_embeds"].shape, generator=g)
+    # local gradient of this rank (no reduction), for the reference mean
+    trainer.bank.zero_grad()
+    out = trainer.compute_losses(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    out["loss"].backward()
+    local = trainer.bank.flat_grad.clone()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    mean = torch.stack(gathered).mean(0)
+    # the real step: reduces, clips, updates
+    p0 = trainer.bank.flat.clone()
+    trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    torch.save(dict(mean=mean, reduced=trainer.bank.flat_grad.clone(), params=trainer.bank.flat.clone(), p0=p0,
+                    local=local), os.path.join(out_dir, f"rank{rank}.pt"))
+    cdist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_grad_mean(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(world)]
+    assert not torch.allclose(r[0]["local"], r[1]["local"])           # ranks really saw different data
+    for i in range(world):
+        assert torch.allclose(r[i]["reduced"], r[i]["mean"], rtol=1e-5, atol=1e-7)  # all-reduce(mean)
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])
+    assert torch.equal(r[0]["params"], r[1]["params"])                  # replicas stay in sync
+    assert not torch.equal(r[0]["params"], r[0]["p0"])
