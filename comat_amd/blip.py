@@ -120,7 +120,7 @@ class Blip:
         for Lr in self.vlayers:
             x = ops.layer_norm(h, *Lr["ln1"], eps=cfg.v_eps)
             q, k, v = (ops.linear(x, w) for w in Lr["qkv"])
-            o, _ = ops.attention(q, k, v, B, N, N, nh, d // nh)
+            o, _ = ops.attention(q, k, v, B, N, N, nh, d // nh, need_probs=False)
             h = ops.linear(o, Lr["proj"], residual=h)
             x = ops.layer_norm(h, *Lr["ln2"], eps=cfg.v_eps)
             h = ops.linear(ops.gelu(ops.linear(x, Lr["fc1"])), Lr["fc2"], residual=h)
@@ -142,7 +142,7 @@ class Blip:
             h = ops.layer_norm(ops.linear(o, Lr["so"], residual=h), *Lr["sln"], eps=cfg.t_eps)
             q = ops.linear(h, Lr["cq"])
             k, v = ops.linear(image_embeds, Lr["ck"]), ops.linear(image_embeds, Lr["cv"])
-            o, _ = ops.attention(q, k, v, B, T, N_img, nh, hdim // nh)
+            o, _ = ops.attention(q, k, v, B, T, N_img, nh, hdim // nh, need_probs=False)
             h = ops.layer_norm(ops.linear(o, Lr["co"], residual=h), *Lr["cln"], eps=cfg.t_eps)
             f = ops.gelu(ops.linear(h, Lr["fi"]))
             h = ops.layer_norm(ops.linear(f, Lr["fo"], residual=h), *Lr["fln"], eps=cfg.t_eps)

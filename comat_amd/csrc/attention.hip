@@ -1,0 +1,493 @@
+// attention.hip — fused (flash-style) attention forward and backward on MFMA for gfx950.
+//
+// Used wherever the probability map itself is not needed (UNet self-attention: 4096^2 scores per head at 64x64 latents
+// that the reference materialises through its patched Attention.forward, attn_utils/tc_attn_utils.py:126-146; BLIP
+// ViT self-attention; cross-attention on steps that do not capture maps).  Scores never touch HBM: per 32-key tile the
+// wave computes S^T = K Q^T with MFMA, does the online softmax in registers and feeds P^T straight back into MFMA.
+//
+// Transposed formulation (the wave64 trick): with S^T [keys x queries] in the 32x32 accumulator layout
+// (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)), every lane owns ONE query column, so the softmax
+// statistics (running max m, sum l, LSE, D) are per-lane scalars and the row reductions are over the lane's own 16
+// registers plus one xor-32 shuffle.  The same registers, converted to the storage type, are the B operand of the next
+// MFMA (O^T += V^T P^T), because any k-permutation shared by the A and B fragments cancels in the sum: the A fragment
+// (V^T, K^T, Q^T, dO^T) is gathered from the LDS tile with the identical key order.
+//
+// Kernels (T = bf16 -> v_mfma_f32_32x32x16_bf16, T = fp32 -> exact v_mfma_f32_32x32x2_f32; DMAX = padded head dim):
+//   flash_fwd   : block = 4 waves x 32 queries, loops over 32-key tiles (K,V staged through LDS, register prefetch)
+//   flash_prep  : D[q] = sum_d dO[q,d] * O[q,d]
+//   flash_dq    : same geometry as forward; dQ^T += K^T dS^T
+//   flash_dkdv  : block = 4 waves x 32 keys, loops over 32-query tiles; dV^T += dO^T P, dK^T += Q^T dS
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+template <typename T> struct FragOf;
+template <> struct FragOf<bf16_t> { typedef short8_t type; };
+template <> struct FragOf<float> { typedef f32x4_t type; };
+
+union V16 {
+    uint4 u;
+    float f[4];
+    bf16_t h[8];
+};
+
+__device__ __forceinline__ void mma(f32x16_t& acc, const short8_t& a, const short8_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                  acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x16_t& acc, const f32x4_t& a, const f32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+// accumulator register i of lane-half hh  <->  row index inside the 32x32 tile
+__device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+template <typename T, int DMAX> struct Geo {
+    static constexpr int KC = 16 / sizeof(T);             // elements per 16-byte chunk
+    static constexpr int NKS = DMAX / (2 * KC);           // MFMA k-steps over the head dim
+    static constexpr int NJ = 32 / (2 * KC);              // MFMA k-steps over a 32-row tile
+    static constexpr int NT32 = DMAX / 32;                // 32-wide output tiles over the head dim
+    static constexpr int RS = DMAX * (int)sizeof(T) + 16;  // LDS row stride in bytes (16-B pad)
+    static constexpr int CPRW = DMAX * (int)sizeof(T) / 16;
+    static constexpr int NCHK = (32 * CPRW + NT - 1) / NT;
+    static constexpr int TILE_BYTES = 32 * RS;
+};
+
+// cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
+template <typename T, int DMAX> struct TileMover {
+    typedef Geo<T, DMAX> G;
+    uint4 regs[G::NCHK];
+    __device__ __forceinline__ void load(const T* base, int64_t ld, int row0, int nrows, int d) {
+#pragma unroll
+        for (int i = 0; i < G::NCHK; ++i) {
+            const int c = threadIdx.x + i * NT;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < 32 * G::CPRW) {
+                const int rr = c / G::CPRW, col = (c % G::CPRW) * G::KC;
+                if (row0 + rr < nrows && col < d) v = *(const uint4*)(base + (int64_t)(row0 + rr) * ld + col);
+            }
+            regs[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* lds) const {
+#pragma unroll
+        for (int i = 0; i < G::NCHK; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (c < 32 * G::CPRW) *(uint4*)(lds + (c / G::CPRW) * G::RS + (c % G::CPRW) * 16) = regs[i];
+        }
+    }
+};
+
+// fragment with rows = tile rows, k = head-dim chunk (k-contiguous 16-byte read)
+template <typename T, int DMAX>
+__device__ __forceinline__ typename FragOf<T>::type frag_kc(const char* lds, int row, int s, int hh) {
+    return *(const typename FragOf<T>::type*)(lds + row * Geo<T, DMAX>::RS + s * 32 + hh * 16);
+}
+// fragment with rows = head-dim index n, k = tile rows in accumulator order (gathered, k-major)
+template <typename T, int DMAX>
+__device__ __forceinline__ typename FragOf<T>::type frag_km(const char* lds, int n, int j, int hh) {
+    constexpr int KC = Geo<T, DMAX>::KC;
+    V16 v;
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        const char* p = lds + crow(KC * j + e, hh) * Geo<T, DMAX>::RS + n * (int)sizeof(T);
+        if (sizeof(T) == 2) v.h[e] = *(const bf16_t*)p;
+        else v.f[e] = *(const float*)p;
+    }
+    typename FragOf<T>::type out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+// accumulator registers KC*j .. KC*j+KC-1 as a fragment of the storage type
+template <typename T> __device__ __forceinline__ typename FragOf<T>::type pack_acc(const f32x16_t& a, int j) {
+    constexpr int KC = 16 / sizeof(T);
+    V16 v;
+#pragma unroll
+    for (int e = 0; e < KC; ++e) {
+        if (sizeof(T) == 2) v.h[e] = f32_to_bf16(a[KC * j + e]);
+        else v.f[e] = a[KC * j + e];
+    }
+    typename FragOf<T>::type out;
+    __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+// per-lane fragment (column = this lane's row of the global matrix, chunk 2s+hh of the head dim) straight from HBM
+template <typename T, int DMAX>
+__device__ __forceinline__ void load_col_frags(typename FragOf<T>::type* f, const T* base, int64_t ld, int row,
+                                               int nrows, int d, int hh) {
+    typedef Geo<T, DMAX> G;
+#pragma unroll
+    for (int s = 0; s < G::NKS; ++s) {
+        const int col = (2 * s + hh) * G::KC;
+        V16 v;
+        v.u = make_uint4(0, 0, 0, 0);
+        if (row < nrows && col < d) v.u = *(const uint4*)(base + (int64_t)row * ld + col);
+        __builtin_memcpy(&f[s], &v, 16);
+    }
+}
+
+struct FlashArgs {
+    const void *Q, *K, *V, *O, *dO;
+    void *Out, *dQ, *dK, *dV;
+    float* lse;
+    float* Dbuf;
+    int B, H, Nq, Nk, d;
+    int64_t ldq, ldk, ldv, ldo;
+    float scale;
+};
+
+template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
+    typedef Geo<T, DMAX> G;
+    typedef typename FragOf<T>::type F;
+    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
+    char* Kt = smem;
+    char* Vt = smem + G::TILE_BYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+
+    F qf[G::NKS];
+    load_col_frags<T, DMAX>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    f32x16_t oT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oT[t][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    TileMover<T, DMAX> km, vm;
+    const int ntiles = (a.Nk + 31) / 32;
+    km.load(Kb, a.ldk, 0, a.Nk, a.d);
+    vm.load(Vb, a.ldv, 0, a.Nk, a.d);
+    km.store(Kt);
+    vm.store(Vt);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            km.load(Kb, a.ldk, (t + 1) * 32, a.Nk, a.d);
+            vm.load(Vb, a.ldv, (t + 1) * 32, a.Nk, a.d);
+        }
+        f32x16_t st;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < G::NKS; ++s) mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float v = (t * 32 + crow(i, hh) < a.Nk) ? st[i] * a.scale : -INFINITY;
+            st[i] = v;
+            mt = fmaxf(mt, v);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m, mt);
+        const float alpha = __expf(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __expf(st[i] - m_new);
+            st[i] = p;
+            ps += p;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oT[t2][i] *= alpha;
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            const F pb = pack_acc<T>(st, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
+        }
+        __syncthreads();
+        if (more) {
+            km.store(Kt);
+            vm.store(Vt);
+            __syncthreads();
+        }
+    }
+    if (q < a.Nq) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
+            }
+        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m + __logf(l);
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void flash_prep_kernel(FlashArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;  // (b*H + h)*Nq + q
+    const int64_t total = (int64_t)a.B * a.H * a.Nq;
+    if (idx >= total) return;
+    const int q = (int)(idx % a.Nq);
+    const int bh = (int)(idx / a.Nq);
+    const int b = bh / a.H, h = bh % a.H;
+    const T* o = (const T*)a.O + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
+    const T* g = (const T*)a.dO + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
+    float acc = 0.f;
+    for (int c = 0; c < a.d; ++c) acc += ldf<T>(o + c) * ldf<T>(g + c);
+    a.Dbuf[idx] = acc;
+}
+
+template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
+    typedef Geo<T, DMAX> G;
+    typedef typename FragOf<T>::type F;
+    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
+    char* Kt = smem;
+    char* Vt = smem + G::TILE_BYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    T* dQb = (T*)a.dQ + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    F qf[G::NKS], gf[G::NKS];
+    load_col_frags<T, DMAX>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    load_col_frags<T, DMAX>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
+    const float lse_q = q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
+    const float D_q = q < a.Nq ? a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
+    f32x16_t dqT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqT[t][i] = 0.f;
+    TileMover<T, DMAX> km, vm;
+    const int ntiles = (a.Nk + 31) / 32;
+    km.load(Kb, a.ldk, 0, a.Nk, a.d);
+    vm.load(Vb, a.ldv, 0, a.Nk, a.d);
+    km.store(Kt);
+    vm.store(Vt);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            km.load(Kb, a.ldk, (t + 1) * 32, a.Nk, a.d);
+            vm.load(Vb, a.ldv, (t + 1) * 32, a.Nk, a.d);
+        }
+        f32x16_t st, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < G::NKS; ++s) {
+            mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
+            mma(dp, frag_kc<T, DMAX>(Vt, r, s, hh), gf[s]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = (t * 32 + crow(i, hh) < a.Nk) ? __expf(st[i] * a.scale - lse_q) : 0.f;
+            st[i] = p * (dp[i] - D_q) * a.scale;
+        }
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            const F db = pack_acc<T>(st, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
+        }
+        __syncthreads();
+        if (more) {
+            km.store(Kt);
+            vm.store(Vt);
+            __syncthreads();
+        }
+    }
+    if (q < a.Nq) {
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, dqT[t2][i]);
+            }
+    }
+}
+
+template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
+    typedef Geo<T, DMAX> G;
+    typedef typename FragOf<T>::type F;
+    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + 256];
+    char* Qt = smem;
+    char* Gt = smem + G::TILE_BYTES;
+    float* lse_s = (float*)(smem + 2 * G::TILE_BYTES);
+    float* D_s = lse_s + 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    T* dKb = (T*)a.dK + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    T* dVb = (T*)a.dV + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const int key = blockIdx.x * 128 + wave * 32 + r;
+    F kf[G::NKS], vf[G::NKS];
+    load_col_frags<T, DMAX>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
+    load_col_frags<T, DMAX>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
+    f32x16_t dkT[G::NT32], dvT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkT[t][i] = 0.f; dvT[t][i] = 0.f; }
+    const float* lse_g = a.lse + (int64_t)blockIdx.y * a.Nq;
+    const float* D_g = a.Dbuf + (int64_t)blockIdx.y * a.Nq;
+    TileMover<T, DMAX> qm, gm;
+    const int ntiles = (a.Nq + 31) / 32;
+    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31
+    qm.load(Qb, a.ldq, 0, a.Nq, a.d);
+    gm.load(Gb, a.ldo, 0, a.Nq, a.d);
+    if (threadIdx.x < 32) {
+        const int qi = threadIdx.x;
+        lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
+        D_r = qi < a.Nq ? D_g[qi] : 0.f;
+    }
+    qm.store(Qt);
+    gm.store(Gt);
+    if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            qm.load(Qb, a.ldq, (t + 1) * 32, a.Nq, a.d);
+            gm.load(Gb, a.ldo, (t + 1) * 32, a.Nq, a.d);
+            if (threadIdx.x < 32) {
+                const int qi = (t + 1) * 32 + threadIdx.x;
+                lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
+                D_r = qi < a.Nq ? D_g[qi] : 0.f;
+            }
+        }
+        f32x16_t sc, dp;  // [query rows x key cols]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < G::NKS; ++s) {
+            mma(sc, frag_kc<T, DMAX>(Qt, r, s, hh), kf[s]);
+            mma(dp, frag_kc<T, DMAX>(Gt, r, s, hh), vf[s]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = crow(i, hh);
+            const bool valid = (t * 32 + qr < a.Nq) && (key < a.Nk);
+            const float p = valid ? __expf(sc[i] * a.scale - lse_s[qr]) : 0.f;
+            sc[i] = p;
+            dp[i] = p * (dp[i] - D_s[qr]) * a.scale;
+        }
+#pragma unroll
+        for (int j = 0; j < G::NJ; ++j) {
+            const F pb = pack_acc<T>(sc, j);
+            const F db = pack_acc<T>(dp, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) {
+                mma(dvT[t2], frag_km<T, DMAX>(Gt, t2 * 32 + r, j, hh), pb);
+                mma(dkT[t2], frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            qm.store(Qt);
+            gm.store(Gt);
+            if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
+            __syncthreads();
+        }
+    }
+    if (key < a.Nk) {
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) {
+                    stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
+                    stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
+                }
+            }
+    }
+}
+
+template <typename T, int DMAX> void launch_fwd(const FlashArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+}
+template <typename T, int DMAX> void launch_bwd(const FlashArgs& a, hipStream_t st) {
+    const int64_t total = (int64_t)a.B * a.H * a.Nq;
+    hipLaunchKernelGGL((flash_prep_kernel<T>), dim3((unsigned)cdiv64(total, NT)), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+}
+
+template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
+#define FA_CASE(D)                     \
+    if (a.d <= D) {                    \
+        if (bwd) launch_bwd<T, D>(a, st); \
+        else launch_fwd<T, D>(a, st);  \
+        return 0;                      \
+    }
+    FA_CASE(32)
+    FA_CASE(64)
+    FA_CASE(96)
+    FA_CASE(160)
+#undef FA_CASE
+    return -1;
+}
+
+int check_args(const char* what, const void* Q, const void* K, const void* V, int B, int H, int Nq, int Nk, int d,
+               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int dtype) {
+    COMAT_REQUIRE(Q && K && V, "%s: null pointer", what);
+    COMAT_REQUIRE(B > 0 && H > 0 && Nq > 0 && Nk > 0 && d > 0 && (int64_t)B * H <= 65535, "%s: bad shape", what);
+    COMAT_REQUIRE(dtype_ok(dtype), "%s: bad dtype", what);
+    const int kc = dtype == COMAT_BF16 ? 8 : 4;
+    COMAT_REQUIRE(d <= 160 && d % kc == 0, "%s: head dim %d unsupported (<=160, multiple of %d)", what, d, kc);
+    COMAT_REQUIRE(ldq % kc == 0 && ldk % kc == 0 && ldv % kc == 0 && ldo % kc == 0, "%s: leading dims must be 16-byte multiples", what);
+    COMAT_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, "%s: operands must be 16-byte aligned", what);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B,
+                                    int32_t H, int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk,
+                                    int64_t ldv, int64_t ldo, float scale, int32_t dtype, void* stream) {
+    if (int rc = check_args("comat_flash_attn_fwd", Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
+    COMAT_REQUIRE(O && lse, "comat_flash_attn_fwd: null output");
+    FlashArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.Out = O; a.lse = lse;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    const int rc = dtype == COMAT_BF16 ? dispatch<bf16_t>(a, false, (hipStream_t)stream)
+                                       : dispatch<float>(a, false, (hipStream_t)stream);
+    COMAT_REQUIRE(rc == 0, "comat_flash_attn_fwd: unsupported head dim");
+    return comat_check_launch("comat_flash_attn_fwd");
+}
+
+extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                                    const float* lse, float* Dbuf, void* dQ, void* dK, void* dV, int32_t B, int32_t H,
+                                    int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv,
+                                    int64_t ldo, float scale, int32_t dtype, void* stream) {
+    if (int rc = check_args("comat_flash_attn_bwd", Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
+    COMAT_REQUIRE(O && dO && lse && Dbuf && dQ && dK && dV, "comat_flash_attn_bwd: null pointer");
+    COMAT_REQUIRE((((uintptr_t)dO) & 15) == 0, "comat_flash_attn_bwd: dO must be 16-byte aligned");
+    FlashArgs a = {};
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.lse = (float*)lse; a.Dbuf = Dbuf;
+    a.dQ = dQ; a.dK = dK; a.dV = dV;
+    a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    const int rc = dtype == COMAT_BF16 ? dispatch<bf16_t>(a, true, (hipStream_t)stream)
+                                       : dispatch<float>(a, true, (hipStream_t)stream);
+    COMAT_REQUIRE(rc == 0, "comat_flash_attn_bwd: unsupported head dim");
+    return comat_check_launch("comat_flash_attn_bwd");
+}

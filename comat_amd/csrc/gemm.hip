@@ -537,9 +537,9 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
         p.splits = s < 1 ? 1 : (int)s;
         return p;
     }
-    if (ws_bytes > 0 && blocks < 512 && nk >= 8) {
+    if (ws_bytes > 0 && blocks <= 256 && nk >= 32) {  // only long serial k-loops on a mostly idle chip are worth a reduce pass
         int64_t s = cdiv64(768, blocks);
-        if (s > nk / 4) s = nk / 4;
+        if (s > nk / 8) s = nk / 8;
         const int64_t cap = ws_bytes / (batch * M * N * 4);
         if (s > cap) s = cap;
         if (s > 64) s = 64;

@@ -66,14 +66,18 @@ class LoRAPair:
     """fp32 master LoRA factors (trainable leaves) with cached compute-dtype copies.
     y += scale * up(down(x)); down [r, in], up [out, r]  (diffusers LoRALinearLayer)."""
 
-    def __init__(self, down: torch.Tensor, up: torch.Tensor, dtype, scale=1.0):
+    def __init__(self, down: torch.Tensor, up: torch.Tensor, dtype, scale=1.0, bank=None, views=None):
         self.down, self.up = down, up  # views into the flat fp32 parameter buffer, requires_grad
         self.dtype, self.scale = dtype, scale
         self._cache = None
+        self.bank, self.views = bank, views  # optional: compute-dtype views of the bank's flat compute copy
 
     def compute_copies(self):
         if self.dtype == torch.float32:
             return self.down.detach(), self.up.detach()
+        if self.bank is not None:
+            self.bank.ensure_compute_copy()
+            return self.views
         key = (self.down._version, self.up._version)
         if self._cache is None or self._cache[0] != key:
             self._cache = (key, cast(self.down.detach(), self.dtype), cast(self.up.detach(), self.dtype))
@@ -292,11 +296,11 @@ def add_rowvec(x, v):
 # ----------------------------------------------------------------------------------------------------------------
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, residual, lin, act):
+    def forward(ctx, x, residual, lin, act, out_dtype=None):
         x = _c(x)
         M, Kd = x.shape
         N = lin.out_features
-        y = x.new_empty((M, N))
+        y = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
         if residual is not None:
             residual = _c(residual)
         kernels().gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
@@ -315,12 +319,12 @@ class _Linear(Function):
         if ctx.needs_input_grad[0]:
             dx = g.new_empty((M, Kd))
             kernels().gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)
-        return dx, (g if ctx.has_res else None), None, None
+        return dx, (g if ctx.has_res else None), None, None, None
 
 
-def linear(x, lin: FrozenLinear, residual=None, act=ACT_NONE):
-    """y = x W^T + b (+ residual); W frozen."""
-    return _Linear.apply(x, residual, lin, act)
+def linear(x, lin: FrozenLinear, residual=None, act=ACT_NONE, out_dtype=None):
+    """y = x W^T + b (+ residual); W frozen.  `out_dtype` (no-grad use) lets the GEMM epilogue emit fp32 directly."""
+    return _Linear.apply(x, residual, lin, act, out_dtype)
 
 
 class _LoRALinear(Function):
@@ -344,8 +348,9 @@ class _LoRALinear(Function):
                beta=1.0 if residual is not None else 0.0)
         k.gemm(h, uc, y, M, N, r, r, r, N, R=y, ldr=N, alpha=lora.scale, beta=1.0)
         ctx.save_for_backward(x, h, dc, uc)
-        ctx.lin, ctx.scale = lin, lora.scale
+        ctx.lin, ctx.scale, ctx.lora = lin, lora.scale, lora
         ctx.has_res = residual is not None
+        assert lora.down.grad is not None and lora.up.grad is not None, "LoRA factors need preallocated .grad views"
         return y
 
     @staticmethod
@@ -361,12 +366,16 @@ class _LoRALinear(Function):
         dh = g.new_empty((M, r))
         k.gemm(g, uc, dh, M, r, N, N, r, r, transB=True, alpha=s)
         d_up = d_down = dx = None
-        if ctx.needs_input_grad[3]:  # dU [N, r] = s * g^T h
-            d_up = torch.empty((N, r), dtype=torch.float32, device=g.device)
-            k.gemm(g, h, d_up, N, r, M, N, r, r, transA=True, transB=True, alpha=s)
-        if ctx.needs_input_grad[2]:  # dD [r, K] = dh^T x
-            d_down = torch.empty((r, Kd), dtype=torch.float32, device=g.device)
-            k.gemm(dh, x, d_down, r, Kd, M, r, Kd, Kd, transA=True, transB=True)
+        # LoRA weight gradients are ACCUMULATED by the GEMM epilogue straight into the flat fp32 gradient buffer
+        # (lora.up.grad / lora.down.grad are views of it), so autograd returns None for them: no temporary, no
+        # separate accumulate kernel per factor and per UNet call.
+        lora = ctx.lora
+        if ctx.needs_input_grad[3]:  # dU [N, r] += s * g^T h
+            gu = lora.up.grad
+            k.gemm(g, h, gu, N, r, M, N, r, r, transA=True, transB=True, alpha=s, R=gu, ldr=r, beta=1.0)
+        if ctx.needs_input_grad[2]:  # dD [r, K] += dh^T x
+            gd = lora.down.grad
+            k.gemm(dh, x, gd, r, Kd, M, r, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
         if ctx.needs_input_grad[0]:
             dx = g.new_empty((M, Kd))
             k.gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)
@@ -556,10 +565,43 @@ class _Attention(Function):
         return dQ, dK, dV, None, None, None, None, None, None, None, None
 
 
-def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None):
-    """q: [B*Nq, heads*dim], k/v: [B*Nk, heads*dim] -> (out [B*Nq, heads*dim], probs [B, heads, Nq, Nk])."""
+class _FlashAttention(Function):
+    """Fused attention (scores stay on chip); saves Q, K, V, O and the per-row log-sum-exp for the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k_, v, B, Nq, Nk, H, d, scale):
+        q, k_, v = _c(q), _c(k_), _c(v)
+        HD = H * d
+        O = q.new_empty((B * Nq, HD))
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        kernels().flash_attn_fwd(q, k_, v, O, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
+        ctx.save_for_backward(q, k_, v, O, lse)
+        ctx.cfg = (B, Nq, Nk, H, d, scale)
+        return O
+
+    @staticmethod
+    def backward(ctx, gO):
+        q, k_, v, O, lse = ctx.saved_tensors
+        B, Nq, Nk, H, d, scale = ctx.cfg
+        HD = H * d
+        gO = _c(gO)
+        dQ, dK, dV = torch.empty_like(q), torch.empty_like(k_), torch.empty_like(v)
+        dbuf = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        kernels().flash_attn_bwd(q, k_, v, O, gO, lse, dbuf, dQ, dK, dV, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
+        return dQ, dK, dV, None, None, None, None, None, None
+
+
+def flash_ok(dim, dtype):
+    return dim <= 160 and dim % (8 if dtype == torch.bfloat16 else 4) == 0
+
+
+def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None, need_probs=True):
+    """q: [B*Nq, heads*dim], k/v: [B*Nk, heads*dim] -> (out [B*Nq, heads*dim], probs [B, heads, Nq, Nk] or None).
+    `need_probs=False` selects the fused kernel (no probability map in HBM) when the layer allows it."""
     if scale is None:
         scale = dim ** -0.5
+    if not need_probs and not causal and key_mask is None and flash_ok(dim, q.dtype):
+        return _FlashAttention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale)), None
     return _Attention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale), bool(causal), key_mask)
 
 

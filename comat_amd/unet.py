@@ -61,12 +61,30 @@ class LoRABank:
             p.grad = self.flat_grad[off:off + num].view(shp)
             self.params[n] = p
             off += num
+        # ONE compute-dtype copy of the whole flat buffer, refreshed by one cast kernel per optimizer step
+        self.dtype = dtype
+        self.flat_c = None if dtype == torch.float32 else torch.empty(total, dtype=dtype, device=device)
+        self._fresh = False
+        offs = {}
+        off = 0
+        for n, shp in zip(self.names, sizes):
+            offs[n] = (off, shp)
+            off += shp[0] * shp[1]
         self.pairs = {}
         for path, _, _, _ in attention_names(cfg):
             for proj in ("to_q", "to_k", "to_v", "to_out.0"):
                 base = f"{path}.{proj}"
+                views = None
+                if self.flat_c is not None:
+                    (od, sd), (ou, su) = offs[base + ".lora.down.weight"], offs[base + ".lora.up.weight"]
+                    views = (self.flat_c[od:od + sd[0] * sd[1]].view(sd), self.flat_c[ou:ou + su[0] * su[1]].view(su))
                 self.pairs[base] = ops.LoRAPair(self.params[base + ".lora.down.weight"],
-                                                self.params[base + ".lora.up.weight"], dtype)
+                                                self.params[base + ".lora.up.weight"], dtype, bank=self, views=views)
+
+    def ensure_compute_copy(self):
+        if not self._fresh and self.flat_c is not None:
+            ops.kernels().unary(ops.UN_COPY, self.flat, self.flat_c, self.flat.numel())
+            self._fresh = True
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -76,8 +94,7 @@ class LoRABank:
 
     def mark_updated(self):
         """call after an in-place update of `flat` by the optimizer kernel: drops the cached compute-dtype copies."""
-        for pr in self.pairs.values():
-            pr._cache = None
+        self._fresh = False
 
     def set_requires_grad(self, flag: bool):
         for p in self.params.values():
@@ -123,8 +140,10 @@ class ResBlock:
         h = ops.group_norm(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True)
         b2 = None
         if self.temb is not None:
-            with torch.no_grad():  # depends on t and frozen weights only
-                b2 = ops.cast(ops.linear(temb_act, self.temb), torch.float32)
+            b2 = temb_act.get(id(self))
+            if b2 is None:
+                with torch.no_grad():  # depends on t and frozen weights only: computed once per timestep value
+                    b2 = temb_act[id(self)] = ops.linear(temb_act["silu_temb"], self.temb, out_dtype=torch.float32)
         h = ops.conv2d(h, self.c1, B, H, W, bias2=b2)
         h = ops.group_norm(h, *self.n2, B, HW, G=self.groups, eps=self.eps, silu=True)
         sc = x if self.short is None else ops.linear(x, self.short)
@@ -147,21 +166,21 @@ class CrossAttnBlock:
                 self.att[(a, p)] = (m.lin(key), lora.pairs[key] if lora is not None else None)
         self.ff1, self.ff2 = m.lin(f"{b}.ff.net.0.proj"), m.lin(f"{b}.ff.net.2")
 
-    def _attn(self, a, x, src, B, N, L):
+    def _attn(self, a, x, src, B, N, L, need_probs):
         q = ops.lora_linear(x, *self.att[(a, "to_q")])
         k = ops.lora_linear(src, *self.att[(a, "to_k")])
         v = ops.lora_linear(src, *self.att[(a, "to_v")])
         heads = self.cfg.num_heads
-        return ops.attention(q, k, v, B, N, L, heads, q.shape[1] // heads)
+        return ops.attention(q, k, v, B, N, L, heads, q.shape[1] // heads, need_probs=need_probs)
 
     def __call__(self, x, B, H, W, ctx, L, want_probs):
         N = H * W
         h = ops.group_norm(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
         h = ops.linear(h, self.proj_in)
         y = ops.layer_norm(h, *self.ln[0])
-        o, _ = self._attn("attn1", y, y, B, N, N)
+        o, _ = self._attn("attn1", y, y, B, N, N, False)
         h = ops.lora_linear(o, *self.att[("attn1", "to_out.0")], residual=h)
-        o, probs = self._attn("attn2", ops.layer_norm(h, *self.ln[1]), ctx, B, N, L)
+        o, probs = self._attn("attn2", ops.layer_norm(h, *self.ln[1]), ctx, B, N, L, want_probs)
         h = ops.lora_linear(o, *self.att[("attn2", "to_out.0")], residual=h)
         f = ops.geglu(ops.linear(ops.layer_norm(h, *self.ln[2]), self.ff1))
         h = ops.linear(f, self.ff2, residual=h)
@@ -193,15 +212,22 @@ class UNet:
             self.up.append((res, att, us))
         self.norm_out = m.norm("conv_norm_out")
         self.conv_out = m.conv("conv_out")
+        self._temb_cache = {}
 
     def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=()):
         """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
         maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}."""
         cfg = self.cfg
-        with torch.no_grad():
-            te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
-            te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
-            temb_act = ops.linear(te, self.t2, act=ops.ACT_SILU)  # SiLU(temb): every ResBlock consumes silu(temb)
+        # time-embedding MLP and the per-ResBlock projections depend only on (t, batch) and frozen weights: memoised
+        temb_act = self._temb_cache.get((int(t), B))
+        if temb_act is None:
+            with torch.no_grad():
+                te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
+                te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
+                # SiLU(temb): every ResBlock consumes silu(temb)
+                temb_act = {"silu_temb": ops.linear(te, self.t2, act=ops.ACT_SILU)}
+            if len(self._temb_cache) < 128:
+                self._temb_cache[(int(t), B)] = temb_act
         maps = {p: [] for p in capture_places}
         h = ops.conv2d(x, self.conv_in, B, H, W)
         skips = [h]
@@ -283,7 +309,7 @@ class VAEDecoder:
         N = H * W
         hn = ops.group_norm(h, *self.a_norm, B, N, G=g, eps=1e-6, silu=False)
         q, k, v = ops.linear(hn, self.a_q), ops.linear(hn, self.a_k), ops.linear(hn, self.a_v)
-        o, _ = ops.attention(q, k, v, B, N, N, 1, q.shape[1])
+        o, _ = ops.attention(q, k, v, B, N, N, 1, q.shape[1], need_probs=False)
         h = ops.linear(o, self.a_o, residual=h)
         h = self.mid1(h, B, H, W, None)
         hh, ww = H, W

@@ -121,6 +121,23 @@ int comat_softmax_bwd(const void* P, const void* dP, void* dS, int64_t rows, int
                       int32_t p_dtype, int32_t dp_dtype, int32_t ds_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * Fused (flash-style) attention for layers whose probability map is not captured: O = softmax(scale Q K^T) V per
+ * (batch, head), scores never written to HBM.  Q: [B*Nq, ldq], K/V: [B*Nk, ldk/ldv], O: [B*Nq, ldo] with head h in
+ * columns h*d .. (h+1)*d; lse: [B, H, Nq] fp32 log-sum-exp of the scaled scores (saved for backward).
+ * Head dim d <= 160, multiple of 8 (bf16) / 4 (fp32); leading dims and base pointers 16-byte aligned.
+ * bwd: Dbuf [B, H, Nq] fp32 caller workspace; dO has the layout of O; dQ/dK/dV the layouts of Q/K/V.
+ * Replaces the materialised softmax(QK^T)V of the reference's patched Attention.forward
+ * (attn_utils/tc_attn_utils.py:126-146) for self-attention (268 MB of fp16 scores per layer per sample at 64x64).
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B, int32_t H,
+                         int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         float scale, int32_t dtype, void* stream);
+int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                         const float* lse, float* Dbuf, void* dQ, void* dK, void* dV, int32_t B, int32_t H,
+                         int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         float scale, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Elementwise family (HBM-bound, 16-byte vectorised).
  * ---------------------------------------------------------------------------------------------------------- */
 enum { COMAT_UN_COPY = 0, COMAT_UN_SILU = 1, COMAT_UN_GELU = 2, COMAT_UN_AFFINE = 3 };

@@ -144,6 +144,28 @@ class SimKernels:
         g = dP.reshape(rows, cols).float()
         dS.reshape(rows, cols).copy_((scale * p * (g - (g * p).sum(-1, keepdim=True))).to(dS.dtype))
 
+    @staticmethod
+    def _heads(t, B, N, H, d, ld):
+        return _v(t, (B, H, N, d), (N * ld, d, ld, 1)).float()
+
+    def flash_attn_fwd(self, q, k, v, o, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+        qh, kh, vh = self._heads(q, B, Nq, H, d, ldq), self._heads(k, B, Nk, H, d, ldk), self._heads(v, B, Nk, H, d, ldv)
+        s = qh @ kh.transpose(-1, -2) * scale
+        lse.copy_(torch.logsumexp(s, -1))
+        _v(o, (B, H, Nq, d), (Nq * ldo, d, ldo, 1)).copy_((torch.softmax(s, -1) @ vh).to(o.dtype))
+
+    def flash_attn_bwd(self, q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+        qh, kh, vh = self._heads(q, B, Nq, H, d, ldq), self._heads(k, B, Nk, H, d, ldk), self._heads(v, B, Nk, H, d, ldv)
+        oh, gh = self._heads(o, B, Nq, H, d, ldo), self._heads(do, B, Nq, H, d, ldo)
+        p = torch.exp(qh @ kh.transpose(-1, -2) * scale - lse[..., None])
+        D = (oh * gh).sum(-1)
+        dbuf.copy_(D)
+        dp = gh @ vh.transpose(-1, -2)
+        ds = p * (dp - D[..., None]) * scale
+        _v(dv, (B, H, Nk, d), (Nk * ldv, d, ldv, 1)).copy_((p.transpose(-1, -2) @ gh).to(dv.dtype))
+        _v(dq, (B, H, Nq, d), (Nq * ldq, d, ldq, 1)).copy_((ds @ kh).to(dq.dtype))
+        _v(dk, (B, H, Nk, d), (Nk * ldk, d, ldk, 1)).copy_((ds.transpose(-1, -2) @ qh).to(dk.dtype))
+
     # ---- elementwise ---------------------------------------------------------------------------------------
     def unary(self, op, x, y, n, p0=0.0, p1=0.0):
         v = x.reshape(-1)[:n].float()

@@ -132,7 +132,7 @@ def test_sampler_k_of_n(dev, dtype, attrcon):
         assert list(pipe.attn_dict.keys()) == ["1"] and sorted(pipe.attn_dict["1"]) == sorted(ad_o["1"])
         for k in ad_o["1"]:
             for a, b in zip(pipe.attn_dict["1"][k], ad_o["1"][k]):
-                check(a, b, dtype, f"attn_dict {k}", factor=2)
+                check(a, b, dtype, f"attn_dict {k}", factor=2 if dtype == torch.float32 else 5)
         loss = loss + sum((m.float() * m.float()).sum() for m in pipe.attn_dict["1"]["up_4"])
     loss.backward()
     check(latf, lat_o, dtype, "final latents", factor=3)

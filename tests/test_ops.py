@@ -216,6 +216,31 @@ def test_attention(dev, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    (2, 4096, 4096, 8, 40),   # SD1.5 self-attention at 64x64 latents (bf16 run is the full-size property check)
+    (2, 70, 70, 2, 40), (1, 300, 77, 8, 80), (2, 64, 200, 2, 160), (1, 577, 577, 3, 64), (2, 16, 37, 2, 16),
+    (1, 130, 33, 1, 32), (1, 5, 577, 2, 96),
+])
+def test_flash_attention(dev, dtype, cfg):
+    B_, Nq, Nk, H, d = cfg
+    if Nq == 4096 and (dtype == torch.float32 or dev.type == "cpu"):
+        pytest.skip("full-size case runs in bf16 on the GPU only")
+    q, k, v = (rnd(B_ * n, H * d, dtype=dtype, seed=s) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    go = rnd(B_ * Nq, H * d, dtype=dtype, seed=4)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = ref_attention(qr, kr, vr, B_, Nq, Nk, H, d, False, None)
+    (o_ref * go).sum().backward()
+    qd, kd, vd = (dv(t, dev, dtype, grad=True) for t in (q, k, v))
+    o, p = ops.attention(qd, kd, vd, B_, Nq, Nk, H, d, need_probs=False)
+    assert p is None
+    (o.float() * dv(go, dev)).sum().backward()
+    check(o, o_ref, dtype, "flash out")
+    check(qd.grad, qr.grad, dtype, "flash dQ", factor=3)
+    check(kd.grad, kr.grad, dtype, "flash dK", factor=3)
+    check(vd.grad, vr.grad, dtype, "flash dV", factor=3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_lora_linear(dev, dtype):
     M, K, N, r = 130, 64, 96, 8
     x = rnd(M, K, dtype=dtype, seed=1)
@@ -232,6 +257,7 @@ def test_lora_linear(dev, dtype):
     yr.backward(gy)
     lin = ops.FrozenLinear(w, b, dtype, dev)
     dd, ud = dv(down, dev, grad=True), dv(up, dev, grad=True)
+    dd.grad, ud.grad = torch.zeros_like(dd), torch.zeros_like(ud)  # grads accumulate in place (flat-buffer views)
     lora = ops.LoRAPair(dd, ud, dtype)
     xd, rd = dv(x, dev, dtype, grad=True), dv(res, dev, dtype, grad=True)
     y = ops.lora_linear(xd, lin, lora, residual=rd)

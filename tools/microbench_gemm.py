@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 T = torch.bfloat16
 
 
-def time_it(fn, n=50):
+def time_it(fn, n=int(os.environ.get("MB_N", "50"))):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
