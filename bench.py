@@ -126,7 +126,8 @@ def build_world(device, dtype, rank, cfg_name):
     if cfg_name == "c2":
         scfg = StepConfig(resolution=512, total_step=5, K=5, gan_loss=True, attrcon=False)
     elif cfg_name == "c3":
-        scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True)
+        scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True,
+                          attrcon=os.environ.get("COMAT_C3_ATTRCON", "1") != "0")
     else:
         raise ValueError(cfg_name)
     t0 = time.time()
@@ -144,6 +145,8 @@ def build_world(device, dtype, rank, cfg_name):
                 torch.randn(1, generator=g) * 0.1)
     del dsd
     trainer = CoMatTrainer(TrainableSDPipeline(unet, vae), bank, blip, disc, scfg, seed=rank)
+    if scfg.total_step > scfg.K and os.environ.get("COMAT_PRECAPTURE", "0") != "0":
+        trainer.pipe.prepare_graphs(1, scfg.resolution, scfg.resolution, 77, scfg.total_step)
     # synthetic batch; per-rank seeds differ (each rank has its own prompt)
     g = torch.Generator().manual_seed(1000 + rank)
     L, T = 77, 16

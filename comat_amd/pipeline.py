@@ -19,7 +19,9 @@ import math
 import torch
 
 from . import ops
-from .unet import UNet, VAEDecoder, regroup_maps
+import os
+
+from .unet import GraphedUNetForward, UNet, VAEDecoder, regroup_maps
 
 
 class DDPMScheduler:
@@ -64,6 +66,26 @@ class TrainableSDPipeline:
         self.scheduler = scheduler or DDPMScheduler()
         self.dtype, self.device = unet.dtype, unet.device
         self.attn_dict = {}
+        # hipGraph replay for the untrained (no-grad) denoise steps; COMAT_GRAPHS=0 disables it.  Open issue (round 1):
+        # with attribute-concentration steps in the same forward, a device fault appears from the second optimisation
+        # step on when graphs are replayed (not reproduced without attrcon, nor with syncs between phases) — until it
+        # is root-caused the graphed path is only taken when no attrcon step is requested.
+        use_graphs = torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
+        self.graphed = GraphedUNetForward(unet) if use_graphs else None
+
+    def prepare_graphs(self, batch_size, height, width, L, num_inference_steps):
+        """Capture the no-grad UNet forward graph of every timestep up front (before training starts), so that no
+        capture — and none of the allocator housekeeping it triggers — happens in the middle of a step."""
+        if self.graphed is None:
+            return 0
+        h, w = height // 8, width // 8
+        B = 2 * batch_size
+        x = torch.zeros((B * h * w, self.unet.cfg.in_channels), dtype=self.dtype, device=self.device)
+        ctx = torch.zeros((B * L, self.unet.cfg.cross_attention_dim), dtype=self.dtype, device=self.device)
+        for t in self.scheduler.set_timesteps(num_inference_steps):
+            self.graphed(x, B, h, w, int(t), ctx, L)
+        torch.cuda.synchronize()
+        return len(self.graphed.graphs)
 
     def prepare_latents(self, batch_size, height, width, generator=None, latents=None):
         """(bs,4,h/8,w/8) NCHW fp32 -> channels-last tokens [bs*h*w, 4] fp32 on the device."""
@@ -103,7 +125,10 @@ class TrainableSDPipeline:
                 xin = x2 if train else x2.detach()
                 xin = ops.cast_grad(xin, T)
                 cap = places if (train and i in attrcon_train_steps) else ()
-                eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap)
+                if not train and self.graphed is not None and not attrcon_train_steps:
+                    eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
+                else:
+                    eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap)
                 if cap:
                     cond = {p: [m[bs:] for m in lst] for p, lst in maps.items()}
                     self.attn_dict[str(int(t))] = regroup_maps(cond, reses=attn_reses)
@@ -112,6 +137,10 @@ class TrainableSDPipeline:
             else:
                 z = torch.randn(lat.shape, generator=generator, dtype=torch.float32,
                                 device=dev if generator is None else generator.device).to(dev)
+            dbg = os.environ.get("COMAT_DEBUG_SYNC")
+            if dbg == "1" or (dbg == "train" and train) or (dbg == "nograd" and not train):
+                torch.cuda.synchronize()
+                print(f"[comat] denoise step {i} (t={int(t)}, train={train}, capture={bool(cap)}) ok", flush=True)
             cx, ce, sigma = self.scheduler.step_coefficients(int(t))
             with torch.set_grad_enabled(len(training_timesteps) == 0 or i >= tmin):
                 lat = ops.cfg_ddpm_step(lat, eps2, z, guidance_scale, cx, ce, sigma)

@@ -12,7 +12,9 @@ gradient buffers, so clip + AdamW is one HBM pass per buffer.
 """
 from __future__ import annotations
 
+import os
 import random
+import sys
 from dataclasses import dataclass, field
 
 import torch
@@ -52,6 +54,13 @@ class StepConfig:
     max_grad_norm: float = 0.1
     max_grad_norm_D: float = 1.0
     label_smoothing: float = 0.1
+
+
+def _dbg(tag):
+    """COMAT_DEBUG_SYNC=1: synchronise and print a phase marker (locates asynchronous device faults)."""
+    if os.environ.get("COMAT_DEBUG_SYNC") in ("1", "phase"):
+        torch.cuda.synchronize()
+        print(f"[comat] phase ok: {tag}", file=sys.stderr, flush=True)
 
 
 class FlatAdamW:
@@ -124,11 +133,13 @@ class CoMatTrainer:
             batch["prompt_embeds"], batch["negative_prompt_embeds"], height=res, width=res,
             training_timesteps=training_steps, num_inference_steps=cfg.total_step, guidance_scale=cfg.cfg_scale,
             latents=batch.get("latents"), noises=batch.get("noises"), return_latents=True, output_type="tokens", **kw)
+        _dbg("sampler + vae")
         bs = batch["prompt_embeds"].shape[0]
         if crop is None:
             crop = sample_crop(res, self.rng)
         reward, logp = self.blip.score(img, bs, H, W, batch["blip_input_ids"], batch["blip_attention_mask"], crop=crop,
                                        label_smoothing=cfg.label_smoothing)
+        _dbg("blip")
         out = dict(Blip=reward.detach(), token_logp=logp, training_steps=training_steps, crop=crop)
         loss = -reward
         h, w = res // 8, res // 8
@@ -137,12 +148,14 @@ class CoMatTrainer:
                                                   num_inference_steps=cfg.total_step, h=h, w=w)
             loss = loss + cfg.gan_loss_weight * G_loss
             out["G_loss"] = G_loss.detach()
+            _dbg("G loss")
         if cfg.attrcon:
             tl, pl = mask_loss(self.pipe.attn_dict, batch["masks"], batch["attributes"], cfg.train_layer_ls, bs,
                                self.device)
             loss = loss + cfg.mask_token_loss_weight * tl + cfg.mask_pixel_loss_weight * pl
             out["token_loss"], out["pixel_loss"] = tl.detach(), pl.detach()
             self.pipe.attn_dict = {}
+            _dbg("mask loss")
         out["loss"] = loss
         out["training_latents"] = lat
         out["image"] = (img, H, W)
@@ -156,6 +169,7 @@ class CoMatTrainer:
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
         out["loss"].backward()
+        _dbg("G backward")
         self.reducer.start(self.bank.flat_grad)  # async RCCL all-reduce; overlaps the D step below
         logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
         logs["step_loss"] = out["loss"].detach()

@@ -264,6 +264,41 @@ class UNet:
         return ops.conv2d(h, self.conv_out, B, hh, ww), maps
 
 
+class GraphedUNetForward:
+    """hipGraph replay of the NO-GRAD UNet forward (the N-K untrained denoise steps of a CoMat step are ~700 small
+    launches each and host-bound when issued one by one).  One graph per (t, batch, H, W, L): the time-embedding
+    projections are baked per timestep; latents and text context go through static input buffers; LoRA factors are
+    read from the bank's flat compute copy at replay time, so optimizer updates are seen without re-capture."""
+
+    def __init__(self, unet: "UNet"):
+        self.unet = unet
+        self.graphs = {}
+
+    def __call__(self, x, B, H, W, t, ctx, L):
+        key = (int(t), B, H, W, L)
+        ent = self.graphs.get(key)
+        if ent is None:
+            u = self.unet
+            sx, sc = torch.empty_like(x), torch.empty_like(ctx)
+            sx.copy_(x)
+            sc.copy_(ctx)
+            with torch.no_grad():
+                u(sx, B, H, W, t, sc, L)  # eager warm-up: fills the temb memo, LoRA compute copy, split-K workspace
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out, _ = u(sx, B, H, W, t, sc, L)
+            ent = self.graphs[key] = (g, sx, sc, out)
+        g, sx, sc, out = ent
+        k = ops.kernels()
+        k.unary(ops.UN_COPY, x, sx, x.numel())
+        k.unary(ops.UN_COPY, ctx, sc, ctx.numel())
+        if self.unet.lora is not None:
+            self.unet.lora.ensure_compute_copy()
+        g.replay()
+        return out
+
+
 def regroup_maps(maps: dict, reses=(64, 32, 16, 8), poses=("down", "mid", "up")):
     """Same key/shape schema as the reference's get_cross_attn_map_from_unet (attn_utils/tc_attn_utils.py:198-217):
     {f"{pos}_{res}": [Tensor(B*heads, res, res, L), ...]} — views of the stored probabilities, no copy."""
