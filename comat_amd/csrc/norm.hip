@@ -177,13 +177,13 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ stats, double* __restrict__ ws,
                                                        int HW, int C, int G, int silu, int rows_per_block) {
     constexpr int EPV = 16 / sizeof(T);
-    __shared__ float s_a[MAX_G], s_b[MAX_G];
+    // per-(row lane, channel) partial sums: reduced in a FIXED order below, so the block result is deterministic
+    // (LDS float atomics from many waves made run-to-run results differ in the last bf16 bit of a few outputs)
+    __shared__ float p_a[4096], p_b[4096];
     const int b = blockIdx.y;
     const int VPR = C / EPV;
     const int R = VPR >= NT ? 1 : NT / VPR;  // rows processed in parallel
     const int cpg = C / G;
-    if (threadIdx.x < MAX_G) { s_a[threadIdx.x] = 0.f; s_b[threadIdx.x] = 0.f; }
-    __syncthreads();
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(r0 + rows_per_block, HW);
     const int64_t base = (int64_t)b * HW * C;
@@ -224,27 +224,22 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
                 }
             }
         }
-        // fold the EPV channels into their groups (consecutive channels mostly share a group)
-        int gcur = c0 / cpg;
-        float f1 = 0.f, f2 = 0.f;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-            const int ge = (c0 + e) / cpg;
-            if (ge != gcur) {
-                atomicAdd(&s_a[gcur], f1);
-                atomicAdd(&s_b[gcur], f2);
-                gcur = ge; f1 = 0.f; f2 = 0.f;
-            }
-            f1 += a1[e];
-            f2 += a2[e];
+            p_a[rsub * C + c0 + e] = a1[e];
+            p_b[rsub * C + c0 + e] = a2[e];
         }
-        atomicAdd(&s_a[gcur], f1);
-        atomicAdd(&s_b[gcur], f2);
     }
     __syncthreads();
     if (threadIdx.x < G) {
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_a[threadIdx.x]);
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_b[threadIdx.x]);
+        float f1 = 0.f, f2 = 0.f;
+        for (int rr = 0; rr < R; ++rr)
+            for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
+                f1 += p_a[rr * C + c];
+                f2 += p_b[rr * C + c];
+            }
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)f1);
+        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)f2);
     }
 }
 
@@ -328,8 +323,10 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
 
 static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int64_t HW) {
     const int epv = dtype == COMAT_BF16 ? 8 : 4;
-    return (C % epv) == 0 && C / epv <= NT * VSLOTS && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 &&
-           HW < (1ll << 31);
+    const int vpr = C / epv;
+    const int R = vpr >= NT ? 1 : NT / (vpr > 0 ? vpr : 1);
+    return (C % epv) == 0 && vpr <= NT * VSLOTS && (int64_t)R * C <= 4096 && ((uintptr_t)a % 16) == 0 &&
+           ((uintptr_t)b % 16) == 0 && HW < (1ll << 31);
 }
 
 // ---- LayerNorm: one wave per row ----------------------------------------------------------------------------------

@@ -61,6 +61,8 @@ class DDPMScheduler:
 
 
 class TrainableSDPipeline:
+    is_sdxl = False
+
     def __init__(self, unet: UNet, vae: VAEDecoder, scheduler: DDPMScheduler | None = None):
         self.unet, self.vae = unet, vae
         self.scheduler = scheduler or DDPMScheduler()
@@ -70,7 +72,8 @@ class TrainableSDPipeline:
         # with attribute-concentration steps in the same forward, a device fault appears from the second optimisation
         # step on when graphs are replayed (not reproduced without attrcon, nor with syncs between phases) — until it
         # is root-caused the graphed path is only taken when no attrcon step is requested.
-        use_graphs = torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
+        use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
+                      and not unet.cfg.addition_embed)
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
 
     def prepare_graphs(self, batch_size, height, width, L, num_inference_steps):
@@ -99,7 +102,8 @@ class TrainableSDPipeline:
                 num_inference_steps=50, guidance_scale=7.5, latents=None, generator=None, noises=None,
                 detach_gradient=True, bp_on_trained=True, early_exit=False, double_laststep=False,
                 fast_training=False, return_latents=False, attrcon_train_steps=(), train_layer_ls=(),
-                attn_reses=(64, 32, 16, 8), output_type="image"):
+                attn_reses=(64, 32, 16, 8), output_type="image", pooled_prompt_embeds=None,
+                negative_pooled_prompt_embeds=None, add_time_ids=None):
         """prompt_embeds / negative_prompt_embeds: (bs, L, cross_dim) text-encoder outputs (the CLIP text encoder is
         a no-grad preprocessing step outside this path).  Returns image/2+0.5 as (bs,3,H,W) [output_type 'image'] or
         as channels-last tokens ([bs*H*W,3], H, W) ['tokens'], plus the final latents when `return_latents`."""
@@ -111,6 +115,12 @@ class TrainableSDPipeline:
         dev, T = self.device, self.dtype
         ctx = torch.cat([negative_prompt_embeds, prompt_embeds]).to(dev, torch.float32)
         ctx = ops.cast(ctx.reshape(2 * bs * L, -1).contiguous(), T)
+        added = None
+        if self.is_sdxl:  # added_cond_kwargs of TrainableSDPipeline.py:772-784,807
+            if add_time_ids is None:
+                add_time_ids = (height, width, 0, 0, height, width)  # original_size + crop_top_left + target_size
+            text_embeds = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds]).to(dev, torch.float32)
+            added = (text_embeds, [list(add_time_ids)] * (2 * bs))
         timesteps = self.scheduler.set_timesteps(num_inference_steps)
         lat, h, w = self.prepare_latents(bs, height, width, generator, latents)
         training_timesteps = list(training_timesteps)
@@ -122,13 +132,15 @@ class TrainableSDPipeline:
             with torch.set_grad_enabled(len(training_timesteps) == 0 or i > tmin):
                 x2 = ops.concat_rows(lat, lat)
             with torch.set_grad_enabled(train):
-                xin = x2 if train else x2.detach()
+                # SDXL forward detaches the UNet input on every step (`detach_gradient=True`, no bp_on_trained
+                # exception: TrainableSDPipeline.py:805-806, AttrConcenTrainableSDXLPipeline.py:393-410)
+                xin = x2 if (train and not self.is_sdxl) else x2.detach()
                 xin = ops.cast_grad(xin, T)
                 cap = places if (train and i in attrcon_train_steps) else ()
                 if not train and self.graphed is not None and not attrcon_train_steps:
                     eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
                 else:
-                    eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap)
+                    eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added)
                 if cap:
                     cond = {p: [m[bs:] for m in lst] for p, lst in maps.items()}
                     self.attn_dict[str(int(t))] = regroup_maps(cond, reses=attn_reses)
@@ -146,7 +158,8 @@ class TrainableSDPipeline:
                 lat = ops.cfg_ddpm_step(lat, eps2, z, guidance_scale, cx, ce, sigma)
         z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), T)
         img, H, W = self.vae(z0, bs, h, w)
-        img = ops.affine(img, 0.5, 0.5)
+        if not (self.is_sdxl and return_latents):  # SDXL + return_latents returns the raw decode (:838-840)
+            img = ops.affine(img, 0.5, 0.5)
         if output_type == "tokens":
             out = (img, H, W)
         else:
@@ -154,3 +167,10 @@ class TrainableSDPipeline:
         if return_latents:
             return out, (lat if output_type == "tokens" else ops.tokens_to_nchw(lat, bs, h, w))
         return out
+
+
+class TrainableSDXLPipeline(TrainableSDPipeline):
+    """SDXL variant (TrainableSDPipeline.py:657-846, AttrConcenTrainableSDXLPipeline.py:234-496): pooled text
+    embedding + size/crop ids as additional conditioning, UNet input always detached, raw VAE decode returned with
+    `return_latents`.  Use with an SDXL_UNET-style UNetConfig and VAEConfig(scaling_factor=0.13025)."""
+    is_sdxl = True

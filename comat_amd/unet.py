@@ -118,6 +118,7 @@ class _Mods:
                               stride=stride, pad=pad)
 
     def conv1x1(self, name):
+        """1x1 conv (weight [Co,Ci,1,1]) or nn.Linear (weight [Co,Ci]) — the same GEMM on channels-last tokens."""
         w = self.sd[name + ".weight"]
         return ops.FrozenLinear(w.reshape(w.shape[0], w.shape[1]), self.sd.get(name + ".bias"), self.dtype,
                                 self.device)
@@ -151,40 +152,49 @@ class ResBlock:
 
 
 class CrossAttnBlock:
-    """Transformer2DModel with one BasicTransformerBlock (self-attn, cross-attn to the text context, GEGLU FFN)."""
+    """Transformer2DModel: GroupNorm, proj_in, `depth` BasicTransformerBlocks (self-attn, cross-attn to the text
+    context, GEGLU FFN), proj_out, residual.  SD1.5: depth 1; SDXL: 1 / 2 / 10."""
 
-    def __init__(self, m: _Mods, name, cfg: UNetConfig, lora: LoRABank | None):
+    def __init__(self, m: _Mods, name, cfg: UNetConfig, lora: LoRABank | None, level=0):
         self.cfg = cfg
+        self.heads = cfg.heads(level)
         self.norm = m.norm(name + ".norm")
         self.proj_in, self.proj_out = m.conv1x1(name + ".proj_in"), m.conv1x1(name + ".proj_out")
-        b = name + ".transformer_blocks.0"
-        self.ln = [m.norm(f"{b}.norm{i}") for i in (1, 2, 3)]
-        self.att = {}
-        for a in ("attn1", "attn2"):
-            for p in ("to_q", "to_k", "to_v", "to_out.0"):
-                key = f"{b}.{a}.{p}"
-                self.att[(a, p)] = (m.lin(key), lora.pairs[key] if lora is not None else None)
-        self.ff1, self.ff2 = m.lin(f"{b}.ff.net.0.proj"), m.lin(f"{b}.ff.net.2")
+        self.layers = []
+        for k in range(cfg.depth(level)):
+            b = f"{name}.transformer_blocks.{k}"
+            att = {}
+            for a in ("attn1", "attn2"):
+                for p in ("to_q", "to_k", "to_v", "to_out.0"):
+                    key = f"{b}.{a}.{p}"
+                    att[(a, p)] = (m.lin(key), lora.pairs[key] if lora is not None else None)
+            self.layers.append(dict(ln=[m.norm(f"{b}.norm{i}") for i in (1, 2, 3)], att=att,
+                                    ff1=m.lin(f"{b}.ff.net.0.proj"), ff2=m.lin(f"{b}.ff.net.2")))
 
-    def _attn(self, a, x, src, B, N, L, need_probs):
-        q = ops.lora_linear(x, *self.att[(a, "to_q")])
-        k = ops.lora_linear(src, *self.att[(a, "to_k")])
-        v = ops.lora_linear(src, *self.att[(a, "to_v")])
-        heads = self.cfg.num_heads
-        return ops.attention(q, k, v, B, N, L, heads, q.shape[1] // heads, need_probs=need_probs)
+    def _attn(self, att, a, x, src, B, N, L, need_probs):
+        q = ops.lora_linear(x, *att[(a, "to_q")])
+        k = ops.lora_linear(src, *att[(a, "to_k")])
+        v = ops.lora_linear(src, *att[(a, "to_v")])
+        return ops.attention(q, k, v, B, N, L, self.heads, q.shape[1] // self.heads, need_probs=need_probs)
 
     def __call__(self, x, B, H, W, ctx, L, want_probs):
+        """returns (tokens, [cross-attention probabilities of every transformer layer] or None)"""
         N = H * W
         h = ops.group_norm(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
         h = ops.linear(h, self.proj_in)
-        y = ops.layer_norm(h, *self.ln[0])
-        o, _ = self._attn("attn1", y, y, B, N, N, False)
-        h = ops.lora_linear(o, *self.att[("attn1", "to_out.0")], residual=h)
-        o, probs = self._attn("attn2", ops.layer_norm(h, *self.ln[1]), ctx, B, N, L, want_probs)
-        h = ops.lora_linear(o, *self.att[("attn2", "to_out.0")], residual=h)
-        f = ops.geglu(ops.linear(ops.layer_norm(h, *self.ln[2]), self.ff1))
-        h = ops.linear(f, self.ff2, residual=h)
-        return ops.linear(h, self.proj_out, residual=x), (probs if want_probs else None)
+        probs_all = [] if want_probs else None
+        for Lr in self.layers:
+            att, ln = Lr["att"], Lr["ln"]
+            y = ops.layer_norm(h, *ln[0])
+            o, _ = self._attn(att, "attn1", y, y, B, N, N, False)
+            h = ops.lora_linear(o, *att[("attn1", "to_out.0")], residual=h)
+            o, probs = self._attn(att, "attn2", ops.layer_norm(h, *ln[1]), ctx, B, N, L, want_probs)
+            h = ops.lora_linear(o, *att[("attn2", "to_out.0")], residual=h)
+            f = ops.geglu(ops.linear(ops.layer_norm(h, *ln[2]), Lr["ff1"]))
+            h = ops.linear(f, Lr["ff2"], residual=h)
+            if want_probs:
+                probs_all.append(probs)
+        return ops.linear(h, self.proj_out, residual=x), probs_all
 
 
 class UNet:
@@ -193,20 +203,23 @@ class UNet:
         m = _Mods(sd, dtype, device)
         g = cfg.norm_groups
         self.t1, self.t2 = m.lin("time_embedding.linear_1"), m.lin("time_embedding.linear_2")
+        if cfg.addition_embed:
+            self.a1, self.a2 = m.lin("add_embedding.linear_1"), m.lin("add_embedding.linear_2")
         self.conv_in = m.conv("conv_in")
         nb = len(cfg.block_out_channels)
         self.down, self.up = [], []
         for i in range(nb):
             res = [ResBlock(m, f"down_blocks.{i}.resnets.{j}", g, 1e-5) for j in range(cfg.layers_per_block)]
-            att = [CrossAttnBlock(m, f"down_blocks.{i}.attentions.{j}", cfg, lora)
+            att = [CrossAttnBlock(m, f"down_blocks.{i}.attentions.{j}", cfg, lora, i)
                    for j in range(cfg.layers_per_block)] if cfg.down_attn[i] else None
             ds = m.conv(f"down_blocks.{i}.downsamplers.0.conv", stride=2, pad=1) if i < nb - 1 else None
             self.down.append((res, att, ds))
-        self.mid = (ResBlock(m, "mid_block.resnets.0", g, 1e-5), CrossAttnBlock(m, "mid_block.attentions.0", cfg, lora),
+        self.mid = (ResBlock(m, "mid_block.resnets.0", g, 1e-5),
+                    CrossAttnBlock(m, "mid_block.attentions.0", cfg, lora, nb - 1),
                     ResBlock(m, "mid_block.resnets.1", g, 1e-5))
         for i in range(nb):
             res = [ResBlock(m, f"up_blocks.{i}.resnets.{j}", g, 1e-5) for j in range(cfg.layers_per_block + 1)]
-            att = [CrossAttnBlock(m, f"up_blocks.{i}.attentions.{j}", cfg, lora)
+            att = [CrossAttnBlock(m, f"up_blocks.{i}.attentions.{j}", cfg, lora, nb - 1 - i)
                    for j in range(cfg.layers_per_block + 1)] if cfg.up_attn[i] else None
             us = m.conv(f"up_blocks.{i}.upsamplers.0.conv") if i < nb - 1 else None
             self.up.append((res, att, us))
@@ -214,20 +227,38 @@ class UNet:
         self.conv_out = m.conv("conv_out")
         self._temb_cache = {}
 
-    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=()):
-        """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
-        maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}."""
+    def _time_embedding(self, t, B, added):
+        """{"silu_temb": SiLU(emb)} plus, lazily, each ResBlock's projection of it.  SD1.5: depends on (t, batch)
+        and frozen weights only -> memoised.  SDXL: emb = temb(t) + add_embedding([pooled text | sinusoid(time_ids)])
+        (TrainableSDPipeline.py:772-784,807) depends on the prompt -> recomputed per call."""
         cfg = self.cfg
-        # time-embedding MLP and the per-ResBlock projections depend only on (t, batch) and frozen weights: memoised
-        temb_act = self._temb_cache.get((int(t), B))
-        if temb_act is None:
-            with torch.no_grad():
-                te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
-                te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
-                # SiLU(temb): every ResBlock consumes silu(temb)
+        if not cfg.addition_embed:
+            temb_act = self._temb_cache.get((int(t), B))
+            if temb_act is not None:
+                return temb_act
+        with torch.no_grad():
+            te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
+            te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
+            if not cfg.addition_embed:
                 temb_act = {"silu_temb": ops.linear(te, self.t2, act=ops.ACT_SILU)}
-            if len(self._temb_cache) < 128:
-                self._temb_cache[(int(t), B)] = temb_act
+                if len(self._temb_cache) < 128:
+                    self._temb_cache[(int(t), B)] = temb_act
+                return temb_act
+            text_embeds, time_ids = added  # [B, pooled] device tensor, [B, 6] host values
+            tid = np.concatenate([timestep_embedding(float(v), cfg.addition_time_embed_dim, 1).numpy()
+                                  for v in np.asarray(time_ids, dtype=np.float32).reshape(-1)], axis=1)
+            tid = torch.from_numpy(tid.reshape(B, -1)).to(self.device)
+            add = ops.concat_cols(ops.cast(text_embeds.to(self.device), self.dtype), ops.cast(tid, self.dtype))
+            aug = ops.linear(ops.linear(add, self.a1, act=ops.ACT_SILU), self.a2)
+            emb = ops.linear(te, self.t2, residual=aug)
+            return {"silu_temb": ops.silu(emb)}
+
+    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=(), added=None):
+        """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
+        maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}.
+        SDXL: added = (text_embeds [B, pooled], time_ids [B, 6])."""
+        cfg = self.cfg
+        temb_act = self._time_embedding(t, B, added)
         maps = {p: [] for p in capture_places}
         h = ops.conv2d(x, self.conv_in, B, H, W)
         skips = [h]
@@ -238,7 +269,7 @@ class UNet:
                 if att is not None:
                     h, p = att[j](h, B, hh, ww, ctx, L, "down" in maps)
                     if p is not None:
-                        maps["down"].append(p)
+                        maps["down"].extend(p)
                 skips.append(h)
             if ds is not None:
                 h = ops.conv2d(h, ds, B, hh, ww)
@@ -247,7 +278,7 @@ class UNet:
         h = self.mid[0](h, B, hh, ww, temb_act)
         h, p = self.mid[1](h, B, hh, ww, ctx, L, "mid" in maps)
         if p is not None:
-            maps["mid"].append(p)
+            maps["mid"].extend(p)
         h = self.mid[2](h, B, hh, ww, temb_act)
         for res, att, us in self.up:
             for j, r in enumerate(res):
@@ -256,7 +287,7 @@ class UNet:
                 if att is not None:
                     h, p = att[j](h, B, hh, ww, ctx, L, "up" in maps)
                     if p is not None:
-                        maps["up"].append(p)
+                        maps["up"].extend(p)
             if us is not None:
                 h = ops.conv2d(h, us, B, hh, ww, ups=2)
                 hh, ww = hh * 2, ww * 2

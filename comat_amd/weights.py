@@ -42,19 +42,20 @@ def attention_names(cfg: UNetConfig):
     out = []
     nb = len(cfg.block_out_channels)
 
-    def blk(prefix, c):
-        out.append((prefix + ".transformer_blocks.0.attn1", c, c, c))
-        out.append((prefix + ".transformer_blocks.0.attn2", c, cfg.cross_attention_dim, c))
+    def blk(prefix, c, level):
+        for k in range(cfg.depth(level)):
+            out.append((f"{prefix}.transformer_blocks.{k}.attn1", c, c, c))
+            out.append((f"{prefix}.transformer_blocks.{k}.attn2", c, cfg.cross_attention_dim, c))
     for i in range(nb):
         if cfg.down_attn[i]:
             for j in range(cfg.layers_per_block):
-                blk(f"down_blocks.{i}.attentions.{j}", cfg.block_out_channels[i])
-    blk("mid_block.attentions.0", cfg.block_out_channels[-1])
+                blk(f"down_blocks.{i}.attentions.{j}", cfg.block_out_channels[i], i)
+    blk("mid_block.attentions.0", cfg.block_out_channels[-1], nb - 1)
     rev = list(reversed(cfg.block_out_channels))
     for i in range(nb):
         if cfg.up_attn[i]:
             for j in range(cfg.layers_per_block + 1):
-                blk(f"up_blocks.{i}.attentions.{j}", rev[i])
+                blk(f"up_blocks.{i}.attentions.{j}", rev[i], nb - 1 - i)
     return out
 
 
@@ -64,6 +65,9 @@ def make_unet_weights(cfg: UNetConfig, seed=1234, perturb_norms=False):
     ted = cfg.time_embed_dim
     it.linear("time_embedding.linear_1", c0, ted)
     it.linear("time_embedding.linear_2", ted, ted)
+    if cfg.addition_embed:
+        it.linear("add_embedding.linear_1", cfg.pooled_dim + 6 * cfg.addition_time_embed_dim, ted)
+        it.linear("add_embedding.linear_2", ted, ted)
     it.conv("conv_in", cfg.in_channels, c0, 3)
 
     def resnet(name, cin, cout):
@@ -75,20 +79,27 @@ def make_unet_weights(cfg: UNetConfig, seed=1234, perturb_norms=False):
         if cin != cout:
             it.conv(name + ".conv_shortcut", cin, cout, 1)
 
-    def transformer(name, c):
+    def transformer(name, c, level):
         it.norm(name + ".norm", c)
-        it.conv(name + ".proj_in", c, c, 1)
-        b = name + ".transformer_blocks.0"
-        for a, kv in (("attn1", c), ("attn2", cfg.cross_attention_dim)):
-            it.linear(f"{b}.{a}.to_q", c, c, bias=False)
-            it.linear(f"{b}.{a}.to_k", kv, c, bias=False)
-            it.linear(f"{b}.{a}.to_v", kv, c, bias=False)
-            it.linear(f"{b}.{a}.to_out.0", c, c)
-        for n in ("norm1", "norm2", "norm3"):
-            it.norm(f"{b}.{n}", c)
-        it.linear(f"{b}.ff.net.0.proj", c, 8 * c)
-        it.linear(f"{b}.ff.net.2", 4 * c, c)
-        it.conv(name + ".proj_out", c, c, 1)
+        if cfg.linear_projection:
+            it.linear(name + ".proj_in", c, c)
+        else:
+            it.conv(name + ".proj_in", c, c, 1)
+        for k in range(cfg.depth(level)):
+            b = f"{name}.transformer_blocks.{k}"
+            for a, kv in (("attn1", c), ("attn2", cfg.cross_attention_dim)):
+                it.linear(f"{b}.{a}.to_q", c, c, bias=False)
+                it.linear(f"{b}.{a}.to_k", kv, c, bias=False)
+                it.linear(f"{b}.{a}.to_v", kv, c, bias=False)
+                it.linear(f"{b}.{a}.to_out.0", c, c)
+            for n in ("norm1", "norm2", "norm3"):
+                it.norm(f"{b}.{n}", c)
+            it.linear(f"{b}.ff.net.0.proj", c, 8 * c)
+            it.linear(f"{b}.ff.net.2", 4 * c, c)
+        if cfg.linear_projection:
+            it.linear(name + ".proj_out", c, c)
+        else:
+            it.conv(name + ".proj_out", c, c, 1)
 
     nb = len(cfg.block_out_channels)
     ch = c0
@@ -99,13 +110,13 @@ def make_unet_weights(cfg: UNetConfig, seed=1234, perturb_norms=False):
             resnet(f"down_blocks.{i}.resnets.{j}", ch, cout)
             ch = cout
             if cfg.down_attn[i]:
-                transformer(f"down_blocks.{i}.attentions.{j}", cout)
+                transformer(f"down_blocks.{i}.attentions.{j}", cout, i)
             skip_ch.append(ch)
         if i < nb - 1:
             it.conv(f"down_blocks.{i}.downsamplers.0.conv", ch, ch, 3)
             skip_ch.append(ch)
     resnet("mid_block.resnets.0", ch, ch)
-    transformer("mid_block.attentions.0", ch)
+    transformer("mid_block.attentions.0", ch, nb - 1)
     resnet("mid_block.resnets.1", ch, ch)
     rev = list(reversed(cfg.block_out_channels))
     for i in range(nb):
@@ -114,7 +125,7 @@ def make_unet_weights(cfg: UNetConfig, seed=1234, perturb_norms=False):
             resnet(f"up_blocks.{i}.resnets.{j}", ch + skip_ch.pop(), cout)
             ch = cout
             if cfg.up_attn[i]:
-                transformer(f"up_blocks.{i}.attentions.{j}", cout)
+                transformer(f"up_blocks.{i}.attentions.{j}", cout, nb - 1 - i)
         if i < nb - 1:
             it.conv(f"up_blocks.{i}.upsamplers.0.conv", ch, ch, 3)
     it.norm("conv_norm_out", ch)

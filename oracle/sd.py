@@ -37,6 +37,12 @@ class UNetConfig:
     cross_attention_dim: int = 768
     norm_groups: int = 32
     lora_rank: int = 128
+    heads_per_level: tuple = ()          # SDXL: (5, 10, 20)
+    transformer_layers: tuple = ()       # SDXL: (1, 2, 10)
+    linear_projection: bool = False      # SDXL: proj_in / proj_out are nn.Linear on tokens
+    addition_embed: bool = False         # SDXL: addition_embed_type "text_time"
+    addition_time_embed_dim: int = 256
+    pooled_dim: int = 1280
 
     @property
     def time_embed_dim(self):
@@ -45,6 +51,12 @@ class UNetConfig:
     @property
     def up_attn(self):
         return tuple(reversed(self.down_attn))
+
+    def heads(self, level):
+        return self.heads_per_level[level] if self.heads_per_level else self.num_heads
+
+    def depth(self, level):
+        return self.transformer_layers[level] if self.transformer_layers else 1
 
 
 @dataclass
@@ -61,6 +73,10 @@ SD15_UNET = UNetConfig()
 SD15_VAE = VAEConfig()
 TINY_UNET = UNetConfig(block_out_channels=(32, 64, 64), down_attn=(True, True, False), layers_per_block=1,
                        num_heads=2, cross_attention_dim=24, norm_groups=8, lora_rank=4)
+TINY_SDXL_UNET = UNetConfig(block_out_channels=(32, 64, 64), down_attn=(False, True, True), layers_per_block=1,
+                            heads_per_level=(2, 2, 4), transformer_layers=(1, 2, 3), cross_attention_dim=24,
+                            norm_groups=8, lora_rank=4, linear_projection=True, addition_embed=True,
+                            addition_time_embed_dim=8, pooled_dim=16)
 TINY_VAE = VAEConfig(block_out_channels=(8, 16, 16, 32), layers_per_block=1, norm_groups=8)
 
 
@@ -175,30 +191,44 @@ def resnet(sd, name, x, temb, groups, eps=1e-5):
     return x + h
 
 
-def transformer(sd, name, x, ctx, cfg: UNetConfig, lora, capture, place):
+def transformer(sd, name, x, ctx, cfg: UNetConfig, lora, capture, place, level=0):
     B, C, H, W = x.shape
     res = x
+    heads = cfg.heads(level)
     h = _gn(sd, name + ".norm", x, cfg.norm_groups, 1e-6)
-    h = _conv(sd, name + ".proj_in", h, padding=0)
-    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    blk = name + ".transformer_blocks.0"
-    h = attention(sd, blk + ".attn1", _ln(sd, blk + ".norm1", h), None, cfg.num_heads, lora, capture, place, h)
-    h = attention(sd, blk + ".attn2", _ln(sd, blk + ".norm2", h), ctx, cfg.num_heads, lora, capture, place, h)
-    f = _lin(sd, blk + ".ff.net.0.proj", _ln(sd, blk + ".norm3", h))
-    a, gate = f.chunk(2, dim=-1)
-    h = _lin(sd, blk + ".ff.net.2", a * F.gelu(gate)) + h
-    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    return _conv(sd, name + ".proj_out", h, padding=0) + res
+    if cfg.linear_projection:
+        h = _lin(sd, name + ".proj_in", h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+    else:
+        h = _conv(sd, name + ".proj_in", h, padding=0).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    for k in range(cfg.depth(level)):
+        blk = f"{name}.transformer_blocks.{k}"
+        h = attention(sd, blk + ".attn1", _ln(sd, blk + ".norm1", h), None, heads, lora, capture, place, h)
+        h = attention(sd, blk + ".attn2", _ln(sd, blk + ".norm2", h), ctx, heads, lora, capture, place, h)
+        f = _lin(sd, blk + ".ff.net.0.proj", _ln(sd, blk + ".norm3", h))
+        a, gate = f.chunk(2, dim=-1)
+        h = _lin(sd, blk + ".ff.net.2", a * F.gelu(gate)) + h
+    if cfg.linear_projection:
+        h = _lin(sd, name + ".proj_out", h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    else:
+        h = _conv(sd, name + ".proj_out", h.reshape(B, H, W, C).permute(0, 3, 1, 2), padding=0)
+    return h + res
 
 
-def unet_forward(sd, cfg: UNetConfig, sample, t, ctx, lora=None, capture=None):
+def unet_forward(sd, cfg: UNetConfig, sample, t, ctx, lora=None, capture=None, added_cond=None):
     """sample (B,4,h,w), t int, ctx (B,77,cross_dim) -> eps (B,4,h,w).  `capture(probs, is_cross, place)` is the
-    AttentionControl protocol; places are 'down' / 'mid' / 'up'."""
+    AttentionControl protocol; places are 'down' / 'mid' / 'up'.  SDXL: added_cond = (text_embeds (B,pooled),
+    time_ids (B,6)) — `added_cond_kwargs` of TrainableSDPipeline.py:807."""
     B = sample.shape[0]
     g = cfg.norm_groups
     temb = timestep_embedding([t] * B, cfg.block_out_channels[0])
     temb = F.linear(temb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
     temb = F.linear(F.silu(temb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
+    if cfg.addition_embed:
+        text_embeds, time_ids = added_cond
+        tid = timestep_embedding(time_ids.reshape(-1), cfg.addition_time_embed_dim).reshape(B, -1)
+        add = torch.cat([text_embeds, tid], dim=-1)
+        add = F.linear(add, sd["add_embedding.linear_1.weight"], sd["add_embedding.linear_1.bias"])
+        temb = temb + F.linear(F.silu(add), sd["add_embedding.linear_2.weight"], sd["add_embedding.linear_2.bias"])
     h = _conv(sd, "conv_in", sample)
     skips = [h]
     nb = len(cfg.block_out_channels)
@@ -206,20 +236,20 @@ def unet_forward(sd, cfg: UNetConfig, sample, t, ctx, lora=None, capture=None):
         for j in range(cfg.layers_per_block):
             h = resnet(sd, f"down_blocks.{i}.resnets.{j}", h, temb, g)
             if cfg.down_attn[i]:
-                h = transformer(sd, f"down_blocks.{i}.attentions.{j}", h, ctx, cfg, lora, capture, "down")
+                h = transformer(sd, f"down_blocks.{i}.attentions.{j}", h, ctx, cfg, lora, capture, "down", i)
             skips.append(h)
         if i < nb - 1:
             h = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", h, stride=2, padding=1)
             skips.append(h)
     h = resnet(sd, "mid_block.resnets.0", h, temb, g)
-    h = transformer(sd, "mid_block.attentions.0", h, ctx, cfg, lora, capture, "mid")
+    h = transformer(sd, "mid_block.attentions.0", h, ctx, cfg, lora, capture, "mid", nb - 1)
     h = resnet(sd, "mid_block.resnets.1", h, temb, g)
     for i in range(nb):
         for j in range(cfg.layers_per_block + 1):
             h = torch.cat([h, skips.pop()], dim=1)
             h = resnet(sd, f"up_blocks.{i}.resnets.{j}", h, temb, g)
             if cfg.up_attn[i]:
-                h = transformer(sd, f"up_blocks.{i}.attentions.{j}", h, ctx, cfg, lora, capture, "up")
+                h = transformer(sd, f"up_blocks.{i}.attentions.{j}", h, ctx, cfg, lora, capture, "up", nb - 1 - i)
         if i < nb - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", h)
@@ -291,31 +321,42 @@ class AttentionStore:
 # bp_on_trained=True, early_exit=False, double_laststep=False, fast_training=False (training_script.py:558-567).
 # ----------------------------------------------------------------------------------------------------------------
 def sample_with_grad(unet_sd, ucfg, vae_sd, vcfg, lora, ctx_uncond, ctx_cond, latents, noises, total_steps,
-                     training_steps, guidance=7.5, attrcon_steps=(), train_layer_ls=(), reses=(64, 32, 16, 8)):
-    """Returns (image/2+0.5 (B,3,H,W), final latents, attn_dict {str(t): {place_res: [maps]}})."""
+                     training_steps, guidance=7.5, attrcon_steps=(), train_layer_ls=(), reses=(64, 32, 16, 8),
+                     sdxl_cond=None):
+    """Returns (image/2+0.5 (B,3,H,W), final latents, attn_dict {str(t): {place_res: [maps]}}).
+    sdxl_cond = (neg_pooled, pooled, time_ids (1,6)) selects the SDXL variants (TrainableSDPipeline.py:657-846,
+    AttrConcenTrainableSDXLPipeline.py:234-447): the UNet input is ALWAYS detached (`detach_gradient=True`, no
+    bp_on_trained exception) and, with return_latents, the decoded image is returned WITHOUT /2+0.5 (:838-840)."""
     sched = DDPM()
     timesteps = sched.set_timesteps(total_steps)
     ctx = torch.cat([ctx_uncond, ctx_cond])
     bs = latents.shape[0]
     attn_dict = {}
+    added = None
+    if sdxl_cond is not None:
+        neg_pooled, pooled, time_ids = sdxl_cond
+        added = (torch.cat([neg_pooled, pooled]), torch.cat([time_ids, time_ids]).repeat(bs, 1))
     tmin = min(training_steps) if len(training_steps) else 0
     for i, t in enumerate(timesteps):
         with torch.set_grad_enabled(len(training_steps) == 0 or i > tmin):
             x_in = torch.cat([latents] * 2)
         train = i in training_steps
         with torch.set_grad_enabled(train):
-            inp = x_in if train else x_in.detach()
+            inp = x_in if (train and sdxl_cond is None) else x_in.detach()
+            half = lambda a, lo, hi: None if a is None else (a[0][lo:hi], a[1][lo:hi])
             if train and i in attrcon_steps:
                 store = AttentionStore(train_layer_ls)
-                e_c = unet_forward(unet_sd, ucfg, inp[bs:], t, ctx[bs:], lora, store)
+                e_c = unet_forward(unet_sd, ucfg, inp[bs:], t, ctx[bs:], lora, store, half(added, bs, 2 * bs))
                 attn_dict[str(t)] = store.maps(reses)
-                e_u = unet_forward(unet_sd, ucfg, inp[:bs], t, ctx[:bs], lora, None)
+                e_u = unet_forward(unet_sd, ucfg, inp[:bs], t, ctx[:bs], lora, None, half(added, 0, bs))
                 eps2 = torch.cat([e_u, e_c])
             else:
-                eps2 = unet_forward(unet_sd, ucfg, inp, t, ctx, lora, None)
+                eps2 = unet_forward(unet_sd, ucfg, inp, t, ctx, lora, None, added)
             e_u, e_c = eps2.chunk(2)
             eps = e_u + guidance * (e_c - e_u)
         with torch.set_grad_enabled(len(training_steps) == 0 or i >= tmin):
             latents = sched.step(eps, t, latents, noises[i])
     image = vae_decode(vae_sd, vcfg, latents / vcfg.scaling_factor)
+    if sdxl_cond is not None:
+        return image, latents, attn_dict
     return image / 2 + 0.5, latents, attn_dict
