@@ -153,9 +153,10 @@ class HipKernels:
         self._ws = {}
 
     def _workspace(self, dev):
-        ws = self._ws.get(dev)
+        key = (dev, _stream())  # one slab workspace per stream: kernels on different streams may overlap
+        ws = self._ws.get(key)
         if ws is None:
-            ws = self._ws[dev] = torch.empty(self.WS_BYTES // 4, dtype=torch.float32, device=dev)
+            ws = self._ws[key] = torch.empty(self.WS_BYTES // 4, dtype=torch.float32, device=dev)
         return ws
 
     # ---- contraction ---------------------------------------------------------------------------------------

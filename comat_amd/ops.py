@@ -35,6 +35,48 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ---- side stream for work that is off the critical path of backward (LoRA weight gradients) -----------------------
+_side = {}
+_side_keep = []
+_side_enabled = True
+
+
+def set_side_stream_enabled(flag: bool):
+    global _side_enabled
+    _side_enabled = bool(flag)
+
+
+def _side_stream(dev):
+    """A second HIP stream per device (None on CPU / when disabled): the K = B*H*W split-K GEMMs of the LoRA weight
+    gradients have few tiles each and no consumer until the optimizer, so they overlap the main backward chain."""
+    if dev.type != "cuda" or not _side_enabled:
+        return None
+    st = _side.get(dev)
+    if st is None:
+        st = _side[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+_join_queued = False
+
+
+def join_side_streams():
+    """Make the current stream wait for everything queued on the side streams.  Queued automatically as an autograd
+    end-of-backward callback, so LoRA gradients are complete (in stream order) when `.backward()` returns."""
+    global _join_queued
+    _join_queued = False
+    for dev, st in _side.items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+    _side_keep.clear()
+
+
+def _queue_join():
+    global _join_queued
+    if not _join_queued:
+        _join_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # parameter holders
 # ----------------------------------------------------------------------------------------------------------------
@@ -370,12 +412,24 @@ class _LoRALinear(Function):
         # (lora.up.grad / lora.down.grad are views of it), so autograd returns None for them: no temporary, no
         # separate accumulate kernel per factor and per UNet call.
         lora = ctx.lora
-        if ctx.needs_input_grad[3]:  # dU [N, r] += s * g^T h
-            gu = lora.up.grad
-            k.gemm(g, h, gu, N, r, M, N, r, r, transA=True, transB=True, alpha=s, R=gu, ldr=r, beta=1.0)
-        if ctx.needs_input_grad[2]:  # dD [r, K] += dh^T x
-            gd = lora.down.grad
-            k.gemm(dh, x, gd, r, Kd, M, r, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
+
+        def weight_grads():
+            if ctx.needs_input_grad[3]:  # dU [N, r] += s * g^T h
+                gu = lora.up.grad
+                k.gemm(g, h, gu, N, r, M, N, r, r, transA=True, transB=True, alpha=s, R=gu, ldr=r, beta=1.0)
+            if ctx.needs_input_grad[2]:  # dD [r, K] += dh^T x
+                gd = lora.down.grad
+                k.gemm(dh, x, gd, r, Kd, M, r, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
+
+        side = _side_stream(g.device)
+        if side is None:
+            weight_grads()
+        else:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                weight_grads()
+            _side_keep.append((g, h, dh, x))  # keep the operands alive until join_side_streams()
+            _queue_join()
         if ctx.needs_input_grad[0]:
             dx = g.new_empty((M, Kd))
             k.gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)

@@ -169,6 +169,7 @@ class CoMatTrainer:
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
         out["loss"].backward()
+        ops.join_side_streams()
         _dbg("G backward")
         self.reducer.start(self.bank.flat_grad)  # async RCCL all-reduce; overlaps the D step below
         logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
@@ -182,6 +183,7 @@ class CoMatTrainer:
                                                   negative_prompt_embeds=batch["gan_null_embeds"],
                                                   num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
             D_loss.backward()
+            ops.join_side_streams()
             logs["D_loss"] = D_loss.detach()
         self.reducer.finish()
         self.opt.step()

@@ -116,3 +116,19 @@ def test_second_step_uses_updated_lora(sim):
     l1 = trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
     l2 = trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
     assert abs(float(l1["step_loss"]) - float(l2["step_loss"])) > 1e-6
+
+
+@pytest.mark.gpu
+def test_side_stream_overlap_is_bit_exact(hip):
+    """LoRA weight-gradient GEMMs overlapped on a second HIP stream give bit-identical gradients and parameters."""
+    from comat_amd import ops
+    res = []
+    for enabled in (False, True):
+        ops.set_side_stream_enabled(enabled)
+        cfg, batch, W, trainer = make_world(torch.bfloat16, hip, False)
+        trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+        torch.cuda.synchronize()
+        res.append((trainer.bank.flat_grad.clone(), trainer.bank.flat.clone(), trainer.D.bank.flat.clone()))
+    ops.set_side_stream_enabled(True)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
