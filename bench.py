@@ -221,14 +221,19 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank, args.config)
 
+    run_step = lambda: trainer.train_step(batch, **fixed)
+    if os.environ.get("COMAT_STEP_GRAPH", "0") == "1" and "training_steps" in fixed and world == 1:
+        from comat_amd.step import GraphedTrainStep
+        gstep = GraphedTrainStep(trainer)
+        run_step = lambda: gstep(batch, fixed["training_steps"], fixed["crop"])
     for _ in range(args.warmup):
-        trainer.train_step(batch, **fixed)
+        run_step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.steps):
-        trainer.train_step(batch, **fixed)
+        run_step()
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
@@ -244,8 +249,10 @@ def main():
     if rank == 0 and not args.no_kernel_timing:
         timed = TimedKernels(ops.kernels())
         ops.set_kernel_backend(timed)
+        ops.set_side_stream_enabled(False)  # per-kernel event timing needs one stream (no overlapping kernels)
         trainer.train_step(batch, **fixed)
         fam = timed.summary()
+        ops.set_side_stream_enabled(True)
         ops.set_kernel_backend(timed.inner)
         tot_t = sum(v[0] for v in fam.values())
         dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])

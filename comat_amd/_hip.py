@@ -80,9 +80,9 @@ SIGNATURES = {
     "comat_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_embedding": [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
     "comat_cross_entropy_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _i32, _vp],
-    "comat_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _f, _i32, _vp],
+    "comat_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _i32, _vp],
     "comat_disc_head_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
-    "comat_disc_head_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "comat_disc_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_attnmap_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_sumsq": [_vp, _i64, _vp, _vp],
@@ -302,17 +302,17 @@ class HipKernels:
                                             _ptr(loss_sum_cnt), T, V, ld, ignore_index, ls, dt(logits), _stream()),
                "comat_cross_entropy_fwd")
 
-    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, gscale):
+    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, g_up, loss_sum_cnt):
         _check(_lib.comat_cross_entropy_bwd(_ptr(logits), _ptr(labels), _ptr(row_lse), _ptr(dlogits), T, V, ld,
-                                            ignore_index, ls, gscale, dt(logits), _stream()),
+                                            ignore_index, ls, _ptr(g_up), _ptr(loss_sum_cnt), dt(logits), _stream()),
                "comat_cross_entropy_bwd")
 
     def disc_head_fwd(self, x, w, b, target, loss, P, pix_per_sample):
         _check(_lib.comat_disc_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(loss), P, pix_per_sample,
                                         dt(x), _stream()), "comat_disc_head_fwd")
 
-    def disc_head_bwd(self, x, w, b, target, gscale, dx, dw, db, P, pix_per_sample):
-        _check(_lib.comat_disc_head_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), gscale, _ptr(dx), _ptr(dw),
+    def disc_head_bwd(self, x, w, b, target, g_up, dx, dw, db, P, pix_per_sample):
+        _check(_lib.comat_disc_head_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(g_up), _ptr(dx), _ptr(dw),
                                         _ptr(db), P, pix_per_sample, dt(x), _stream()), "comat_disc_head_bwd")
 
     def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):

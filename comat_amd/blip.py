@@ -155,16 +155,16 @@ class Blip:
         emb, N = self.vision(pixel_tokens, B)
         logits = self.decoder_logits(input_ids, attention_mask, emb, B, N)
         T = input_ids.shape[1]
-        shifted = torch.full((B, T), -100, dtype=torch.int64)
-        shifted[:, :-1] = labels[:, 1:].cpu()
-        loss, logp = ops.cross_entropy(logits, shifted.reshape(-1).to(self.device), -100, ls)
+        labels = labels.to(self.device)
+        shifted = torch.cat([labels[:, 1:], torch.full((B, 1), -100, dtype=torch.int64, device=self.device)], dim=1)
+        loss, logp = ops.cross_entropy(logits, shifted.reshape(-1).contiguous(), -100, ls)
         return loss, logits, logp.reshape(B, T)[:, :-1]
 
     @staticmethod
     def make_labels(input_ids, pad_token_id=0, prompt_length=4):
         """caption_blip.py:51-54: pads and the 'a photography of' prefix are ignored."""
         labels = input_ids.masked_fill(input_ids == pad_token_id, -100)
-        labels[:, :prompt_length] = -100
+        labels[:, :prompt_length] = -100  # masked_fill returned a copy: the caller's ids are untouched
         return labels
 
     def score(self, images, B, H, W, input_ids, attention_mask, crop=None, pad_token_id=0, prompt_length=4,
@@ -172,6 +172,6 @@ class Blip:
         """`Blip.score`: images are channels-last tokens [B*H*W, 3] in [0,1] (unclamped, TrainableSDPipeline.py:223).
         Returns (reward = -loss, token log-probs [B, T-1])."""
         pv = self.preprocess(images, B, H, W, crop)
-        labels = self.make_labels(input_ids.cpu(), pad_token_id, prompt_length)
+        labels = self.make_labels(input_ids, pad_token_id, prompt_length)
         loss, _, logp = self.caption_loss(pv, B, input_ids, attention_mask, labels, label_smoothing)
         return -loss, logp

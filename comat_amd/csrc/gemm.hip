@@ -18,7 +18,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int KTB = 64;              // bytes of k per row per k-tile (128 measured slower: LDS footprint halves occupancy)
+constexpr int KTB = 64;              // bytes of k per row per k-tile (128 B measured no better: fewer barriers but half the occupancy)
 constexpr int ROWB = KTB + 16;       // bytes per LDS row, k-contiguous image (36 dwords: conflict-free b128 reads)
 constexpr int CPR = KTB / 16;        // 16-byte chunks per row
 constexpr int PF = 4;  // k-tiles kept in flight per thread (register prefetch ring): hides HBM/L2 latency when few
@@ -537,8 +537,10 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
         p.splits = s < 1 ? 1 : (int)s;
         return p;
     }
-    if (ws_bytes > 0 && blocks <= 256 && nk >= 32) {  // only long serial k-loops on a mostly idle chip are worth a reduce pass
-        int64_t s = cdiv64(768, blocks);
+    // split when the grid leaves CUs idle and the serial k-loop is long enough (>= 8 k-tiles per split) to pay for
+    // the reduce pass; measured with tools/microbench_gemm.py on the shapes of this workload
+    if (ws_bytes > 0 && blocks < 768 && nk >= 16) {
+        int64_t s = cdiv64(1024, blocks);
         if (s > nk / 8) s = nk / 8;
         const int64_t cap = ws_bytes / (batch * M * N * 4);
         if (s > cap) s = cap;

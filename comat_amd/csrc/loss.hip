@@ -45,7 +45,10 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits
 template <typename T>
 __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                                     const float* __restrict__ row_lse, T* __restrict__ dlogits, int V,
-                                                    int64_t ld, int ignore_index, float ls, float gscale) {
+                                                    int64_t ld, int ignore_index, float ls,
+                                                    const float* __restrict__ g_up,
+                                                    const float* __restrict__ loss_sum_cnt) {
+    const float gscale = g_up[0] / fmaxf(loss_sum_cnt[1], 1.0f);  // upstream gradient / number of valid tokens
     const int64_t t = blockIdx.x;
     const T* z = logits + t * ld;
     T* d = dlogits + t * ld;
@@ -87,13 +90,14 @@ __global__ __launch_bounds__(NT) void disc_head_fwd_kernel(const void* __restric
 
 __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b,
-                                                           const float* __restrict__ target, float gscale,
+                                                           const float* __restrict__ target,
+                                                           const float* __restrict__ g_up,
                                                            void* __restrict__ dx, float* __restrict__ dw,
                                                            float* __restrict__ db, int64_t P, int64_t pps, int dt) {
     __shared__ float sbuf[4];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
     const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], bb = b[0];
-    const float gs = gscale / (float)P;
+    const float gs = g_up[0] / (float)P;  // upstream gradient is a device scalar (no host sync)
     for (int64_t p = (int64_t)blockIdx.x * NT + threadIdx.x; p < P; p += (int64_t)gridDim.x * NT) {
         const float x0 = ld_dt(x, 4 * p, dt), x1 = ld_dt(x, 4 * p + 1, dt), x2 = ld_dt(x, 4 * p + 2, dt),
                     x3 = ld_dt(x, 4 * p + 3, dt);
@@ -191,15 +195,16 @@ extern "C" int comat_cross_entropy_fwd(const void* logits, const int64_t* labels
 
 extern "C" int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse, void* dlogits,
                                        int64_t T, int32_t V, int64_t ld, int32_t ignore_index, float label_smoothing,
-                                       float gscale, int32_t dtype, void* stream) {
-    COMAT_REQUIRE(logits && labels && row_lse && dlogits, "comat_cross_entropy_bwd: null pointer");
+                                       const float* g_up, const float* loss_sum_cnt, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(logits && labels && row_lse && dlogits && g_up && loss_sum_cnt,
+                  "comat_cross_entropy_bwd: null pointer");
     COMAT_REQUIRE(T > 0 && V > 0 && ld >= V && T < (1ll << 31) && dtype_ok(dtype), "comat_cross_entropy_bwd: bad args");
     if (dtype == COMAT_BF16)
         hipLaunchKernelGGL(ce_bwd_kernel<bf16_t>, dim3((unsigned)T), dim3(NT), 0, ST, (const bf16_t*)logits, labels,
-                           row_lse, (bf16_t*)dlogits, V, ld, ignore_index, label_smoothing, gscale);
+                           row_lse, (bf16_t*)dlogits, V, ld, ignore_index, label_smoothing, g_up, loss_sum_cnt);
     else
         hipLaunchKernelGGL(ce_bwd_kernel<float>, dim3((unsigned)T), dim3(NT), 0, ST, (const float*)logits, labels, row_lse,
-                           (float*)dlogits, V, ld, ignore_index, label_smoothing, gscale);
+                           (float*)dlogits, V, ld, ignore_index, label_smoothing, g_up, loss_sum_cnt);
     return comat_check_launch("comat_cross_entropy_bwd");
 }
 
@@ -216,13 +221,13 @@ extern "C" int comat_disc_head_fwd(const void* x, const float* w, const float* b
     return comat_check_launch("comat_disc_head_fwd");
 }
 
-extern "C" int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, float gscale,
-                                   void* dx, float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype,
-                                   void* stream) {
-    COMAT_REQUIRE(x && w && b && target, "comat_disc_head_bwd: null pointer");
+extern "C" int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target,
+                                   const float* g_up, void* dx, float* dw, float* db, int64_t P,
+                                   int64_t pix_per_sample, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && w && b && target && g_up, "comat_disc_head_bwd: null pointer");
     COMAT_REQUIRE((dw == nullptr) == (db == nullptr), "comat_disc_head_bwd: dw and db must both be given or both NULL");
     COMAT_REQUIRE(P > 0 && pix_per_sample > 0 && dtype_ok(dtype), "comat_disc_head_bwd: bad args");
-    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, gscale, dx, dw,
+    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, g_up, dx, dw,
                        db, P, pix_per_sample, dtype);
     return comat_check_launch("comat_disc_head_bwd");
 }

@@ -26,6 +26,14 @@ class D_sd:
         self.b = self.head[4:].requires_grad_(True)
         self.w.grad, self.b.grad = self.head_grad[:4], self.head_grad[4:]
         self.ori_scheduler = DDPMScheduler()
+        self._targets = {}
+
+    def _target(self, bs, side):
+        key = (bs, side)
+        if key not in self._targets:
+            t = torch.ones(bs) if side == "G" else torch.cat([torch.zeros(bs), torch.ones(bs)])
+            self._targets[key] = t.to(self.unet.device)
+        return self._targets[key]
 
     def zero_grad(self):
         self.bank.zero_grad()
@@ -49,8 +57,7 @@ class D_sd:
             self.set_D_sd_pipeline_lora(False)
             ctx = ops.cast(null.reshape(bs * L, -1).contiguous(), T)
             eps, _ = u(ops.cast_grad(training_latents, T), bs, h, w, t_last, ctx, L)
-            target = torch.ones(bs, dtype=torch.float32, device=dev)
-            return ops.disc_head_loss(eps, self.w, self.b, target, h * w)
+            return ops.disc_head_loss(eps, self.w, self.b, self._target(bs, "G"), h * w)
         if side == "D":
             self.set_D_sd_pipeline_lora(True)
             with torch.no_grad():
@@ -58,6 +65,5 @@ class D_sd:
                 x = ops.cast(x, T)
             ctx = ops.cast(torch.cat([null, null]).reshape(2 * bs * L, -1).contiguous(), T)
             eps, _ = u(x, 2 * bs, h, w, t_last, ctx, L)
-            target = torch.cat([torch.zeros(bs), torch.ones(bs)]).to(dev)
-            return ops.disc_head_loss(eps, self.w, self.b, target, h * w)
+            return ops.disc_head_loss(eps, self.w, self.b, self._target(bs, "D"), h * w)
         raise ValueError(side)

@@ -811,9 +811,9 @@ class _CrossEntropy(Function):
         logits, labels, lse, acc = ctx.saved_tensors
         ignore_index, ls = ctx.cfg
         T, V = logits.shape
-        gscale = float(g) / float(acc[1])  # host sync on two scalars, once per step
         dl = torch.empty_like(logits)
-        kernels().cross_entropy_bwd(logits, labels, lse, dl, T, V, V, ignore_index, ls, gscale)
+        g_up = _c(g.reshape(1).to(torch.float32))  # device scalar: no host sync in the middle of backward
+        kernels().cross_entropy_bwd(logits, labels, lse, dl, T, V, V, ignore_index, ls, g_up, acc)
         return dl, None, None, None
 
 
@@ -843,7 +843,7 @@ class _DiscHead(Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.zeros((4,), dtype=torch.float32, device=x.device)
             db = torch.zeros((1,), dtype=torch.float32, device=x.device)
-        kernels().disc_head_bwd(x, w, b, target, float(g), dx, dw, db, P, ctx.pps)
+        kernels().disc_head_bwd(x, w, b, target, _c(g.reshape(1).to(torch.float32)), dx, dw, db, P, ctx.pps)
         return dx, dw, db, None, None
 
 

@@ -137,7 +137,8 @@ class TrainableSDPipeline:
                 xin = x2 if (train and not self.is_sdxl) else x2.detach()
                 xin = ops.cast_grad(xin, T)
                 cap = places if (train and i in attrcon_train_steps) else ()
-                if not train and self.graphed is not None and not attrcon_train_steps:
+                if (not train and self.graphed is not None and not attrcon_train_steps
+                        and not torch.cuda.is_current_stream_capturing()):
                     eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
                 else:
                     eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added)

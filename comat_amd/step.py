@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .blip import Blip
-from .dist import GradReducer
+from .dist import GradReducer, world_size
 from .gan import D_sd
 from .losses import mask_loss
 from .pipeline import TrainableSDPipeline
@@ -161,16 +161,58 @@ class CoMatTrainer:
         out["image"] = (img, H, W)
         return out
 
+    def _forward_backward(self, batch, fixed):
+        """G forward + backward, then the D forward + backward (everything of the step that precedes the exchange and
+        the optimizer updates).  Returns a dict of device scalars (no host sync)."""
+        cfg = self.cfg
+        self.bank.set_requires_grad(True)
+        self.bank.zero_grad()
+        out = self.compute_losses(batch, **fixed)
+        out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
+        _dbg("G backward")
+        logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
+        logs["step_loss"] = out["loss"].detach()
+        self._last = (out["training_steps"], out["crop"])
+        if cfg.gan_loss:
+            h = w = cfg.resolution // 8
+            self.D.zero_grad()
+            real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
+            D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
+                                                  negative_prompt_embeds=batch["gan_null_embeds"],
+                                                  num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
+            D_loss.backward()
+            logs["D_loss"] = D_loss.detach()
+        return logs
+
+    def _apply_updates(self):
+        """all-reduce(mean) of the flat gradient buffers (RCCL, async) + clip + AdamW for G and D."""
+        self.reducer.start(self.bank.flat_grad)
+        if self.cfg.gan_loss:
+            self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
+        self.reducer.finish()
+        self.opt.step()
+        self.bank.mark_updated()
+        if self.cfg.gan_loss:
+            self.opt_D.step()
+            self.D.bank.mark_updated()
+
     def train_step(self, batch, **fixed):
-        """Full step: G forward/backward/update, then the D step.  Returns a dict of detached scalars (tensors: no
-        host sync here) plus `training_steps` / `crop`."""
+        """Full step: G forward/backward, D forward/backward, gradient exchange, G and D updates.  Returns a dict of
+        detached device scalars (no host sync here) plus `training_steps` / `crop`."""
+        if world_size() > 1:
+            # multi-GPU: start the G all-reduce right after G-backward so that it overlaps the whole D step
+            return self._train_step_overlapped(batch, fixed)
+        logs = self._forward_backward(batch, fixed)
+        self._apply_updates()
+        logs["training_steps"], logs["crop"] = self._last
+        return logs
+
+    def _train_step_overlapped(self, batch, fixed):
         cfg = self.cfg
         self.bank.set_requires_grad(True)
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
         out["loss"].backward()
-        ops.join_side_streams()
-        _dbg("G backward")
         self.reducer.start(self.bank.flat_grad)  # async RCCL all-reduce; overlaps the D step below
         logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
         logs["step_loss"] = out["loss"].detach()
@@ -183,7 +225,6 @@ class CoMatTrainer:
                                                   negative_prompt_embeds=batch["gan_null_embeds"],
                                                   num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
             D_loss.backward()
-            ops.join_side_streams()
             logs["D_loss"] = D_loss.detach()
         self.reducer.finish()
         self.opt.step()
@@ -194,3 +235,57 @@ class CoMatTrainer:
             self.opt_D.step()
             self.D.bank.mark_updated()
         return logs
+
+
+class GraphedTrainStep:
+    """Whole-step hipGraph: the forward + backward of G and D (≈16 k kernel launches, partly host-bound when issued
+    one by one) is captured ONCE per (training_steps, crop) variant and replayed; inputs go through static device
+    buffers; the gradient exchange and the optimizer kernels (whose bias-correction scalars change every step) stay
+    eager.  Opt-in: needs fixed `training_steps` and `crop` per variant and a device-resident batch."""
+
+    def __init__(self, trainer: CoMatTrainer):
+        self.tr = trainer
+        self.graphs = {}
+        self.static = None
+
+    def _stage(self, batch):
+        dev = self.tr.device
+        if self.static is None:
+            self.static = {}
+            for k, v in batch.items():
+                if isinstance(v, torch.Tensor):
+                    self.static[k] = v.to(dev).clone()
+                elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+                    self.static[k] = [t.to(dev).clone() for t in v]
+                else:
+                    self.static[k] = v
+            return
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                self.static[k].copy_(v)
+            elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+                for d, t in zip(self.static[k], v):
+                    d.copy_(t)
+
+    def __call__(self, batch, training_steps, crop):
+        tr = self.tr
+        key = (tuple(training_steps), tuple(crop))
+        self._stage(batch)
+        fixed = dict(training_steps=list(training_steps), crop=tuple(crop))
+        ent = self.graphs.get(key)
+        if ent is None:
+            # eager warm-up with the static buffers (fills memo tables, LoRA compute copies, side stream, workspaces)
+            tr._forward_backward(self.static, fixed)
+            tr._apply_updates()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logs = tr._forward_backward(self.static, fixed)
+            ent = self.graphs[key] = (g, logs)
+            torch.cuda.synchronize()
+        g, logs = ent
+        g.replay()
+        tr._apply_updates()
+        out = dict(logs)
+        out["training_steps"], out["crop"] = list(training_steps), tuple(crop)
+        return out

@@ -202,17 +202,19 @@ int comat_embedding(const int64_t* ids, const void* table, void* out, int64_t n,
 int comat_cross_entropy_fwd(const void* logits, const int64_t* labels, float* logp, float* row_lse,
                             float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld, int32_t ignore_index,
                             float label_smoothing, int32_t dtype, void* stream);
-/* dlogits = gscale * (softmax - smoothed one-hot) on valid rows, 0 elsewhere; gscale = upstream / n_valid. */
+/* dlogits = (g_up[0] / loss_sum_cnt[1]) * (softmax - smoothed one-hot) on valid rows, 0 elsewhere.  The upstream
+ * gradient and the valid-token count are DEVICE scalars: no host synchronisation in the middle of backward. */
 int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse, void* dlogits,
                             int64_t T, int32_t V, int64_t ld, int32_t ignore_index, float label_smoothing,
-                            float gscale, int32_t dtype, void* stream);
+                            const float* g_up, const float* loss_sum_cnt, int32_t dtype, void* stream);
 /* Discriminator head (training_utils/gan_sdxl.py:32-35,83-88,124-131): pred = x[p, 0:4] . w + b per pixel,
  * BCE-with-logits against target[p / pix_per_sample], mean over pixels.  x: [P, 4] channels-last UNet output.
  * fwd writes loss[0]; bwd writes dx [P,4] and accumulates dw[4], db[1] (fp32, caller zeroes). */
 int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss, int64_t P,
                         int64_t pix_per_sample, int32_t dtype, void* stream);
-int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, float gscale, void* dx,
-                        float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream);
+int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, const float* g_up,
+                        void* dx, float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype,
+                        void* stream);  /* g_up: upstream gradient, a DEVICE scalar */
 
 /* Attribute-concentration losses on one captured cross-attention map (attn_utils/tc_loss_utils.py:104-167).
  *   amap: [heads, res*res, L] probabilities of ONE sample and ONE layer; mask: [n_obj, res*res] fp32 {0,1};

@@ -279,7 +279,8 @@ class SimKernels:
         loss_sum_cnt[0] = loss[valid].sum()
         loss_sum_cnt[1] = valid.sum().float()
 
-    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, gscale):
+    def cross_entropy_bwd(self, logits, labels, row_lse, dlogits, T, V, ld, ignore_index, ls, g_up, loss_sum_cnt):
+        gscale = float(g_up[0]) / max(float(loss_sum_cnt[1]), 1.0)
         z = logits.float()
         valid = (labels != ignore_index) & (labels >= 0) & (labels < V)
         g = torch.exp(z - row_lse[:, None]) - ls / V
@@ -293,7 +294,8 @@ class SimKernels:
         t = target.float().repeat_interleave(pix_per_sample)[:P]
         loss[0] = F.binary_cross_entropy_with_logits(z, t)
 
-    def disc_head_bwd(self, x, w, b, target, gscale, dx, dw, db, P, pix_per_sample):
+    def disc_head_bwd(self, x, w, b, target, g_up, dx, dw, db, P, pix_per_sample):
+        gscale = float(g_up[0])
         xf = x.float()
         z = xf @ w.float() + b.float()
         t = target.float().repeat_interleave(pix_per_sample)[:P]
