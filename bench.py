@@ -222,10 +222,6 @@ def main():
     trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank, args.config)
 
     run_step = lambda: trainer.train_step(batch, **fixed)
-    if os.environ.get("COMAT_STEP_GRAPH", "0") == "1" and "training_steps" in fixed and world == 1:
-        from comat_amd.step import GraphedTrainStep
-        gstep = GraphedTrainStep(trainer)
-        run_step = lambda: gstep(batch, fixed["training_steps"], fixed["crop"])
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()

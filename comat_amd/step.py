@@ -235,57 +235,3 @@ class CoMatTrainer:
             self.opt_D.step()
             self.D.bank.mark_updated()
         return logs
-
-
-class GraphedTrainStep:
-    """Whole-step hipGraph: the forward + backward of G and D (≈16 k kernel launches, partly host-bound when issued
-    one by one) is captured ONCE per (training_steps, crop) variant and replayed; inputs go through static device
-    buffers; the gradient exchange and the optimizer kernels (whose bias-correction scalars change every step) stay
-    eager.  Opt-in: needs fixed `training_steps` and `crop` per variant and a device-resident batch."""
-
-    def __init__(self, trainer: CoMatTrainer):
-        self.tr = trainer
-        self.graphs = {}
-        self.static = None
-
-    def _stage(self, batch):
-        dev = self.tr.device
-        if self.static is None:
-            self.static = {}
-            for k, v in batch.items():
-                if isinstance(v, torch.Tensor):
-                    self.static[k] = v.to(dev).clone()
-                elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
-                    self.static[k] = [t.to(dev).clone() for t in v]
-                else:
-                    self.static[k] = v
-            return
-        for k, v in batch.items():
-            if isinstance(v, torch.Tensor):
-                self.static[k].copy_(v)
-            elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
-                for d, t in zip(self.static[k], v):
-                    d.copy_(t)
-
-    def __call__(self, batch, training_steps, crop):
-        tr = self.tr
-        key = (tuple(training_steps), tuple(crop))
-        self._stage(batch)
-        fixed = dict(training_steps=list(training_steps), crop=tuple(crop))
-        ent = self.graphs.get(key)
-        if ent is None:
-            # eager warm-up with the static buffers (fills memo tables, LoRA compute copies, side stream, workspaces)
-            tr._forward_backward(self.static, fixed)
-            tr._apply_updates()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                logs = tr._forward_backward(self.static, fixed)
-            ent = self.graphs[key] = (g, logs)
-            torch.cuda.synchronize()
-        g, logs = ent
-        g.replay()
-        tr._apply_updates()
-        out = dict(logs)
-        out["training_steps"], out["crop"] = list(training_steps), tuple(crop)
-        return out

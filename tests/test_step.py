@@ -132,27 +132,3 @@ def test_side_stream_overlap_is_bit_exact(hip):
     ops.set_side_stream_enabled(True)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
-
-
-@pytest.mark.gpu
-def test_whole_step_graph_matches_eager(hip):
-    """hipGraph replay of forward+backward (G and D) == the eager step, bit for bit, over several optimizer steps."""
-    from comat_amd.step import GraphedTrainStep
-    res = []
-    for graphed in (False, True):
-        cfg, batch, W, trainer = make_world(torch.bfloat16, hip, False)
-        gs = GraphedTrainStep(trainer) if graphed else None
-        losses = []
-        for it in range(4):
-            batch["latents"] = torch.randn(batch["latents"].shape, generator=torch.Generator().manual_seed(it))
-            if graphed:
-                logs = gs(batch, [1, 2], (0, 0, 63, 63))
-            else:
-                if it == 0:  # the graphed path takes one extra eager warm-up step on first use: mirror it
-                    trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
-                logs = trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
-            losses.append(float(logs["step_loss"]))
-        torch.cuda.synchronize()
-        res.append((losses, trainer.bank.flat.clone(), trainer.D.bank.flat.clone()))
-    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
-    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
