@@ -79,13 +79,13 @@ SIGNATURES = {
                          _i32, _vp],
     "comat_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_embedding": [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
-    "comat_cross_entropy_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _i32, _vp],
+    "comat_cross_entropy_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _i32, _vp],
     "comat_cross_entropy_bwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _f, _vp, _vp, _i32, _vp],
-    "comat_disc_head_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
+    "comat_disc_head_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "comat_disc_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp],
-    "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_attnmap_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "comat_sumsq": [_vp, _i64, _vp, _vp],
+    "comat_sumsq": [_vp, _i64, _vp, _vp, _vp],
     "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _f, _vp],
 }
 
@@ -296,9 +296,18 @@ class HipKernels:
                "comat_embedding")
 
     # ---- losses --------------------------------------------------------------------------------------------
+    def _scratch(self, dev, n):
+        """small fp32 scratch for the two-stage (fixed-order) reductions; one per (device, stream)"""
+        key = ("scratch", dev, _stream())
+        t = self._ws.get(key)
+        if t is None or t.numel() < n:
+            t = self._ws[key] = torch.empty(max(n, 16384), dtype=torch.float32, device=dev)
+        return t
+
     def cross_entropy_fwd(self, logits, labels, logp, row_lse, loss_sum_cnt, T, V, ld, ignore_index, ls):
         assert labels.dtype == torch.int64
-        _check(_lib.comat_cross_entropy_fwd(_ptr(logits), _ptr(labels), _ptr(logp), _ptr(row_lse),
+        ws = self._scratch(logits.device, T)
+        _check(_lib.comat_cross_entropy_fwd(_ptr(logits), _ptr(labels), _ptr(logp), _ptr(row_lse), _ptr(ws),
                                             _ptr(loss_sum_cnt), T, V, ld, ignore_index, ls, dt(logits), _stream()),
                "comat_cross_entropy_fwd")
 
@@ -308,18 +317,22 @@ class HipKernels:
                "comat_cross_entropy_bwd")
 
     def disc_head_fwd(self, x, w, b, target, loss, P, pix_per_sample):
-        _check(_lib.comat_disc_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(loss), P, pix_per_sample,
-                                        dt(x), _stream()), "comat_disc_head_fwd")
+        ws = self._scratch(x.device, 512)
+        _check(_lib.comat_disc_head_fwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(loss), _ptr(ws), P,
+                                        pix_per_sample, dt(x), _stream()), "comat_disc_head_fwd")
 
-    def disc_head_bwd(self, x, w, b, target, g_up, dx, dw, db, P, pix_per_sample):
-        _check(_lib.comat_disc_head_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(g_up), _ptr(dx), _ptr(dw),
-                                        _ptr(db), P, pix_per_sample, dt(x), _stream()), "comat_disc_head_bwd")
+    def disc_head_bwd(self, x, w, b, target, g_up, dx, dwb, P, pix_per_sample):
+        """dwb: fp32 [5] = (dw[0..3], db), accumulated; or None"""
+        ws = self._scratch(x.device, 512 * 5)
+        _check(_lib.comat_disc_head_bwd(_ptr(x), _ptr(w), _ptr(b), _ptr(target), _ptr(g_up), _ptr(dx), _ptr(dwb),
+                                        _ptr(ws), P, pix_per_sample, dt(x), _stream()), "comat_disc_head_bwd")
 
     def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):
         assert tok_idx.dtype == torch.int32 and tok_obj.dtype == torch.int32
+        ws = self._scratch(amap.device, ((npix + 255) // 256) * heads * n_tok * 2)
         _check(_lib.comat_attnmap_gather_fwd(_ptr(amap), _ptr(mask), _ptr(tok_idx), _ptr(tok_obj), _ptr(num),
-                                             _ptr(den), _ptr(avg), heads, npix, L, n_tok, dt(amap), _stream()),
-               "comat_attnmap_gather_fwd")
+                                             _ptr(den), _ptr(avg), _ptr(ws), heads, npix, L, n_tok, dt(amap),
+                                             _stream()), "comat_attnmap_gather_fwd")
 
     def attnmap_gather_bwd(self, g_num, g_den, g_avg, mask, tok_idx, tok_obj, damap, heads, npix, L, n_tok):
         _check(_lib.comat_attnmap_gather_bwd(_ptr(g_num), _ptr(g_den), _ptr(g_avg), _ptr(mask), _ptr(tok_idx),
@@ -328,7 +341,8 @@ class HipKernels:
 
     # ---- optimizer -----------------------------------------------------------------------------------------
     def sumsq(self, x, n, out):
-        _check(_lib.comat_sumsq(_ptr(x), n, _ptr(out), _stream()), "comat_sumsq")
+        ws = self._scratch(x.device, 1024)
+        _check(_lib.comat_sumsq(_ptr(x), n, _ptr(out), _ptr(ws), _stream()), "comat_sumsq")
 
     def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
         _check(_lib.comat_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, wd, step,

@@ -10,7 +10,7 @@ constexpr int NT = 256;
 template <typename T>
 __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits, const int64_t* __restrict__ labels,
                                                     float* __restrict__ logp, float* __restrict__ row_lse,
-                                                    float* __restrict__ loss_sum_cnt, int V, int64_t ld,
+                                                    float* __restrict__ row_loss, int V, int64_t ld,
                                                     int ignore_index, float ls) {
     __shared__ float sbuf[4];
     const int64_t t = blockIdx.x;
@@ -32,13 +32,23 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* __restrict__ logits
         const int64_t y = labels[t];
         if (y == ignore_index || y < 0 || y >= V) {
             logp[t] = 0.f;
+            row_loss[t] = -1.0f;  // marks an ignored row (a CE loss is never negative)
         } else {
             const float lp = ldf<T>(z + y) - lse;
             logp[t] = lp;
-            const float loss = (1.0f - ls) * (-lp) + ls * (lse - sz / V);
-            atomicAdd(&loss_sum_cnt[0], loss);
-            atomicAdd(&loss_sum_cnt[1], 1.0f);
+            row_loss[t] = (1.0f - ls) * (-lp) + ls * (lse - sz / V);
         }
+    }
+}
+
+// fixed-order sum over the token rows (deterministic; T is a few dozen)
+__global__ void ce_final_kernel(const float* __restrict__ row_loss, int64_t T, float* __restrict__ loss_sum_cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float sum = 0.f, cnt = 0.f;
+        for (int64_t t = 0; t < T; ++t)
+            if (row_loss[t] >= 0.f) { sum += row_loss[t]; cnt += 1.f; }
+        loss_sum_cnt[0] = sum;
+        loss_sum_cnt[1] = cnt;
     }
 }
 
@@ -74,7 +84,7 @@ __device__ __forceinline__ float bce_logits(float z, float t) {
 
 __global__ __launch_bounds__(NT) void disc_head_fwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b,
-                                                           const float* __restrict__ target, float* __restrict__ loss,
+                                                           const float* __restrict__ target, float* __restrict__ ws,
                                                            int64_t P, int64_t pps, int dt) {
     __shared__ float sbuf[4];
     float acc = 0.f;
@@ -85,15 +95,27 @@ __global__ __launch_bounds__(NT) void disc_head_fwd_kernel(const void* __restric
         acc += bce_logits(z, target[p / pps]);
     }
     acc = block_sum_256(acc, sbuf);
-    if (threadIdx.x == 0) atomicAdd(loss, acc / (float)P);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;  // reduced in fixed order by reduce_cols_kernel
+}
+
+// out[c] (+)= scale * sum_b ws[b*ncol + c], b in fixed order: the deterministic second stage of the loss reductions
+__global__ __launch_bounds__(NT) void reduce_cols_kernel(const float* __restrict__ ws, int nparts, int ncol,
+                                                         float scale, float* __restrict__ out, int accumulate) {
+    __shared__ float sbuf[4];
+    for (int c = 0; c < ncol; ++c) {
+        float acc = 0.f;
+        for (int i = threadIdx.x; i < nparts; i += NT) acc += ws[(int64_t)i * ncol + c];
+        acc = block_sum_256(acc, sbuf);
+        if (threadIdx.x == 0) out[c] = (accumulate ? out[c] : 0.f) + scale * acc;
+    }
 }
 
 __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ b,
                                                            const float* __restrict__ target,
                                                            const float* __restrict__ g_up,
-                                                           void* __restrict__ dx, float* __restrict__ dw,
-                                                           float* __restrict__ db, int64_t P, int64_t pps, int dt) {
+                                                           void* __restrict__ dx, float* __restrict__ ws,
+                                                           int want_wgrad, int64_t P, int64_t pps, int dt) {
     __shared__ float sbuf[4];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, ab = 0.f;
     const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], bb = b[0];
@@ -111,15 +133,15 @@ __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restric
         }
         a0 += dz * x0; a1 += dz * x1; a2 += dz * x2; a3 += dz * x3; ab += dz;
     }
-    if (dw) {
+    if (want_wgrad) {
         a0 = block_sum_256(a0, sbuf);
         a1 = block_sum_256(a1, sbuf);
         a2 = block_sum_256(a2, sbuf);
         a3 = block_sum_256(a3, sbuf);
         ab = block_sum_256(ab, sbuf);
         if (threadIdx.x == 0) {
-            atomicAdd(&dw[0], a0); atomicAdd(&dw[1], a1); atomicAdd(&dw[2], a2); atomicAdd(&dw[3], a3);
-            atomicAdd(&db[0], ab);
+            float* o = ws + (int64_t)blockIdx.x * 5;
+            o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; o[4] = ab;
         }
     }
 }
@@ -127,29 +149,46 @@ __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restric
 // ---- attribute-concentration gather over one captured map [heads, npix, L] ----------------------------------------
 constexpr int MAX_TOK = 32;
 
+// One block per 256-pixel chunk, looping over heads: the head-mean map is accumulated in registers (single owner, no
+// atomics) and the per-(head, token) spatial sums are written as per-block partials, reduced in fixed order afterwards.
 __global__ __launch_bounds__(NT) void attnmap_fwd_kernel(const void* __restrict__ amap, const float* __restrict__ mask,
                                                          const int32_t* __restrict__ tok_idx,
-                                                         const int32_t* __restrict__ tok_obj, float* __restrict__ num,
-                                                         float* __restrict__ den, float* __restrict__ avg, int heads,
-                                                         int npix, int L, int n_tok, int dt) {
+                                                         const int32_t* __restrict__ tok_obj, float* __restrict__ ws,
+                                                         float* __restrict__ avg, int heads, int npix, int L, int n_tok,
+                                                         int dt) {
     __shared__ float sbuf[4];
-    const int h = blockIdx.y;
     const int px = blockIdx.x * NT + threadIdx.x;
     const float inv_h = 1.0f / heads;
     for (int t = 0; t < n_tok; ++t) {
-        float v = 0.f, vm = 0.f;
-        if (px < npix) {
-            v = ld_dt(amap, ((int64_t)h * npix + px) * L + tok_idx[t], dt);
-            vm = v * mask[(int64_t)tok_obj[t] * npix + px];
-            atomicAdd(&avg[(int64_t)t * npix + px], v * inv_h);
+        const int tk = tok_idx[t];
+        const float mk = px < npix ? mask[(int64_t)tok_obj[t] * npix + px] : 0.f;
+        float av = 0.f;
+        for (int h = 0; h < heads; ++h) {
+            const float v = px < npix ? ld_dt(amap, ((int64_t)h * npix + px) * L + tk, dt) : 0.f;
+            av += v;
+            const float sn = block_sum_256(v * mk, sbuf);
+            const float sd = block_sum_256(v, sbuf);
+            if (threadIdx.x == 0) {
+                float* o = ws + (((int64_t)blockIdx.x * heads + h) * n_tok + t) * 2;
+                o[0] = sn;
+                o[1] = sd;
+            }
         }
-        const float sn = block_sum_256(vm, sbuf);
-        const float sd = block_sum_256(v, sbuf);
-        if (threadIdx.x == 0) {
-            atomicAdd(&num[h * n_tok + t], sn);
-            atomicAdd(&den[h * n_tok + t], sd);
-        }
+        if (px < npix) avg[(int64_t)t * npix + px] += av * inv_h;
     }
+}
+// num[h,t] += sum_blk ws[blk,h,t,0]; den likewise (fixed order over blocks)
+__global__ __launch_bounds__(NT) void attnmap_final_kernel(const float* __restrict__ ws, int nblk, int ht,
+                                                           float* __restrict__ num, float* __restrict__ den) {
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ht) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+        a += ws[((int64_t)k * ht + i) * 2];
+        b += ws[((int64_t)k * ht + i) * 2 + 1];
+    }
+    num[i] += a;
+    den[i] += b;
 }
 
 __global__ __launch_bounds__(NT) void attnmap_bwd_kernel(const float* __restrict__ g_num,
@@ -176,20 +215,18 @@ __global__ __launch_bounds__(NT) void attnmap_bwd_kernel(const float* __restrict
 #define ST ((hipStream_t)stream)
 
 extern "C" int comat_cross_entropy_fwd(const void* logits, const int64_t* labels, float* logp, float* row_lse,
-                                       float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld, int32_t ignore_index,
-                                       float label_smoothing, int32_t dtype, void* stream) {
-    COMAT_REQUIRE(logits && labels && logp && row_lse && loss_sum_cnt, "comat_cross_entropy_fwd: null pointer");
+                                       float* row_loss, float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld,
+                                       int32_t ignore_index, float label_smoothing, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(logits && labels && logp && row_lse && row_loss && loss_sum_cnt,
+                  "comat_cross_entropy_fwd: null pointer");
     COMAT_REQUIRE(T > 0 && V > 0 && ld >= V && T < (1ll << 31) && dtype_ok(dtype), "comat_cross_entropy_fwd: bad args");
-    if (hipMemsetAsync(loss_sum_cnt, 0, 2 * sizeof(float), ST) != hipSuccess) {
-        comat_set_error("comat_cross_entropy_fwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
     if (dtype == COMAT_BF16)
         hipLaunchKernelGGL(ce_fwd_kernel<bf16_t>, dim3((unsigned)T), dim3(NT), 0, ST, (const bf16_t*)logits, labels, logp,
-                           row_lse, loss_sum_cnt, V, ld, ignore_index, label_smoothing);
+                           row_lse, row_loss, V, ld, ignore_index, label_smoothing);
     else
         hipLaunchKernelGGL(ce_fwd_kernel<float>, dim3((unsigned)T), dim3(NT), 0, ST, (const float*)logits, labels, logp,
-                           row_lse, loss_sum_cnt, V, ld, ignore_index, label_smoothing);
+                           row_lse, row_loss, V, ld, ignore_index, label_smoothing);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, ST, (const float*)row_loss, T, loss_sum_cnt);
     return comat_check_launch("comat_cross_entropy_fwd");
 }
 
@@ -209,37 +246,43 @@ extern "C" int comat_cross_entropy_bwd(const void* logits, const int64_t* labels
 }
 
 extern "C" int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss,
-                                   int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream) {
-    COMAT_REQUIRE(x && w && b && target && loss, "comat_disc_head_fwd: null pointer");
+                                   float* ws, int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && w && b && target && loss && ws, "comat_disc_head_fwd: null pointer");
     COMAT_REQUIRE(P > 0 && pix_per_sample > 0 && dtype_ok(dtype), "comat_disc_head_fwd: bad args");
-    if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) {
-        comat_set_error("comat_disc_head_fwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
-    hipLaunchKernelGGL(disc_head_fwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, loss, P,
-                       pix_per_sample, dtype);
+    const int parts = grid_1d(P, NT, 512);
+    hipLaunchKernelGGL(disc_head_fwd_kernel, dim3(parts), dim3(NT), 0, ST, x, w, b, target, ws, P, pix_per_sample,
+                       dtype);
+    hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(NT), 0, ST, (const float*)ws, parts, 1, 1.0f / (float)P, loss,
+                       0);
     return comat_check_launch("comat_disc_head_fwd");
 }
 
 extern "C" int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target,
-                                   const float* g_up, void* dx, float* dw, float* db, int64_t P,
+                                   const float* g_up, void* dx, float* dwb, float* ws, int64_t P,
                                    int64_t pix_per_sample, int32_t dtype, void* stream) {
     COMAT_REQUIRE(x && w && b && target && g_up, "comat_disc_head_bwd: null pointer");
-    COMAT_REQUIRE((dw == nullptr) == (db == nullptr), "comat_disc_head_bwd: dw and db must both be given or both NULL");
+    COMAT_REQUIRE(!dwb || ws, "comat_disc_head_bwd: weight gradients need the workspace");
     COMAT_REQUIRE(P > 0 && pix_per_sample > 0 && dtype_ok(dtype), "comat_disc_head_bwd: bad args");
-    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(grid_1d(P, NT, 512)), dim3(NT), 0, ST, x, w, b, target, g_up, dx, dw,
-                       db, P, pix_per_sample, dtype);
+    const int parts = grid_1d(P, NT, 512);
+    hipLaunchKernelGGL(disc_head_bwd_kernel, dim3(parts), dim3(NT), 0, ST, x, w, b, target, g_up, dx, ws,
+                       dwb ? 1 : 0, P, pix_per_sample, dtype);
+    if (dwb) hipLaunchKernelGGL(reduce_cols_kernel, dim3(1), dim3(NT), 0, ST, (const float*)ws, parts, 5, 1.0f, dwb, 1);
     return comat_check_launch("comat_disc_head_bwd");
 }
 
 extern "C" int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx,
-                                        const int32_t* tok_obj, float* num, float* den, float* avg, int32_t heads,
-                                        int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream) {
-    COMAT_REQUIRE(amap && mask && tok_idx && tok_obj && num && den && avg, "comat_attnmap_gather_fwd: null pointer");
+                                        const int32_t* tok_obj, float* num, float* den, float* avg, float* ws,
+                                        int32_t heads, int32_t npix, int32_t L, int32_t n_tok, int32_t dtype,
+                                        void* stream) {
+    COMAT_REQUIRE(amap && mask && tok_idx && tok_obj && num && den && avg && ws,
+                  "comat_attnmap_gather_fwd: null pointer");
     COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
                   "comat_attnmap_gather_fwd: bad args");
-    hipLaunchKernelGGL(attnmap_fwd_kernel, dim3((npix + NT - 1) / NT, heads), dim3(NT), 0, ST, amap, mask, tok_idx,
-                       tok_obj, num, den, avg, heads, npix, L, n_tok, dtype);
+    const int nblk = (npix + NT - 1) / NT;
+    hipLaunchKernelGGL(attnmap_fwd_kernel, dim3(nblk), dim3(NT), 0, ST, amap, mask, tok_idx, tok_obj, ws, avg, heads,
+                       npix, L, n_tok, dtype);
+    hipLaunchKernelGGL(attnmap_final_kernel, dim3((heads * n_tok + NT - 1) / NT), dim3(NT), 0, ST, (const float*)ws, nblk,
+                       heads * n_tok, num, den);
     return comat_check_launch("comat_attnmap_gather_fwd");
 }
 

@@ -238,9 +238,38 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
                 f1 += p_a[rr * C + c];
                 f2 += p_b[rr * C + c];
             }
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)f1);
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)f2);
+        // per-block partial (no atomics): reduced in block order by gn_reduce_kernel -> bit-reproducible statistics
+        double* part = ws + ((int64_t)(1 + blockIdx.x) * gridDim.y + b) * G * 2;
+        part[threadIdx.x * 2 + 0] = (double)f1;
+        part[threadIdx.x * 2 + 1] = (double)f2;
     }
+}
+
+// ws[0 .. n) = sum over blocks of the partial slabs ws[(1+blk)*n + i], in block order
+__global__ void gn_reduce_kernel(double* __restrict__ ws, int nblk, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) acc += ws[(int64_t)(1 + k) * n + i];
+    ws[i] = acc;
+}
+
+// forward: block-ordered reduction of the partial slabs fused with the mean / rstd finalisation
+__global__ void gn_reduce_finalize_kernel(const double* __restrict__ ws, int nblk, int ngroups, float* __restrict__ stats,
+                                          double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngroups) return;
+    const int n = ngroups * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nblk; ++k) {
+        s1 += ws[(int64_t)(1 + k) * n + 2 * i];
+        s2 += ws[(int64_t)(1 + k) * n + 2 * i + 1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0) var = 0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // MODE 0: y = silu?(xhat*gamma+beta).   MODE 1: dx = rstd * (g - (s1 + xhat*s2)/n)
@@ -288,6 +317,7 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
     const int R = vpr >= NT ? 1 : NT / vpr;
     int64_t rpb = cdiv64((int64_t)B * HW, 1024);  // ~4 blocks per CU
     if (rpb < 4 * R) rpb = 4 * R;
+    if (rpb < cdiv64(HW, 1024)) rpb = cdiv64(HW, 1024);  // at most 1024 partial slabs in the workspace
     if (rpb > HW) rpb = HW;
     return (int)rpb;
 }
@@ -300,8 +330,8 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                        (const float*)nullptr, ws, (int)HW, C, G, silu, rpb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, (const double*)ws, stats, B * G,
-                       (double)HW * (C / G), eps);
+    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, st, (const double*)ws, (int)sg.x,
+                       B * G, stats, (double)HW * (C / G), eps);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 0>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
                        (const T*)nullptr, gamma, beta, (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G,
@@ -316,6 +346,7 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
                        (int)HW, C, G, silu, rpb);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3((B * G * 2 + 255) / 256), dim3(256), 0, st, ws, (int)sg.x, B * G * 2);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 1>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
                        (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, nvec);
@@ -392,14 +423,14 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
     COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_fwd: C or G too large");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_fwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
-        comat_set_error("comat_groupnorm_fwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
     if (gn_vec_ok(x, y, C, dtype, HW)) {
         if (dtype == COMAT_BF16) gn_fwd_vec<bf16_t>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
         else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
         return comat_check_launch("comat_groupnorm_fwd");
+    }
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {  // scalar fallback: fp64 atomics
+        comat_set_error("comat_groupnorm_fwd: memset failed");
+        return COMAT_ELAUNCH;
     }
     dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
     const int64_t total = (int64_t)B * HW * C;
@@ -427,14 +458,14 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
     COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_bwd: C or G too large");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
-        comat_set_error("comat_groupnorm_bwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
     if (gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0) {
         if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
         else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
         return comat_check_launch("comat_groupnorm_bwd");
+    }
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
+        comat_set_error("comat_groupnorm_bwd: memset failed");
+        return COMAT_ELAUNCH;
     }
     dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
     const int64_t total = (int64_t)B * HW * C;

@@ -6,12 +6,23 @@ namespace {
 
 constexpr int NT = 256;
 
-__global__ __launch_bounds__(NT) void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// Two stages with a fixed summation order: the global gradient norm (and with it the clip factor) must come out
+// bit-identical on every data-parallel rank, or the replicas drift apart; float atomics would make it order-dependent.
+__global__ __launch_bounds__(NT) void sumsq_partial_kernel(const float* __restrict__ x, int64_t n,
+                                                           float* __restrict__ ws) {
     __shared__ float sbuf[4];
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) acc += x[i] * x[i];
     acc = block_sum_256(acc, sbuf);
-    if (threadIdx.x == 0) atomicAdd(out, acc);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(NT) void sumsq_final_kernel(const float* __restrict__ ws, int nparts,
+                                                         float* __restrict__ out) {
+    __shared__ float sbuf[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += NT) acc += ws[i];
+    acc = block_sum_256(acc, sbuf);
+    if (threadIdx.x == 0) out[0] += acc;
 }
 
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -37,9 +48,11 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
-extern "C" int comat_sumsq(const float* x, int64_t n, float* out, void* stream) {
-    COMAT_REQUIRE(x && out && n > 0, "comat_sumsq: bad args");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_1d(n, NT, 1024)), dim3(NT), 0, (hipStream_t)stream, x, n, out);
+extern "C" int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
+    COMAT_REQUIRE(x && out && ws && n > 0, "comat_sumsq: bad args");
+    const int parts = grid_1d(n, NT, 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(parts), dim3(NT), 0, (hipStream_t)stream, x, n, ws);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, (const float*)ws, parts, out);
     return comat_check_launch("comat_sumsq");
 }
 

@@ -509,7 +509,7 @@ class _GroupNorm(Function):
         assert x.shape[0] == B * HW
         y = torch.empty_like(x)
         stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((B * G * 2,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((B * G * 2 * 1025,), dtype=torch.float64, device=x.device)
         kernels().groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu_)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (B, HW, Cc, G, silu_)
@@ -520,7 +520,7 @@ class _GroupNorm(Function):
         x, gamma, beta, stats = ctx.saved_tensors
         B, HW, Cc, G, silu_ = ctx.cfg
         dx = torch.empty_like(x)
-        ws = torch.empty((B * G * 2,), dtype=torch.float64, device=x.device)
+        ws = torch.empty((B * G * 2 * 1025,), dtype=torch.float64, device=x.device)
         kernels().groupnorm_bwd(_c(g), x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu_)
         return dx, None, None, None, None, None, None, None
 
@@ -839,11 +839,11 @@ class _DiscHead(Function):
         x, w, b, target = ctx.saved_tensors
         P = x.shape[0]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = db = None
+        dwb = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.zeros((4,), dtype=torch.float32, device=x.device)
-            db = torch.zeros((1,), dtype=torch.float32, device=x.device)
-        kernels().disc_head_bwd(x, w, b, target, _c(g.reshape(1).to(torch.float32)), dx, dw, db, P, ctx.pps)
+            dwb = torch.zeros((5,), dtype=torch.float32, device=x.device)
+            dw, db = dwb[:4], dwb[4:]
+        kernels().disc_head_bwd(x, w, b, target, _c(g.reshape(1).to(torch.float32)), dx, dwb, P, ctx.pps)
         return dx, dw, db, None, None
 
 

@@ -90,7 +90,8 @@ int comat_conv2d(const comat_conv_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional fused SiLU) on [B, HW, C] channels-last, G groups.  stats: [B, G, 2] fp32 (mean, rstd),
- * written by fwd and read by bwd.  ws: caller workspace of B*G*2 doubles (zeroed by the call).
+ * written by fwd and read by bwd.  ws: caller workspace of B*G*2*1025 doubles (final sums + up to 1024 per-block
+ * partial slabs, reduced in fixed order: bit-reproducible statistics).
  * gamma/beta fp32 [C].  bwd returns dx only (norm affine parameters are frozen: training_utils/pipeline.py:68-70).
  * Replaces: torch GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / VAE decoder.
  * ---------------------------------------------------------------------------------------------------------- */
@@ -200,8 +201,8 @@ int comat_embedding(const int64_t* ids, const void* table, void* out, int64_t n,
  * logits [T, V]; labels int64 [T] (already shifted by the caller); logp[T] = log-prob of the label ("token-level
  * concept score", 0 where ignored); loss_sum_cnt[2] = {sum of per-token losses, number of valid tokens}. */
 int comat_cross_entropy_fwd(const void* logits, const int64_t* labels, float* logp, float* row_lse,
-                            float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld, int32_t ignore_index,
-                            float label_smoothing, int32_t dtype, void* stream);
+                            float* row_loss /* [T] workspace */, float* loss_sum_cnt, int64_t T, int32_t V, int64_t ld,
+                            int32_t ignore_index, float label_smoothing, int32_t dtype, void* stream);
 /* dlogits = (g_up[0] / loss_sum_cnt[1]) * (softmax - smoothed one-hot) on valid rows, 0 elsewhere.  The upstream
  * gradient and the valid-token count are DEVICE scalars: no host synchronisation in the middle of backward. */
 int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* row_lse, void* dlogits,
@@ -210,11 +211,13 @@ int comat_cross_entropy_bwd(const void* logits, const int64_t* labels, const flo
 /* Discriminator head (training_utils/gan_sdxl.py:32-35,83-88,124-131): pred = x[p, 0:4] . w + b per pixel,
  * BCE-with-logits against target[p / pix_per_sample], mean over pixels.  x: [P, 4] channels-last UNet output.
  * fwd writes loss[0]; bwd writes dx [P,4] and accumulates dw[4], db[1] (fp32, caller zeroes). */
-int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss, int64_t P,
-                        int64_t pix_per_sample, int32_t dtype, void* stream);
+int comat_disc_head_fwd(const void* x, const float* w, const float* b, const float* target, float* loss,
+                        float* ws /* >= 512 floats */, int64_t P, int64_t pix_per_sample, int32_t dtype, void* stream);
+/* g_up: upstream gradient, a DEVICE scalar.  dwb: [5] = {dw[0..3], db}, accumulated (caller zeroes) or NULL;
+ * ws: >= 512*5 floats.  All reductions of this family are two-stage with a fixed order (bit-reproducible). */
 int comat_disc_head_bwd(const void* x, const float* w, const float* b, const float* target, const float* g_up,
-                        void* dx, float* dw, float* db, int64_t P, int64_t pix_per_sample, int32_t dtype,
-                        void* stream);  /* g_up: upstream gradient, a DEVICE scalar */
+                        void* dx, float* dwb, float* ws, int64_t P, int64_t pix_per_sample, int32_t dtype,
+                        void* stream);
 
 /* Attribute-concentration losses on one captured cross-attention map (attn_utils/tc_loss_utils.py:104-167).
  *   amap: [heads, res*res, L] probabilities of ONE sample and ONE layer; mask: [n_obj, res*res] fp32 {0,1};
@@ -225,8 +228,8 @@ int comat_disc_head_bwd(const void* x, const float* w, const float* b, const flo
  * The (tiny) remaining reductions are host-side torch on [heads, n_tok] and [n_tok, res*res] tensors.
  * bwd: dA[h,px,tok_t] += g_num[h,t]*mask + g_den[h,t] + g_avg[t,px]/heads   (dA zero elsewhere; caller zeroes). */
 int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx, const int32_t* tok_obj,
-                             float* num, float* den, float* avg, int32_t heads, int32_t npix, int32_t L,
-                             int32_t n_tok, int32_t dtype, void* stream);
+                             float* num, float* den, float* avg, float* ws /* ceil(npix/256)*heads*n_tok*2 floats */,
+                             int32_t heads, int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream);
 int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float* g_avg, const float* mask,
                              const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,
                              int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream);
@@ -234,8 +237,9 @@ int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer tail on the flat fp32 LoRA buffers (training_script.py:661-664,692-694).
  * ---------------------------------------------------------------------------------------------------------- */
-/* out[0] += sum(x^2)  (caller zeroes out) */
-int comat_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* out[0] += sum(x^2)  (caller zeroes out); ws: >= 1024 floats.  Fixed summation order: every data-parallel rank gets
+ * the bit-identical norm (and clip factor) from the all-reduced gradient. */
+int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 /* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)). */
 int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, void* stream);

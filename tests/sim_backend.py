@@ -294,7 +294,7 @@ class SimKernels:
         t = target.float().repeat_interleave(pix_per_sample)[:P]
         loss[0] = F.binary_cross_entropy_with_logits(z, t)
 
-    def disc_head_bwd(self, x, w, b, target, g_up, dx, dw, db, P, pix_per_sample):
+    def disc_head_bwd(self, x, w, b, target, g_up, dx, dwb, P, pix_per_sample):
         gscale = float(g_up[0])
         xf = x.float()
         z = xf @ w.float() + b.float()
@@ -302,9 +302,9 @@ class SimKernels:
         dz = gscale * (torch.sigmoid(z) - t) / P
         if dx is not None:
             dx.copy_((dz[:, None] * w.float()[None, :]).to(dx.dtype))
-        if dw is not None:
-            dw += dz @ xf
-            db += dz.sum()
+        if dwb is not None:
+            dwb[:4] += dz @ xf
+            dwb[4] += dz.sum()
 
     def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):
         a = amap.float()[:, :, tok_idx.long()]  # [h, npix, n_tok]

@@ -43,7 +43,7 @@ def test_argument_validation_reports_errors_without_launching():
     assert lib.comat_gemm(C.byref(p), None) == -1
     assert b"null operand" in lib.comat_last_error()
     assert lib.comat_unary(99, None, None, 0, 0.0, 0.0, 0, 0, None) == -1
-    assert lib.comat_sumsq(None, 0, None, None) == -1
+    assert lib.comat_sumsq(None, 0, None, None, None) == -1
 
 
 def test_product_fails_loudly_without_gpu_tensors():
