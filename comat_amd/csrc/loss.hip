@@ -149,46 +149,55 @@ __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restric
 // ---- attribute-concentration gather over one captured map [heads, npix, L] ----------------------------------------
 constexpr int MAX_TOK = 32;
 
-// One block per 256-pixel chunk, looping over heads: the head-mean map is accumulated in registers (single owner, no
-// atomics) and the per-(head, token) spatial sums are written as per-block partials, reduced in fixed order afterwards.
+// Grid (256-pixel chunk, head).  No atomics: per-(block, head, token) spatial sums and per-head token maps go to the
+// workspace and are combined in a fixed order by attnmap_final_kernel (bit-reproducible, still fully parallel).
+//   ws  = [nblk, heads, n_tok, 2] partial (masked sum, sum)   followed by   [heads, n_tok, npix] per-head values
 __global__ __launch_bounds__(NT) void attnmap_fwd_kernel(const void* __restrict__ amap, const float* __restrict__ mask,
                                                          const int32_t* __restrict__ tok_idx,
                                                          const int32_t* __restrict__ tok_obj, float* __restrict__ ws,
-                                                         float* __restrict__ avg, int heads, int npix, int L, int n_tok,
-                                                         int dt) {
+                                                         int heads, int npix, int L, int n_tok, int dt) {
     __shared__ float sbuf[4];
+    const int h = blockIdx.y;
     const int px = blockIdx.x * NT + threadIdx.x;
-    const float inv_h = 1.0f / heads;
+    float* wsv = ws + (int64_t)gridDim.x * heads * n_tok * 2;
     for (int t = 0; t < n_tok; ++t) {
-        const int tk = tok_idx[t];
-        const float mk = px < npix ? mask[(int64_t)tok_obj[t] * npix + px] : 0.f;
-        float av = 0.f;
-        for (int h = 0; h < heads; ++h) {
-            const float v = px < npix ? ld_dt(amap, ((int64_t)h * npix + px) * L + tk, dt) : 0.f;
-            av += v;
-            const float sn = block_sum_256(v * mk, sbuf);
-            const float sd = block_sum_256(v, sbuf);
-            if (threadIdx.x == 0) {
-                float* o = ws + (((int64_t)blockIdx.x * heads + h) * n_tok + t) * 2;
-                o[0] = sn;
-                o[1] = sd;
-            }
+        float v = 0.f, vm = 0.f;
+        if (px < npix) {
+            v = ld_dt(amap, ((int64_t)h * npix + px) * L + tok_idx[t], dt);
+            vm = v * mask[(int64_t)tok_obj[t] * npix + px];
+            wsv[((int64_t)h * n_tok + t) * npix + px] = v;
         }
-        if (px < npix) avg[(int64_t)t * npix + px] += av * inv_h;
+        const float sn = block_sum_256(vm, sbuf);
+        const float sd = block_sum_256(v, sbuf);
+        if (threadIdx.x == 0) {
+            float* o = ws + (((int64_t)blockIdx.x * heads + h) * n_tok + t) * 2;
+            o[0] = sn;
+            o[1] = sd;
+        }
     }
 }
-// num[h,t] += sum_blk ws[blk,h,t,0]; den likewise (fixed order over blocks)
-__global__ __launch_bounds__(NT) void attnmap_final_kernel(const float* __restrict__ ws, int nblk, int ht,
-                                                           float* __restrict__ num, float* __restrict__ den) {
-    const int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= ht) return;
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        a += ws[((int64_t)k * ht + i) * 2];
-        b += ws[((int64_t)k * ht + i) * 2 + 1];
+// num[h,t] += sum_blk partial; den likewise; avg[t,px] += (1/heads) * sum_h value[h,t,px]   (fixed orders)
+__global__ __launch_bounds__(NT) void attnmap_final_kernel(const float* __restrict__ ws, int nblk, int heads, int n_tok,
+                                                           int npix, float* __restrict__ num, float* __restrict__ den,
+                                                           float* __restrict__ avg) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int ht = heads * n_tok;
+    if (i < ht) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < nblk; ++k) {
+            a += ws[((int64_t)k * ht + i) * 2];
+            b += ws[((int64_t)k * ht + i) * 2 + 1];
+        }
+        num[i] += a;
+        den[i] += b;
     }
-    num[i] += a;
-    den[i] += b;
+    const float* wsv = ws + (int64_t)nblk * ht * 2;
+    const int64_t tp = (int64_t)n_tok * npix;
+    if (i < tp) {
+        float a = 0.f;
+        for (int h = 0; h < heads; ++h) a += wsv[(int64_t)h * tp + i];
+        avg[i] += a / heads;
+    }
 }
 
 __global__ __launch_bounds__(NT) void attnmap_bwd_kernel(const float* __restrict__ g_num,
@@ -279,10 +288,11 @@ extern "C" int comat_attnmap_gather_fwd(const void* amap, const float* mask, con
     COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
                   "comat_attnmap_gather_fwd: bad args");
     const int nblk = (npix + NT - 1) / NT;
-    hipLaunchKernelGGL(attnmap_fwd_kernel, dim3(nblk), dim3(NT), 0, ST, amap, mask, tok_idx, tok_obj, ws, avg, heads,
+    hipLaunchKernelGGL(attnmap_fwd_kernel, dim3(nblk, heads), dim3(NT), 0, ST, amap, mask, tok_idx, tok_obj, ws, heads,
                        npix, L, n_tok, dtype);
-    hipLaunchKernelGGL(attnmap_final_kernel, dim3((heads * n_tok + NT - 1) / NT), dim3(NT), 0, ST, (const float*)ws, nblk,
-                       heads * n_tok, num, den);
+    const int64_t work = (int64_t)n_tok * npix > (int64_t)heads * n_tok ? (int64_t)n_tok * npix : (int64_t)heads * n_tok;
+    hipLaunchKernelGGL(attnmap_final_kernel, dim3((unsigned)cdiv64(work, NT)), dim3(NT), 0, ST, (const float*)ws, nblk,
+                       heads, n_tok, npix, num, den, avg);
     return comat_check_launch("comat_attnmap_gather_fwd");
 }
 

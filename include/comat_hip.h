@@ -228,7 +228,8 @@ int comat_disc_head_bwd(const void* x, const float* w, const float* b, const flo
  * The (tiny) remaining reductions are host-side torch on [heads, n_tok] and [n_tok, res*res] tensors.
  * bwd: dA[h,px,tok_t] += g_num[h,t]*mask + g_den[h,t] + g_avg[t,px]/heads   (dA zero elsewhere; caller zeroes). */
 int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx, const int32_t* tok_obj,
-                             float* num, float* den, float* avg, float* ws /* ceil(npix/256)*heads*n_tok*2 floats */,
+                             float* num, float* den, float* avg,
+                             float* ws /* (ceil(npix/256)*2 + npix) * heads * n_tok floats */,
                              int32_t heads, int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream);
 int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float* g_avg, const float* mask,
                              const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,
