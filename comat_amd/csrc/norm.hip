@@ -245,31 +245,41 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
     }
 }
 
-// ws[0 .. n) = sum over blocks of the partial slabs ws[(1+blk)*n + i], in block order
-__global__ void gn_reduce_kernel(double* __restrict__ ws, int nblk, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double acc = 0.0;
-    for (int k = 0; k < nblk; ++k) acc += ws[(int64_t)(1 + k) * n + i];
-    ws[i] = acc;
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-// forward: block-ordered reduction of the partial slabs fused with the mean / rstd finalisation
+// ws[0 .. n) = sum over blocks of the partial slabs ws[(1+blk)*n + i]: one wave per output, lane l takes slabs
+// l, l+64, ... and the lanes are combined by a fixed butterfly -> a fixed summation order, but not a serial loop
+__global__ void gn_reduce_kernel(double* __restrict__ ws, int nblk, int n) {
+    const int i = blockIdx.x;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) acc += ws[(int64_t)(1 + k) * n + i];
+    acc = wave_sum_f64(acc);
+    if (threadIdx.x == 0) ws[i] = acc;
+}
+
+// forward: the same reduction fused with the mean / rstd finalisation (one wave per (sample, group))
 __global__ void gn_reduce_finalize_kernel(const double* __restrict__ ws, int nblk, int ngroups, float* __restrict__ stats,
                                           double count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ngroups) return;
+    const int i = blockIdx.x;
     const int n = ngroups * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = threadIdx.x; k < nblk; k += 64) {
         s1 += ws[(int64_t)(1 + k) * n + 2 * i];
         s2 += ws[(int64_t)(1 + k) * n + 2 * i + 1];
     }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0) var = 0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
+    if (threadIdx.x == 0) {
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0) var = 0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // MODE 0: y = silu?(xhat*gamma+beta).   MODE 1: dx = rstd * (g - (s1 + xhat*s2)/n)
@@ -330,8 +340,8 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                        (const float*)nullptr, ws, (int)HW, C, G, silu, rpb);
-    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3((B * G + 63) / 64), dim3(64), 0, st, (const double*)ws, (int)sg.x,
-                       B * G, stats, (double)HW * (C / G), eps);
+    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(B * G), dim3(64), 0, st, (const double*)ws, (int)sg.x, B * G, stats,
+                       (double)HW * (C / G), eps);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 0>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
                        (const T*)nullptr, gamma, beta, (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G,
@@ -346,7 +356,7 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
                        (int)HW, C, G, silu, rpb);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3((B * G * 2 + 255) / 256), dim3(256), 0, st, ws, (int)sg.x, B * G * 2);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 1>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
                        (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, nvec);
