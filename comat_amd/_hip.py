@@ -35,6 +35,10 @@ class GemmParams(C.Structure):
     ]
 
 
+class GemmSegment(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64)]
+
+
 class ConvParams(C.Structure):
     _fields_ = [
         ("X", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p),
@@ -54,6 +58,7 @@ _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 # name -> argtypes (restype is int unless noted); mirrors include/comat_hip.h one to one.
 SIGNATURES = {
     "comat_gemm": [C.POINTER(GemmParams), _vp],
+    "comat_gemm_segments": [C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, _vp],
     "comat_conv2d": [C.POINTER(ConvParams), _vp],
     "comat_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp],
     "comat_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp],
@@ -73,6 +78,7 @@ SIGNATURES = {
     "comat_add_rowvec": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "comat_sumpool2x2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_permute_nchw_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "comat_transpose_cast_tiles": [_vp, _vp, _vp, _i64, _i32, _vp],
     "comat_cfg_ddpm_fwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i32, _vp],
     "comat_cfg_ddpm_bwd": [_vp, _vp, _vp, _i64, _f, _f, _f, _i32, _vp],
     "comat_resample2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
@@ -186,6 +192,31 @@ class HipKernels:
         ws = self._workspace(A.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_gemm(C.byref(p), _stream()), "comat_gemm")
+
+    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0):
+        """Cout[M, N] = alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + beta * R;  segs: [(A, B, K, lda, ldb), ...]"""
+        n = len(segs)
+        arr = (GemmSegment * n)()
+        for i, (A, B, K, lda, ldb) in enumerate(segs):
+            assert A.dtype == B.dtype == segs[0][0].dtype
+            arr[i].A, arr[i].B, arr[i].K, arr[i].lda, arr[i].ldb = _ptr(A), _ptr(B), K, lda, ldb
+        p = GemmParams()
+        p.C, p.bias, p.R = _ptr(Cout), _ptr(bias), _ptr(R)
+        if bias is not None:
+            assert bias.dtype == torch.float32
+        p.M, p.N, p.ldc, p.ldr = M, N, ldc, ldr
+        p.batch1 = p.batch2 = 1
+        p.alpha, p.beta = alpha, beta
+        p.in_dtype, p.out_dtype = dt(segs[0][0]), dt(Cout)
+        p.r_dtype = dt(R) if R is not None else 0
+        ws = self._workspace(Cout.device)
+        p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
+        _check(_lib.comat_gemm_segments(C.byref(p), arr, n, _stream()), "comat_gemm_segments")
+
+    def transpose_cast_tiles(self, src, dst, tiles):
+        assert src.dtype == torch.float32 and tiles.dtype == torch.int64 and tiles.shape[1] == 6
+        _check(_lib.comat_transpose_cast_tiles(_ptr(src), _ptr(dst), _ptr(tiles), tiles.shape[0], dt(dst), _stream()),
+               "comat_transpose_cast_tiles")
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
                bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):

@@ -233,17 +233,25 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_
 }
 
 template <typename T> __global__ __launch_bounds__(NT) void flash_prep_kernel(FlashArgs a) {
-    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;  // (b*H + h)*Nq + q
+    // thread -> (b, q, h) with h fastest: a wave reads whole token rows of O / dO with 16-byte loads
+    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
     const int64_t total = (int64_t)a.B * a.H * a.Nq;
     if (idx >= total) return;
-    const int q = (int)(idx % a.Nq);
-    const int bh = (int)(idx / a.Nq);
-    const int b = bh / a.H, h = bh % a.H;
+    const int h = (int)(idx % a.H);
+    const int q = (int)((idx / a.H) % a.Nq);
+    const int b = (int)(idx / ((int64_t)a.H * a.Nq));
     const T* o = (const T*)a.O + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
     const T* g = (const T*)a.dO + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
+    constexpr int EPV = 16 / (int)sizeof(T);
     float acc = 0.f;
-    for (int c = 0; c < a.d; ++c) acc += ldf<T>(o + c) * ldf<T>(g + c);
-    a.Dbuf[idx] = acc;
+    for (int c = 0; c < a.d; c += EPV) {
+        const uint4 ov = *(const uint4*)(o + c), gv = *(const uint4*)(g + c);
+        const T* oe = (const T*)&ov;
+        const T* ge = (const T*)&gv;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc += ldf<T>(oe + e) * ldf<T>(ge + e);
+    }
+    a.Dbuf[((int64_t)b * a.H + h) * a.Nq + q] = acc;
 }
 
 template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
@@ -480,7 +488,7 @@ extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V,
                                     int64_t ldo, float scale, int32_t dtype, void* stream) {
     if (int rc = check_args("comat_flash_attn_bwd", Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
     COMAT_REQUIRE(O && dO && lse && Dbuf && dQ && dK && dV, "comat_flash_attn_bwd: null pointer");
-    COMAT_REQUIRE((((uintptr_t)dO) & 15) == 0, "comat_flash_attn_bwd: dO must be 16-byte aligned");
+    COMAT_REQUIRE((((uintptr_t)dO | (uintptr_t)O) & 15) == 0, "comat_flash_attn_bwd: O and dO must be 16-byte aligned");
     FlashArgs a = {};
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.lse = (float*)lse; a.Dbuf = Dbuf;
     a.dQ = dQ; a.dK = dK; a.dV = dV;

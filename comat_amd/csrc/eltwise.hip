@@ -144,6 +144,27 @@ __global__ __launch_bounds__(NT) void cfg_ddpm_bwd_kernel(const float* __restric
     }
 }
 
+// Batched transpose + cast of many small matrices in one launch: block b handles the 32x32 tile described by
+// tiles[b] = (src_off, dst_off, rows, cols, r0, c0): dst[dst_off + c*rows + r] = src[src_off + r*cols + c].
+__global__ __launch_bounds__(NT) void transpose_tiles_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                             const int64_t* __restrict__ tiles, int out_dt) {
+    __shared__ float tile[32][33];
+    const int64_t* d = tiles + (int64_t)blockIdx.x * 6;
+    const int64_t so = d[0], dof = d[1], rows = d[2], cols = d[3], r0 = d[4], c0 = d[5];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 32; j += NT / 32) {
+        const int64_t r = r0 + ty + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + j][tx] = src[so + r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += NT / 32) {
+        const int64_t c = c0 + ty + j, r = r0 + tx;
+        if (r < rows && c < cols) st_dt(dst, dof + c * rows + r, tile[tx][ty + j], out_dt);
+    }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)stream)
@@ -236,4 +257,12 @@ extern "C" int comat_cfg_ddpm_bwd(const float* g, float* dx, void* deps2, int64_
     hipLaunchKernelGGL(cfg_ddpm_bwd_kernel, dim3(grid_1d(n, NT)), dim3(NT), 0, ST, g, dx, deps2, n, s, cx, ce,
                        eps_dtype);
     return comat_check_launch("comat_cfg_ddpm_bwd");
+}
+
+extern "C" int comat_transpose_cast_tiles(const float* src, void* dst, const int64_t* tiles, int64_t n_tiles,
+                                          int32_t out_dtype, void* stream) {
+    COMAT_REQUIRE(src && dst && tiles && n_tiles > 0 && n_tiles < (1ll << 31) && dtype_ok(out_dtype),
+                  "comat_transpose_cast_tiles: bad args");
+    hipLaunchKernelGGL(transpose_tiles_kernel, dim3((unsigned)n_tiles), dim3(NT), 0, ST, src, dst, tiles, out_dtype);
+    return comat_check_launch("comat_transpose_cast_tiles");
 }

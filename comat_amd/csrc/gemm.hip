@@ -136,6 +136,119 @@ template <typename T, int ROWS, bool TRANS> struct PlainLoader {
     }
 };
 
+// K-segmented operand: C = sum_s A_s[M, K_s] B_s[N, K_s]^T with every A_s / B_s k-contiguous.  The k-tile sequence is
+// the concatenation of the segments (each padded to whole k-tiles with zeros by the kpos < K mask), so LoRA's
+// "frozen weight + low-rank branch" and the sum of several projections' data-gradients run as ONE contraction.
+constexpr int MAXSEG = 8;
+struct SegTable {
+    const void* A[MAXSEG];
+    const void* B[MAXSEG];
+    int64_t lda[MAXSEG], ldb[MAXSEG];
+    int K[MAXSEG];
+    int nseg;
+};
+
+template <typename T, int ROWS> struct SegLoader {
+    static constexpr bool kTrans = false;
+    static constexpr int EPV = 16 / sizeof(T);
+    static constexpr int BKE = KTB / sizeof(T);
+    static constexpr int NCH = ROWS * CPR / NT;
+    const T* ptr[NCH];
+    int kpos[NCH];
+    int64_t grow[NCH];   // clamped global row of the chunk
+    int rleft[NCH];
+    int lds_off[NCH];
+    int K, seg, tiles_left;
+    bool vec_ok, is_b;
+    uint4 regs[PF][NCH];
+
+    // segment `sg`, starting `toff` k-tiles into it.  The table is scanned with an unrolled select (uniform values:
+    // scalar selects, no dynamic indexing of the kernel-argument struct)
+    __device__ __forceinline__ void setup(const SegTable& t, int sg, int toff) {
+        const void* P = nullptr;
+        int64_t ld = 0;
+        int k = 0;
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s)
+            if (s == sg) {
+                P = is_b ? t.B[s] : t.A[s];
+                ld = is_b ? t.ldb[s] : t.lda[s];
+                k = t.K[s];
+            }
+        seg = sg;
+        K = k;
+        tiles_left = (k + BKE - 1) / BKE - toff;
+        vec_ok = ((ld % EPV) == 0) && ((((uintptr_t)P) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int kv = (threadIdx.x + i * NT) % CPR;
+            kpos[i] = toff * BKE + kv * EPV;
+            ptr[i] = (const T*)P + grow[i] * ld + kpos[i];
+        }
+    }
+    __device__ __forceinline__ void init(const SegTable& t, bool b_operand, int64_t r0, int64_t rmax, int64_t kt0) {
+        is_b = b_operand;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * NT;
+            const int row = c / CPR, kv = c % CPR;
+            const int64_t gr = r0 + row;
+            rleft[i] = gr < rmax ? 1 : 0;
+            grow[i] = gr < rmax ? gr : 0;
+            lds_off[i] = row * ROWB + kv * 16;
+        }
+        int sg = 0;
+        int64_t t0 = kt0;
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s) {
+            const int64_t nt = (t.K[s] + BKE - 1) / BKE;
+            if (s == sg && s + 1 < t.nseg && t0 >= nt) {
+                t0 -= nt;
+                ++sg;
+            }
+        }
+        setup(t, sg, (int)t0);
+    }
+    __device__ __forceinline__ void load(const SegTable& t, int slot) {
+        if (tiles_left <= 0 && seg + 1 < t.nseg) setup(t, seg + 1, 0);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            Vec16 v;
+            v.u = make_uint4(0, 0, 0, 0);
+            const T* src = ptr[i];
+            if (rleft[i] && kpos[i] < K) {
+                if (vec_ok && kpos[i] + EPV <= K) {
+                    v.u = *(const uint4*)src;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e)
+                        if (kpos[i] + e < K) {
+                            if (sizeof(T) == 2) v.h[e] = ((const bf16_t*)src)[e];
+                            else v.f[e] = ((const float*)src)[e];
+                        }
+                }
+            }
+            regs[slot][i] = v.u;
+            ptr[i] += BKE;
+            kpos[i] += BKE;
+        }
+        --tiles_left;
+    }
+    __device__ __forceinline__ void store(char* lds, int slot) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) *(uint4*)(lds + lds_off[i]) = regs[slot][i];
+    }
+};
+
+// adapter: gives a SegLoader the load(slot) interface of the other loaders
+template <typename T, int ROWS> struct SegLoaderRef {
+    static constexpr bool kTrans = false;
+    SegLoader<T, ROWS> l;
+    const SegTable* t;
+    __device__ __forceinline__ void load(int slot) { l.load(*t, slot); }
+    __device__ __forceinline__ void store(char* lds, int slot) const { l.store(lds, slot); }
+};
+
 struct ConvGeom {
     int B, Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad, mode, ups;
 };
@@ -447,6 +560,32 @@ template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_boun
     gemm_block<T, BM, BN>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
 }
 
+struct GemmSegArgs {
+    SegTable t;
+    int64_t M, N, nk;
+    int tiles_m, tiles_n, splits;
+    float* ws;
+    Epi ep;
+};
+
+template <typename T> __global__ __launch_bounds__(NT) void gemm_seg_kernel(GemmSegArgs g) {
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
+    const int64_t per = (g.nk + g.splits - 1) / g.splits;
+    int64_t kt0 = (int64_t)sp * per;
+    const int64_t kt1 = kt0 + per < g.nk ? kt0 + per : g.nk;
+    if (kt0 > g.nk) kt0 = g.nk;
+    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    SegLoaderRef<T, 64> al, bl;
+    al.t = bl.t = &g.t;
+    al.l.init(g.t, false, m0, g.M, kt0);
+    bl.l.init(g.t, true, n0, g.N, kt0);
+    gemm_block<T, 64, 64>(al, bl, kt0, kt1, m0, n0, g.M, g.N, g.ep, slab);
+}
+
 // sums the split-K slabs and applies the fused epilogue: C = act(alpha*sum + bias + bias2) + beta*R
 struct ReduceArgs {
     const float* ws;
@@ -608,6 +747,54 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     if (g.splits > 1)
         launch_reduce(g.ws, p->M, p->N, batch, p->batch2, p->sC1, p->sC2, p->sR1, p->sR2, g.splits, g.ep, st);
     return comat_check_launch("comat_gemm");
+}
+
+extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int32_t nseg,
+                                   void* stream) {
+    COMAT_REQUIRE(p != nullptr && segs != nullptr, "comat_gemm_segments: null params");
+    COMAT_REQUIRE(nseg >= 1 && nseg <= MAXSEG, "comat_gemm_segments: 1..%d segments supported, got %d", MAXSEG, nseg);
+    COMAT_REQUIRE(p->C && p->M > 0 && p->N > 0, "comat_gemm_segments: bad output / shape");
+    COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_gemm_segments: bad dtype");
+    COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_gemm_segments: bad residual dtype");
+    COMAT_REQUIRE(p->batch1 <= 1 && p->batch2 <= 1 && !p->transA && !p->transB,
+                  "comat_gemm_segments: operands must be k-contiguous and unbatched");
+    COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm_segments: bias2 needs rows_per_bias2");
+    COMAT_REQUIRE(p->ldc >= p->N, "comat_gemm_segments: ldc too small");
+    GemmSegArgs g;
+    const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
+    g.nk = 0;
+    for (int s = 0; s < MAXSEG; ++s) {
+        if (s < nseg) {
+            COMAT_REQUIRE(segs[s].A && segs[s].B && segs[s].K > 0 && segs[s].K < (1ll << 30),
+                          "comat_gemm_segments: bad segment %d", s);
+            COMAT_REQUIRE(segs[s].lda >= segs[s].K && segs[s].ldb >= segs[s].K,
+                          "comat_gemm_segments: leading dimension of segment %d too small", s);
+            g.t.A[s] = segs[s].A; g.t.B[s] = segs[s].B;
+            g.t.lda[s] = segs[s].lda; g.t.ldb[s] = segs[s].ldb; g.t.K[s] = (int)segs[s].K;
+            g.nk += cdiv64(segs[s].K, bke);
+        } else {
+            g.t.A[s] = g.t.B[s] = nullptr;
+            g.t.lda[s] = g.t.ldb[s] = 0; g.t.K[s] = 0;
+        }
+    }
+    g.t.nseg = nseg;
+    g.M = p->M; g.N = p->N;
+    g.ep.C = p->C; g.ep.bias = p->bias; g.ep.bias2 = p->bias2; g.ep.R = p->R;
+    g.ep.ldc = p->ldc; g.ep.ldr = p->ldr; g.ep.rows_per_b2 = p->rows_per_bias2 > 0 ? p->rows_per_bias2 : 1;
+    g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
+    g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
+    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, 1, p->ws ? p->ws_bytes : 0);
+    g.tiles_m = (int)cdiv64(p->M, 64);
+    g.tiles_n = (int)cdiv64(p->N, 64);
+    g.splits = plan.splits;
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm_segments: too many tiles");
+    g.ws = (float*)p->ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (p->in_dtype == COMAT_BF16) hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
+    if (g.splits > 1) launch_reduce(g.ws, p->M, p->N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
+    return comat_check_launch("comat_gemm_segments");
 }
 
 extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {

@@ -104,26 +104,110 @@ class FrozenConv:
         self.stride, self.pad = stride, pad
 
 
-class LoRAPair:
-    """fp32 master LoRA factors (trainable leaves) with cached compute-dtype copies.
-    y += scale * up(down(x)); down [r, in], up [out, r]  (diffusers LoRALinearLayer)."""
+class LoRAGroup:
+    """The LoRA factors of G projections that read the SAME input (q/k/v of a self-attention, k/v of a
+    cross-attention, or a single projection):  y_i = x W_i^T + b_i + s * (x D_i^T) U_i^T.
+    The G down factors are adjacent in the store's flat buffers, so `down_cat` [G*r, in] is ONE matrix: one GEMM
+    produces all low-rank activations and one GEMM all down-gradients."""
 
-    def __init__(self, down: torch.Tensor, up: torch.Tensor, dtype, scale=1.0, bank=None, views=None):
-        self.down, self.up = down, up  # views into the flat fp32 parameter buffer, requires_grad
-        self.dtype, self.scale = dtype, scale
-        self._cache = None
-        self.bank, self.views = bank, views  # optional: compute-dtype views of the bank's flat compute copy
+    def __init__(self, store, index, down_cat, ups, rank, scale=1.0):
+        self.store, self.index = store, index
+        self.down_cat, self.ups = down_cat, ups      # fp32 leaves (views of store.flat) with .grad views
+        self.rank, self.scale, self.size = rank, scale, len(ups)
 
     def compute_copies(self):
-        if self.dtype == torch.float32:
-            return self.down.detach(), self.up.detach()
-        if self.bank is not None:
-            self.bank.ensure_compute_copy()
-            return self.views
-        key = (self.down._version, self.up._version)
-        if self._cache is None or self._cache[0] != key:
-            self._cache = (key, cast(self.down.detach(), self.dtype), cast(self.up.detach(), self.dtype))
-        return self._cache[1], self._cache[2]
+        """(down_cat [G*r, in], [up_i [out_i, r]], down_cat^T [in, G*r]) in the compute dtype."""
+        self.store.ensure_compute_copy()
+        return self.store.group_views[self.index]
+
+
+class LoRAStore:
+    """All trainable LoRA factors of one model in ONE flat fp32 buffer (+ one flat gradient buffer).  Every factor
+    is a leaf view whose .grad is a view of the flat gradient: the GEMM epilogues accumulate weight gradients in
+    place, RCCL all-reduces the flat buffer and the fused clip+AdamW kernel consumes it.  Two derived buffers are
+    refreshed by one kernel each after an optimizer step: `flat_c` (compute-dtype copy) and `flat_t` (compute-dtype
+    TRANSPOSED copies of the grouped down factors, so their data-gradient runs through the k-contiguous GEMM path).
+
+    spec: list of groups; a group is a list of (down_name, up_name, down [r, in], up [out, r]) sharing `in`."""
+
+    def __init__(self, spec, dtype, device, scale=1.0):
+        self.names, shapes, layout = [], [], []
+        off = toff = 0
+        for members in spec:
+            r, cin = members[0][2].shape
+            assert all(tuple(m[2].shape) == (r, cin) and m[3].shape[1] == r for m in members)
+            g = dict(down_off=off, rank=r, cin=cin, n=len(members), t_off=toff, ups=[])
+            for dn, _, d, _ in members:
+                self.names.append(dn)
+                shapes.append((off, tuple(d.shape)))
+                off += r * cin
+            for _, un, _, u in members:
+                self.names.append(un)
+                shapes.append((off, tuple(u.shape)))
+                g["ups"].append((off, tuple(u.shape)))
+                off += u.shape[0] * r
+            toff += len(members) * r * cin
+            layout.append(g)
+        total = off
+        src = {}
+        for members in spec:
+            for dn, un, d, u in members:
+                src[dn], src[un] = d, u
+        self.dtype, self.device = dtype, device
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat.copy_(torch.cat([src[n].detach().reshape(-1).float() for n in self.names]).to(device))
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_c = None if dtype == torch.float32 else torch.empty(total, dtype=dtype, device=device)
+        self.flat_t = torch.empty(toff, dtype=dtype, device=device)
+        self._fresh = False
+
+        def leaf(o, shp):
+            n = shp[0] * shp[1]
+            p = self.flat[o:o + n].view(shp).requires_grad_(True)
+            p.grad = self.flat_grad[o:o + n].view(shp)
+            return p
+
+        self.params = {n: leaf(o, shp) for n, (o, shp) in zip(self.names, shapes)}
+        comp = self.flat if self.flat_c is None else self.flat_c
+        self.groups, self.group_views, self._leaves, tiles = [], [], list(self.params.values()), []
+        for gi, g in enumerate(layout):
+            r, cin, n = g["rank"], g["cin"], g["n"]
+            dcat = leaf(g["down_off"], (n * r, cin))
+            ups = [leaf(o, shp) for o, shp in g["ups"]]
+            self._leaves += [dcat] + ups
+            self.groups.append(LoRAGroup(self, gi, dcat, ups, r, scale))
+            cv = lambda o, shp: comp[o:o + shp[0] * shp[1]].view(shp)
+            self.group_views.append((cv(g["down_off"], (n * r, cin)), [cv(o, shp) for o, shp in g["ups"]],
+                                     self.flat_t[g["t_off"]:g["t_off"] + n * r * cin].view(cin, n * r)))
+            for r0 in range(0, n * r, 32):
+                for c0 in range(0, cin, 32):
+                    tiles.append((g["down_off"], g["t_off"], n * r, cin, r0, c0))
+        self._tiles = torch.tensor(tiles, dtype=torch.int64).to(device)
+
+    def ensure_compute_copy(self):
+        if not self._fresh:
+            k = kernels()
+            if self.flat_c is not None:
+                k.unary(UN_COPY, self.flat, self.flat_c, self.flat.numel())
+            k.transpose_cast_tiles(self.flat, self.flat_t, self._tiles)
+            self._fresh = True
+
+    def mark_updated(self):
+        """call after an in-place update of `flat` (optimizer kernel): the derived copies are refreshed lazily."""
+        self._fresh = False
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p in self._leaves:  # keep the views bound (the GEMM epilogues accumulate into them in place)
+            if p.grad is None or p.grad.data_ptr() == 0:
+                raise RuntimeError("LoRA .grad view was dropped")
+
+    def set_requires_grad(self, flag: bool):
+        for p in self._leaves:
+            p.requires_grad_(flag)
+
+    def state_dict(self):
+        return {n: p.detach().clone() for n, p in self.params.items()}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -369,78 +453,97 @@ def linear(x, lin: FrozenLinear, residual=None, act=ACT_NONE, out_dtype=None):
     return _Linear.apply(x, residual, lin, act, out_dtype)
 
 
-class _LoRALinear(Function):
-    """y = x W^T + b + s * (x D^T) U^T (+ residual).  Gradients: x, residual, D (down), U (up) — the last two in
-    fp32 straight out of the GEMM epilogue (training_utils/pipeline.py:123-144 keeps LoRA params in fp32)."""
+class _LoRAGroupLinear(Function):
+    """(y_1 .. y_G) with y_i = x W_i^T + b_i + (h_i) U_i^T (+ residual),  h = s * x [D_1; ..; D_G]^T.
+    Forward: one GEMM for h, then ONE K-segmented GEMM per projection ([x | h_i] . [W_i | U_i]^T).
+    Backward: u_i = s * g_i U_i (G small GEMMs into one [M, G*r] buffer), dx = sum_i g_i W_i + u [D_1; ..; D_G] as
+    ONE K-segmented GEMM, and the LoRA weight gradients in fp32 straight out of the GEMM epilogue, accumulated in
+    place into the flat gradient buffer (training_utils/pipeline.py:123-144 keeps LoRA params in fp32) on the side
+    stream: dU_i += g_i^T h_i, d[D_1; ..; D_G] += u^T x (one GEMM)."""
 
     @staticmethod
-    def forward(ctx, x, residual, down, up, lin, lora):
+    def forward(ctx, x, residual, grp, lins, down_cat, *ups):
         x = _c(x)
         M, Kd = x.shape
-        N = lin.out_features
-        dc, uc = lora.compute_copies()
-        r = dc.shape[0]
+        G, r = grp.size, grp.rank
+        Gr = G * r
+        dc, ucs, dct = grp.compute_copies()
         k = kernels()
-        h = x.new_empty((M, r))
-        k.gemm(x, dc, h, M, r, Kd, Kd, Kd, r)
-        y = x.new_empty((M, N))
+        h = x.new_empty((M, Gr))
+        k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
         if residual is not None:
+            assert G == 1
             residual = _c(residual)
-        k.gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
-               beta=1.0 if residual is not None else 0.0)
-        k.gemm(h, uc, y, M, N, r, r, r, N, R=y, ldr=N, alpha=lora.scale, beta=1.0)
-        ctx.save_for_backward(x, h, dc, uc)
-        ctx.lin, ctx.scale, ctx.lora = lin, lora.scale, lora
+        ys = []
+        for i, lin in enumerate(lins):
+            N = lin.out_features
+            y = x.new_empty((M, N))
+            k.gemm_segments([(x, lin.w, Kd, Kd, Kd), (h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r)], y, M, N, N,
+                            bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
+            ys.append(y)
+        ctx.save_for_backward(x, h, dct, *ucs)
+        ctx.grp, ctx.lins = grp, lins
         ctx.has_res = residual is not None
-        assert lora.down.grad is not None and lora.up.grad is not None, "LoRA factors need preallocated .grad views"
-        return y
+        assert down_cat.grad is not None and all(u.grad is not None for u in ups), \
+            "LoRA factors need preallocated .grad views"
+        return tuple(ys)
 
     @staticmethod
-    def backward(ctx, g):
-        g = _c(g)
-        x, h, dc, uc = ctx.saved_tensors
+    def backward(ctx, *gs):
+        x, h, dct, *ucs = ctx.saved_tensors
+        grp, lins = ctx.grp, ctx.lins
         M, Kd = x.shape
-        N = ctx.lin.out_features
-        r = dc.shape[0]
-        s = ctx.scale
+        G, r = grp.size, grp.rank
+        Gr = G * r
         k = kernels()
-        # dh = s * g U            (B = U stored [N(k), r(n)] -> k-major)
-        dh = g.new_empty((M, r))
-        k.gemm(g, uc, dh, M, r, N, N, r, r, transB=True, alpha=s)
-        d_up = d_down = dx = None
-        # LoRA weight gradients are ACCUMULATED by the GEMM epilogue straight into the flat fp32 gradient buffer
-        # (lora.up.grad / lora.down.grad are views of it), so autograd returns None for them: no temporary, no
-        # separate accumulate kernel per factor and per UNet call.
-        lora = ctx.lora
+        gs = [_c(g) if g is not None else x.new_zeros((M, lin.out_features)) for g, lin in zip(gs, lins)]
+        u = x.new_empty((M, Gr))
+        for i, lin in enumerate(lins):  # u_i = s * g_i U_i   (U_i stored [N(k), r(n)] -> k-major B operand)
+            N = lin.out_features
+            k.gemm(gs[i], ucs[i], u[:, i * r:(i + 1) * r], M, r, N, N, r, Gr, transB=True, alpha=grp.scale)
+        want_down = ctx.needs_input_grad[4]
+        want_ups = ctx.needs_input_grad[5:]
 
         def weight_grads():
-            if ctx.needs_input_grad[3]:  # dU [N, r] += s * g^T h
-                gu = lora.up.grad
-                k.gemm(g, h, gu, N, r, M, N, r, r, transA=True, transB=True, alpha=s, R=gu, ldr=r, beta=1.0)
-            if ctx.needs_input_grad[2]:  # dD [r, K] += dh^T x
-                gd = lora.down.grad
-                k.gemm(dh, x, gd, r, Kd, M, r, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
+            for i, lin in enumerate(lins):
+                if want_ups[i]:  # dU_i [N, r] += g_i^T h_i
+                    N, gu = lin.out_features, grp.ups[i].grad
+                    k.gemm(gs[i], h[:, i * r:(i + 1) * r], gu, N, r, M, N, Gr, r, transA=True, transB=True, R=gu,
+                           ldr=r, beta=1.0)
+            if want_down:  # d[D_1; ..; D_G] [G*r, K] += u^T x
+                gd = grp.down_cat.grad
+                k.gemm(u, x, gd, Gr, Kd, M, Gr, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
 
-        side = _side_stream(g.device)
-        if side is None:
-            weight_grads()
-        else:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
+        if want_down or any(want_ups):
+            side = _side_stream(x.device)
+            if side is None:
                 weight_grads()
-            _side_keep.append((g, h, dh, x))  # keep the operands alive until join_side_streams()
-            _queue_join()
+            else:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    weight_grads()
+                _side_keep.append((gs, h, u, x))  # keep the operands alive until join_side_streams()
+                _queue_join()
+        dx = None
         if ctx.needs_input_grad[0]:
-            dx = g.new_empty((M, Kd))
-            k.gemm(g, ctx.lin.wt, dx, M, Kd, N, N, N, Kd)
-            k.gemm(dh, dc, dx, M, Kd, r, r, Kd, Kd, transB=True, R=dx, ldr=Kd, beta=1.0)
-        return dx, (g if ctx.has_res else None), d_down, d_up, None, None
+            dx = x.new_empty((M, Kd))
+            segs = [(gs[i], lin.wt, lin.out_features, lin.out_features, lin.out_features)
+                    for i, lin in enumerate(lins)]
+            segs.append((u, dct, Gr, Gr, Gr))
+            k.gemm_segments(segs, dx, M, Kd, Kd)
+        return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
 
 
-def lora_linear(x, lin: FrozenLinear, lora: LoRAPair | None, residual=None):
-    if lora is None:
-        return linear(x, lin, residual)
-    return _LoRALinear.apply(x, residual, lora.down, lora.up, lin, lora)
+def lora_group_linear(x, lins, grp: LoRAGroup | None, residual=None):
+    """(x W_i^T + b_i + lora_i(x)) for the projections `lins` that share the input x; a tuple of len(lins)."""
+    if grp is None:
+        assert residual is None or len(lins) == 1
+        return tuple(linear(x, lin, residual) for lin in lins)
+    return _LoRAGroupLinear.apply(x, residual, grp, tuple(lins), grp.down_cat, *grp.ups)
+
+
+def lora_linear(x, lin: FrozenLinear, grp: LoRAGroup | None, residual=None):
+    return lora_group_linear(x, (lin,), grp, residual)[0]
 
 
 class _Conv(Function):

@@ -127,6 +127,7 @@ class TrainableSDPipeline:
         tmin = min(training_timesteps) if training_timesteps else 0
         places = sorted({s.split("_")[0] for s in train_layer_ls})
         self.attn_dict = {}
+        kv_cache = {}  # text key / value projections shared by the denoise steps of this call (see UNet.__call__)
         for i, t in enumerate(timesteps):
             train = i in training_timesteps
             with torch.set_grad_enabled(len(training_timesteps) == 0 or i > tmin):
@@ -141,7 +142,8 @@ class TrainableSDPipeline:
                         and not torch.cuda.is_current_stream_capturing()):
                     eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
                 else:
-                    eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added)
+                    eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added,
+                                           kv_cache=kv_cache)
                 if cap:
                     cond = {p: [m[bs:] for m in lst] for p, lst in maps.items()}
                     self.attn_dict[str(int(t))] = regroup_maps(cond, reses=attn_reses)

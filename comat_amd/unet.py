@@ -34,74 +34,31 @@ def timestep_embedding(t, dim, batch, max_period=10000.0):
     return torch.from_numpy(np.tile(emb[None], (batch, 1)))
 
 
-class LoRABank:
-    """All trainable LoRA factors of one UNet in ONE flat fp32 buffer (+ one flat gradient buffer): each factor is
-    a leaf view whose .grad is a view of the flat gradient, so autograd accumulates straight into the buffer that
-    RCCL all-reduces and the fused AdamW kernel consumes (training_utils/pipeline.py:123-144 collects the same
-    parameters in the same order: q, k, v, out per attention)."""
+# projections of one Attention that read the same input: (group key, members)
+ATTN1_GROUPS = (("qkv", ("to_q", "to_k", "to_v")), ("out", ("to_out.0",)))           # self-attention
+ATTN2_GROUPS = (("q", ("to_q",)), ("kv", ("to_k", "to_v")), ("out", ("to_out.0",)))  # cross-attention
+
+
+def attention_groups(path):
+    return ATTN1_GROUPS if path.endswith("attn1") else ATTN2_GROUPS
+
+
+class LoRABank(ops.LoRAStore):
+    """The LoRA factors of one UNet (training_utils/pipeline.py:84-144: rank-r LoRALinearLayers on to_q / to_k / to_v
+    / to_out.0 of every Attention; the same parameter set, keyed by the same names) in the flat-buffer store of
+    ops.LoRAStore.  Projections that read the same activation form one group (see ops.LoRAGroup); `self.group[(path,
+    key)]` with key in {"qkv", "out"} (attn1) or {"q", "kv", "out"} (attn2)."""
 
     def __init__(self, cfg: UNetConfig, lora_sd: dict, dtype, device):
-        self.names = []
-        sizes = []
+        spec, keys = [], []
         for path, _, _, _ in attention_names(cfg):
-            for proj in ("to_q", "to_k", "to_v", "to_out.0"):
-                for part in ("down", "up"):
-                    n = f"{path}.{proj}.lora.{part}.weight"
-                    self.names.append(n)
-                    sizes.append(tuple(lora_sd[n].shape))
-        total = sum(a * b for a, b in sizes)
-        self.flat = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
-        self.params = {}
-        off = 0
-        self.flat.copy_(torch.cat([lora_sd[n].reshape(-1).float() for n in self.names]).to(device))
-        for n, shp in zip(self.names, sizes):
-            num = shp[0] * shp[1]
-            p = self.flat[off:off + num].view(shp).requires_grad_(True)
-            p.grad = self.flat_grad[off:off + num].view(shp)
-            self.params[n] = p
-            off += num
-        # ONE compute-dtype copy of the whole flat buffer, refreshed by one cast kernel per optimizer step
-        self.dtype = dtype
-        self.flat_c = None if dtype == torch.float32 else torch.empty(total, dtype=dtype, device=device)
-        self._fresh = False
-        offs = {}
-        off = 0
-        for n, shp in zip(self.names, sizes):
-            offs[n] = (off, shp)
-            off += shp[0] * shp[1]
-        self.pairs = {}
-        for path, _, _, _ in attention_names(cfg):
-            for proj in ("to_q", "to_k", "to_v", "to_out.0"):
-                base = f"{path}.{proj}"
-                views = None
-                if self.flat_c is not None:
-                    (od, sd), (ou, su) = offs[base + ".lora.down.weight"], offs[base + ".lora.up.weight"]
-                    views = (self.flat_c[od:od + sd[0] * sd[1]].view(sd), self.flat_c[ou:ou + su[0] * su[1]].view(su))
-                self.pairs[base] = ops.LoRAPair(self.params[base + ".lora.down.weight"],
-                                                self.params[base + ".lora.up.weight"], dtype, bank=self, views=views)
-
-    def ensure_compute_copy(self):
-        if not self._fresh and self.flat_c is not None:
-            ops.kernels().unary(ops.UN_COPY, self.flat, self.flat_c, self.flat.numel())
-            self._fresh = True
-
-    def zero_grad(self):
-        self.flat_grad.zero_()
-        for n, p in self.params.items():  # keep the views bound (autograd then accumulates in place)
-            if p.grad is None or p.grad.data_ptr() == 0:
-                raise RuntimeError("LoRA .grad view was dropped")
-
-    def mark_updated(self):
-        """call after an in-place update of `flat` by the optimizer kernel: drops the cached compute-dtype copies."""
-        self._fresh = False
-
-    def set_requires_grad(self, flag: bool):
-        for p in self.params.values():
-            p.requires_grad_(flag)
-
-    def state_dict(self):
-        return {n: p.detach().clone() for n, p in self.params.items()}
+            for key, projs in attention_groups(path):
+                spec.append([(f"{path}.{p}.lora.down.weight", f"{path}.{p}.lora.up.weight",
+                              lora_sd[f"{path}.{p}.lora.down.weight"], lora_sd[f"{path}.{p}.lora.up.weight"])
+                             for p in projs])
+                keys.append((path, key))
+        super().__init__(spec, dtype, device)
+        self.group = dict(zip(keys, self.groups))
 
 
 class _Mods:
@@ -165,19 +122,32 @@ class CrossAttnBlock:
             b = f"{name}.transformer_blocks.{k}"
             att = {}
             for a in ("attn1", "attn2"):
-                for p in ("to_q", "to_k", "to_v", "to_out.0"):
-                    key = f"{b}.{a}.{p}"
-                    att[(a, p)] = (m.lin(key), lora.pairs[key] if lora is not None else None)
+                for key, projs in attention_groups(a):
+                    att[(a, key)] = ([m.lin(f"{b}.{a}.{p}") for p in projs],
+                                     lora.group[(f"{b}.{a}", key)] if lora is not None else None)
             self.layers.append(dict(ln=[m.norm(f"{b}.norm{i}") for i in (1, 2, 3)], att=att,
                                     ff1=m.lin(f"{b}.ff.net.0.proj"), ff2=m.lin(f"{b}.ff.net.2")))
 
-    def _attn(self, att, a, x, src, B, N, L, need_probs):
-        q = ops.lora_linear(x, *att[(a, "to_q")])
-        k = ops.lora_linear(src, *att[(a, "to_k")])
-        v = ops.lora_linear(src, *att[(a, "to_v")])
+    def _self_attn(self, att, x, B, N):
+        q, k, v = ops.lora_group_linear(x, *att[("attn1", "qkv")])
+        return ops.attention(q, k, v, B, N, N, self.heads, q.shape[1] // self.heads, need_probs=False)[0]
+
+    def _cross_attn(self, att, x, ctx, B, N, L, need_probs, kv_cache):
+        (q,) = ops.lora_group_linear(x, *att[("attn2", "q")])
+        if kv_cache is None:
+            k, v = ops.lora_group_linear(ctx, *att[("attn2", "kv")])
+        else:
+            # the text keys / values depend on the context and the LoRA factors only: within one sampler call (one
+            # optimisation step) every denoise step shares them, and autograd sums their gradients before ONE
+            # backward through the projection
+            key = (id(att), ctx.data_ptr(), tuple(ctx.shape), torch.is_grad_enabled())
+            kv = kv_cache.get(key)
+            if kv is None:
+                kv = kv_cache[key] = ops.lora_group_linear(ctx, *att[("attn2", "kv")])
+            k, v = kv
         return ops.attention(q, k, v, B, N, L, self.heads, q.shape[1] // self.heads, need_probs=need_probs)
 
-    def __call__(self, x, B, H, W, ctx, L, want_probs):
+    def __call__(self, x, B, H, W, ctx, L, want_probs, kv_cache=None):
         """returns (tokens, [cross-attention probabilities of every transformer layer] or None)"""
         N = H * W
         h = ops.group_norm(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
@@ -186,10 +156,10 @@ class CrossAttnBlock:
         for Lr in self.layers:
             att, ln = Lr["att"], Lr["ln"]
             y = ops.layer_norm(h, *ln[0])
-            o, _ = self._attn(att, "attn1", y, y, B, N, N, False)
-            h = ops.lora_linear(o, *att[("attn1", "to_out.0")], residual=h)
-            o, probs = self._attn(att, "attn2", ops.layer_norm(h, *ln[1]), ctx, B, N, L, want_probs)
-            h = ops.lora_linear(o, *att[("attn2", "to_out.0")], residual=h)
+            o = self._self_attn(att, y, B, N)
+            h = ops.lora_group_linear(o, *att[("attn1", "out")], residual=h)[0]
+            o, probs = self._cross_attn(att, ops.layer_norm(h, *ln[1]), ctx, B, N, L, want_probs, kv_cache)
+            h = ops.lora_group_linear(o, *att[("attn2", "out")], residual=h)[0]
             f = ops.geglu(ops.linear(ops.layer_norm(h, *ln[2]), Lr["ff1"]))
             h = ops.linear(f, Lr["ff2"], residual=h)
             if want_probs:
@@ -253,10 +223,12 @@ class UNet:
             emb = ops.linear(te, self.t2, residual=aug)
             return {"silu_temb": ops.silu(emb)}
 
-    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=(), added=None):
+    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=(), added=None, kv_cache=None):
         """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
         maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}.
-        SDXL: added = (text_embeds [B, pooled], time_ids [B, 6])."""
+        SDXL: added = (text_embeds [B, pooled], time_ids [B, 6]).
+        kv_cache: a dict owned by the caller for ONE sampler invocation (LoRA factors and `ctx` must not change while
+        it lives): the cross-attention key / value projections of `ctx` are computed once and shared by its calls."""
         cfg = self.cfg
         temb_act = self._time_embedding(t, B, added)
         maps = {p: [] for p in capture_places}
@@ -267,7 +239,7 @@ class UNet:
             for j, r in enumerate(res):
                 h = r(h, B, hh, ww, temb_act)
                 if att is not None:
-                    h, p = att[j](h, B, hh, ww, ctx, L, "down" in maps)
+                    h, p = att[j](h, B, hh, ww, ctx, L, "down" in maps, kv_cache)
                     if p is not None:
                         maps["down"].extend(p)
                 skips.append(h)
@@ -276,7 +248,7 @@ class UNet:
                 hh, ww = ops.conv_out_hw(ds, hh, ww)
                 skips.append(h)
         h = self.mid[0](h, B, hh, ww, temb_act)
-        h, p = self.mid[1](h, B, hh, ww, ctx, L, "mid" in maps)
+        h, p = self.mid[1](h, B, hh, ww, ctx, L, "mid" in maps, kv_cache)
         if p is not None:
             maps["mid"].extend(p)
         h = self.mid[2](h, B, hh, ww, temb_act)
@@ -285,7 +257,7 @@ class UNet:
                 h = ops.concat_cols(h, skips.pop())
                 h = r(h, B, hh, ww, temb_act)
                 if att is not None:
-                    h, p = att[j](h, B, hh, ww, ctx, L, "up" in maps)
+                    h, p = att[j](h, B, hh, ww, ctx, L, "up" in maps, kv_cache)
                     if p is not None:
                         maps["up"].extend(p)
             if us is not None:

@@ -64,6 +64,18 @@ typedef struct {
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 
+/* K-segmented GEMM:  C = act(alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + bias2) + beta * R   (1 <= nseg <= 8).
+ * Every A_s / B_s is k-contiguous (row-major [rows, K_s] with leading dimension lda / ldb); M, N, the dtypes, the
+ * epilogue and the workspace come from `p` (its A, B, K, lda, ldb, trans*, batch* fields are ignored / must be 0).
+ * One launch replaces the chains  y = x W^T + b;  y += (x D^T) U^T  (LoRALinearLayer added to a frozen nn.Linear,
+ * training_utils/pipeline.py:95-115) and  dx = sum_i g_i W_i + u D  (the data-gradient of q/k/v projections that
+ * share one input plus their low-rank branches). */
+typedef struct {
+    const void* A; const void* B;
+    int64_t K, lda, ldb;
+} comat_gemm_segment;
+int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int32_t nseg, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * conv2d as implicit GEMM on channels-last tensors.
  *   X: [B, Hin, Win, Cin], W: [Cout, KH, KW, Cin] (K-contiguous), Y: [B, Hout, Wout, Cout].
@@ -161,6 +173,12 @@ int comat_add_rowvec(const void* x, const void* v, void* out, int64_t rows, int6
                      void* stream);
 /* 2x2 sum pooling [B, 2H, 2W, C] -> [B, H, W, C]: adjoint of the nearest-2x upsample fused in comat_conv2d. */
 int comat_sumpool2x2(const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+/* Batched transpose + cast of many small fp32 matrices in ONE launch (the per-optimizer-step refresh of the
+ * transposed compute-dtype copies of the LoRA down factors, which lets every LoRA data-gradient run k-contiguous).
+ * tiles: device int64 [n_tiles, 6] = (src_off, dst_off, rows, cols, r0, c0) per 32x32 tile;
+ * dst[dst_off + c*rows + r] = cast(src[src_off + r*cols + c]). */
+int comat_transpose_cast_tiles(const float* src, void* dst, const int64_t* tiles, int64_t n_tiles, int32_t out_dtype,
+                               void* stream);
 /* NCHW <-> NHWC permutation of small boundary tensors (latents, images). to_nhwc != 0: [B,C,H,W] -> [B,H,W,C]. */
 int comat_permute_nchw_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t to_nhwc,
                             int32_t x_dtype, int32_t y_dtype, void* stream);

@@ -48,6 +48,24 @@ class SimKernels:
             acc = acc + beta * _v(R, (b1, b2, M, N), (sR[0], sR[1], ldr, 1)).float()
         _v(Cout, (b1, b2, M, N), (sC[0], sC[1], ldc, 1)).copy_(acc.to(Cout.dtype))
 
+    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0):
+        acc = torch.zeros((M, N), dtype=torch.float32)
+        for A, B, K, lda, ldb in segs:
+            acc = acc + _v(A, (M, K), (lda, 1)).float() @ _v(B, (N, K), (ldb, 1)).float().t()
+        acc = alpha * acc
+        if bias is not None:
+            acc = acc + bias.float()
+        if R is not None:
+            acc = acc + beta * _v(R, (M, N), (ldr, 1)).float()
+        _v(Cout, (M, N), (ldc, 1)).copy_(acc.to(Cout.dtype))
+
+    def transpose_cast_tiles(self, src, dst, tiles):
+        sf, df = src.reshape(-1), dst.reshape(-1)
+        for so, do, rows, cols, r0, c0 in tiles.tolist():
+            r1, c1 = min(r0 + 32, rows), min(c0 + 32, cols)
+            blk = sf[so:so + rows * cols].view(rows, cols)[r0:r1, c0:c1]
+            df[do:do + rows * cols].view(cols, rows)[c0:c1, r0:r1] = blk.t().to(dst.dtype)
+
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
                bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):
         x = _v(X, (B, Hin, Win, Cin), (Hin * Win * Cin, Win * Cin, Cin, 1)).float().permute(0, 3, 1, 2)

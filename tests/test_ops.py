@@ -241,36 +241,114 @@ def test_flash_attention(dev, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_lora_linear(dev, dtype):
-    M, K, N, r = 130, 64, 96, 8
+@pytest.mark.parametrize("shape", [(130, 64, 8), (70, 40, 4), (257, 96, 16)])
+def test_gemm_segments(dev, dtype, shape):
+    """K-segmented GEMM (ragged M / N / K_s, strided operands, bias + residual epilogue) against a plain matmul."""
+    M, N, r = shape
+    Ks = [72, 3 * r, 33 if dtype == torch.float32 else 40, r]
+    k = ops.kernels()
+    acc = torch.zeros(M, N)
+    segs = []
+    for i, K in enumerate(Ks):
+        lda, ldb = K + (8 if i % 2 else 0), K + (16 if i == 2 else 0)
+        A = rnd(M, lda, dtype=dtype, seed=10 + i)
+        B = rnd(N, ldb, dtype=dtype, seed=20 + i, scale=K ** -0.5)
+        acc = acc + A[:, :K] @ B[:, :K].t()
+        segs.append((dv(A, dev, dtype), dv(B, dev, dtype), K, lda, ldb))
+    bias, R = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    for ns in (1, 2, 4):
+        ref = 0.5 * sum(((s[0].float().cpu()[:, :s[2]] @ s[1].float().cpu()[:, :s[2]].t()) for s in segs[:ns]),
+                        torch.zeros(M, N)) + bias + 2.0 * R
+        out = torch.empty((M, N), dtype=dtype, device=dev)
+        k.gemm_segments(segs[:ns], out, M, N, N, bias=dv(bias, dev), R=dv(R, dev, dtype), ldr=N, alpha=0.5, beta=2.0)
+        check(out, ref, dtype, f"gemm_segments nseg={ns}")
+    # long K: exercises the split-K path of the segmented kernel
+    A1, B1 = rnd(64, 2048, dtype=dtype, seed=31, scale=0.3), rnd(48, 2048, dtype=dtype, seed=32, scale=0.3)
+    A2, B2 = rnd(64, 520, dtype=dtype, seed=33, scale=0.3), rnd(48, 520, dtype=dtype, seed=34, scale=0.3)
+    out = torch.empty((64, 48), dtype=torch.float32, device=dev)
+    k.gemm_segments([(dv(A1, dev, dtype), dv(B1, dev, dtype), 2048, 2048, 2048),
+                     (dv(A2, dev, dtype), dv(B2, dev, dtype), 520, 520, 520)], out, 64, 48, 48)
+    check(out, A1 @ B1.t() + A2 @ B2.t(), dtype, "gemm_segments split-K")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_cast_tiles(dev, dtype):
+    src = rnd(5000, seed=1)
+    mats = [(7, 45, 33), (1600, 64, 40), (4200, 8, 96)]  # (offset, rows, cols)
+    tiles, doff, refs = [], 0, []
+    for so, rows, cols in mats:
+        for r0 in range(0, rows, 32):
+            for c0 in range(0, cols, 32):
+                tiles.append((so, doff, rows, cols, r0, c0))
+        refs.append((doff, src[so:so + rows * cols].view(rows, cols).t().contiguous()))
+        doff += rows * cols
+    dst = torch.zeros(doff, dtype=dtype, device=dev)
+    ops.kernels().transpose_cast_tiles(dv(src, dev), dst, torch.tensor(tiles, dtype=torch.int64).to(dev))
+    for o, ref in refs:
+        assert torch.equal(dst[o:o + ref.numel()].cpu().view(ref.shape), ref.to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G", [1, 3])
+def test_lora_group_linear(dev, dtype, G):
+    """Projections sharing one input, each frozen Linear + LoRA branch (+ residual for a single projection):
+    outputs, dx, dresidual and the fp32 LoRA gradients accumulated in place into the store's flat buffer."""
+    M, K, r = 130, 64, 8
+    Ns = [96, 64, 80][:G]
     x = rnd(M, K, dtype=dtype, seed=1)
-    w = rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
-    b = rnd(N, seed=3)
-    down = rnd(r, K, seed=4, scale=r ** -0.5)
-    up = rnd(N, r, seed=5, scale=0.2)
-    res = rnd(M, N, dtype=dtype, seed=6)
-    gy = rnd(M, N, dtype=dtype, seed=7)
-    dq, uq = down.to(dtype).float(), up.to(dtype).float()  # the kernels see the compute-dtype copies
-    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
-    dr, ur = dq.clone().requires_grad_(True), uq.clone().requires_grad_(True)
-    yr = xr @ w.t() + b + (xr @ dr.t()) @ ur.t() + rr
-    yr.backward(gy)
-    lin = ops.FrozenLinear(w, b, dtype, dev)
-    dd, ud = dv(down, dev, grad=True), dv(up, dev, grad=True)
-    dd.grad, ud.grad = torch.zeros_like(dd), torch.zeros_like(ud)  # grads accumulate in place (flat-buffer views)
-    lora = ops.LoRAPair(dd, ud, dtype)
-    xd, rd = dv(x, dev, dtype, grad=True), dv(res, dev, dtype, grad=True)
-    y = ops.lora_linear(xd, lin, lora, residual=rd)
-    y.backward(dv(gy, dev, dtype))
-    check(y, yr, dtype, "lora fwd")
-    check(xd.grad, xr.grad, dtype, "lora dx")
-    check(rd.grad, rr.grad, dtype, "lora dres")
-    assert dd.grad.dtype == torch.float32 and ud.grad.dtype == torch.float32
-    check(dd.grad, dr.grad, dtype, "lora d_down", factor=2)
-    check(ud.grad, ur.grad, dtype, "lora d_up", factor=2)
+    xr = x.clone().requires_grad_(True)
+    res = rnd(M, Ns[0], dtype=dtype, seed=6) if G == 1 else None
+    rr = res.clone().requires_grad_(True) if G == 1 else None
+    spec, lins, refs, loss = [], [], [], 0
+    for i, N in enumerate(Ns):
+        w = rnd(N, K, dtype=dtype, seed=20 + i, scale=K ** -0.5)
+        b = rnd(N, seed=30 + i)
+        down, up = rnd(r, K, seed=40 + i, scale=r ** -0.5), rnd(N, r, seed=50 + i, scale=0.2)
+        gy = rnd(M, N, dtype=dtype, seed=60 + i)
+        dr = down.to(dtype).float().clone().requires_grad_(True)  # the kernels see the compute-dtype copies
+        ur = up.to(dtype).float().clone().requires_grad_(True)
+        yr = xr @ w.t() + b + (xr @ dr.t()) @ ur.t() + (rr if G == 1 else 0)
+        loss = loss + (yr * gy).sum()
+        refs.append((yr, dr, ur, gy))
+        spec.append((f"p{i}.down", f"p{i}.up", down, up))
+        lins.append(ops.FrozenLinear(w, b, dtype, dev))
+    loss.backward()
+    store = ops.LoRAStore([spec], dtype, dev)
+    assert store.names == [f"p{i}.down" for i in range(G)] + [f"p{i}.up" for i in range(G)]
+    xd = dv(x, dev, dtype, grad=True)
+    rd = dv(res, dev, dtype, grad=True) if G == 1 else None
+    for rep in range(2):  # second pass: gradients ACCUMULATE in the flat buffer
+        ys = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
+        sum((y.float() * dv(gy, dev, dtype).float()).sum() for y, (_, _, _, gy) in zip(ys, refs)).backward()
+    for i, (y, (yr, dr, ur, _)) in enumerate(zip(ys, refs)):
+        check(y, yr, dtype, f"lora group y{i}")
+        gd, gu = store.params[f"p{i}.down"].grad, store.params[f"p{i}.up"].grad
+        assert gd.dtype == torch.float32 and gu.dtype == torch.float32
+        check(gd, 2 * dr.grad, dtype, f"lora d_down{i}", factor=2)
+        check(gu, 2 * ur.grad, dtype, f"lora d_up{i}", factor=2)
+    check(xd.grad, 2 * xr.grad, dtype, "lora group dx", factor=2)
+    if G == 1:
+        check(rd.grad, 2 * rr.grad, dtype, "lora dres")
+    # frozen factors (the generator-side pass through the discriminator): dx only, gradient buffer untouched
+    store.zero_grad()
+    store.set_requires_grad(False)
+    xd2 = dv(x, dev, dtype, grad=True)
+    ys = ops.lora_group_linear(xd2, lins, store.groups[0])
+    sum((y.float() * dv(gy, dev, dtype).float()).sum() for y, (_, _, _, gy) in zip(ys, refs)).backward()
+    ref_dx = xr.grad - (rr.grad.sum() * 0 if G == 1 else 0)
+    check(xd2.grad, ref_dx, dtype, "lora group dx (frozen factors)", factor=2)
+    assert float(store.flat_grad.abs().max()) == 0.0
+    # updated parameters are picked up after mark_updated()
+    store.flat.mul_(0.5)
+    store.mark_updated()
+    y0 = ops.lora_group_linear(xd2.detach(), lins, store.groups[0])[0]
+    (yr, dr, ur, _) = refs[0]
+    half = x @ lins[0].w.float().cpu().t() + lins[0].bias.cpu() + (x @ (0.5 * dr.detach()).to(dtype).float().t()) @ \
+        (0.5 * ur.detach()).to(dtype).float().t()
+    check(y0, half, dtype, "lora group after update", factor=2)
     # plain frozen linear, with and without input grad
-    y2 = ops.linear(xd.detach(), lin, act=ops.ACT_GELU)
-    check(y2, F.gelu(x @ w.t() + b), dtype, "linear+gelu")
+    y2 = ops.linear(xd.detach(), lins[0], act=ops.ACT_GELU)
+    check(y2, F.gelu(x @ lins[0].w.float().cpu().t() + lins[0].bias.cpu()), dtype, "linear+gelu")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
