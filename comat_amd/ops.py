@@ -199,7 +199,7 @@ class LoRAStore:
     def zero_grad(self):
         self.flat_grad.zero_()
         for p in self._leaves:  # keep the views bound (the GEMM epilogues accumulate into them in place)
-            if p.grad is None or p.grad.data_ptr() == 0:
+            if p.grad is None:
                 raise RuntimeError("LoRA .grad view was dropped")
 
     def set_requires_grad(self, flag: bool):

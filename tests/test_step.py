@@ -103,11 +103,12 @@ def test_train_step_matches_oracle(dev, dtype, attrcon):
     assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
     hg = torch.cat([ref["head_grads"][0].reshape(-1), ref["head_grads"][1].reshape(-1)])
     assert rel_l2(trainer.D.head_grad, hg) < lim * 3
-    # parameters after clip + AdamW (the update is sign-like at step 1: compare the update direction/size)
+    # parameters after clip + AdamW.  The first Adam update is sign-like (lr * g / (|g| + eps)): elements whose
+    # gradient is ~0 amplify summation-order differences, hence 3e-4 rather than the 1e-3-of-gradient bound / 10
     p_ref = torch.cat([W["lora"][n].detach().reshape(-1) for n in bank.names])
-    assert rel_l2(bank.flat, p_ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(bank.flat, p_ref) < (3e-4 if dtype == torch.float32 else 2e-2)
     pd_ref = torch.cat([W["d_lora"][n].detach().reshape(-1) for n in dbank.names])
-    assert rel_l2(dbank.flat, pd_ref) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_l2(dbank.flat, pd_ref) < (3e-4 if dtype == torch.float32 else 2e-2)
 
 
 def test_second_step_uses_updated_lora(sim):
