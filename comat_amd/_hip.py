@@ -68,7 +68,7 @@ SIGNATURES = {
     "comat_softmax_bwd": [_vp, _vp, _vp, _i64, _i32, _f, _i32, _i32, _i32, _vp],
     "comat_flash_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f, _i32, _vp],
     "comat_flash_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64,
-                             _i64, _i64, _f, _i32, _vp],
+                             _i64, _i64, _f, _i32, _vp, _i64, _vp],
     "comat_unary": [_i32, _vp, _vp, _i64, _f, _f, _i32, _i32, _vp],
     "comat_unary_bwd": [_i32, _vp, _vp, _vp, _i64, _i32, _vp],
     "comat_axpby": [_f, _vp, _f, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -268,9 +268,10 @@ class HipKernels:
                                          ldo, scale, dt(q), _stream()), "comat_flash_attn_fwd")
 
     def flash_attn_bwd(self, q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+        ws = self._workspace(q.device)
         _check(_lib.comat_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(dbuf), _ptr(dq),
                                          _ptr(dk), _ptr(dv), B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale, dt(q),
-                                         _stream()), "comat_flash_attn_bwd")
+                                         ws.data_ptr(), self.WS_BYTES, _stream()), "comat_flash_attn_bwd")
 
     # ---- elementwise ---------------------------------------------------------------------------------------
     def unary(self, op, x, y, n, p0=0.0, p1=0.0):

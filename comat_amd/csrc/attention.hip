@@ -139,6 +139,8 @@ struct FlashArgs {
     int B, H, Nq, Nk, d;
     int64_t ldq, ldk, ldv, ldo;
     float scale;
+    int qsplit;    // dK/dV: number of query ranges (blockIdx.z) whose fp32 partials are summed by flash_kv_reduce
+    float* part;   // [2][qsplit][B*H][Nk][d] fp32 partial dK / dV (qsplit > 1)
 };
 
 template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
@@ -356,12 +358,17 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv
     const float* lse_g = a.lse + (int64_t)blockIdx.y * a.Nq;
     const float* D_g = a.Dbuf + (int64_t)blockIdx.y * a.Nq;
     TileMover<T, DMAX> qm, gm;
-    const int ntiles = (a.Nq + 31) / 32;
+    // query-tile range of this block: few keys (cross-attention: 77) leave one block per (batch, head), so the
+    // query loop is cut into gridDim.z ranges whose partial sums a fixed-order reduce kernel adds up
+    const int ntq = (a.Nq + 31) / 32;
+    const int per = (ntq + a.qsplit - 1) / a.qsplit;
+    const int tbeg = (int)blockIdx.z * per;
+    const int ntiles = tbeg + per < ntq ? tbeg + per : ntq;
     float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31
-    qm.load(Qb, a.ldq, 0, a.Nq, a.d);
-    gm.load(Gb, a.ldo, 0, a.Nq, a.d);
+    qm.load(Qb, a.ldq, tbeg * 32, a.Nq, a.d);
+    gm.load(Gb, a.ldo, tbeg * 32, a.Nq, a.d);
     if (threadIdx.x < 32) {
-        const int qi = threadIdx.x;
+        const int qi = tbeg * 32 + threadIdx.x;
         lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
         D_r = qi < a.Nq ? D_g[qi] : 0.f;
     }
@@ -369,7 +376,7 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv
     gm.store(Gt);
     if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = tbeg; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
         if (more) {
             qm.load(Qb, a.ldq, (t + 1) * 32, a.Nq, a.d);
@@ -415,17 +422,45 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv
         }
     }
     if (key < a.Nk) {
+        const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
+        float* pk = a.qsplit > 1
+                        ? a.part + ((int64_t)blockIdx.z * a.B * a.H + blockIdx.y) * a.Nk * a.d + (int64_t)key * a.d
+                        : nullptr;
+        float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
 #pragma unroll
         for (int t2 = 0; t2 < G::NT32; ++t2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) {
-                    stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
-                    stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
+                    if (a.qsplit > 1) {
+                        pk[n] = dkT[t2][i];
+                        pv[n] = dvT[t2][i];
+                    } else {
+                        stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
+                        stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
+                    }
                 }
             }
     }
+}
+
+// dK / dV = sum over the query ranges of the fp32 partials, in range order (bit-reproducible)
+template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kernel(FlashArgs a) {
+    const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= slab) return;
+    const int n = (int)(i % a.d);
+    const int key = (int)((i / a.d) % a.Nk);
+    const int bh = (int)(i / ((int64_t)a.d * a.Nk));
+    const int b = bh / a.H, h = bh % a.H;
+    float sk = 0.f, sv = 0.f;
+    for (int z = 0; z < a.qsplit; ++z) {
+        sk += a.part[(int64_t)z * slab + i];
+        sv += a.part[((int64_t)a.qsplit + z) * slab + i];
+    }
+    stf<T>((T*)a.dK + ((int64_t)b * a.Nk + key) * a.ldk + h * a.d + n, sk);
+    stf<T>((T*)a.dV + ((int64_t)b * a.Nk + key) * a.ldv + h * a.d + n, sv);
 }
 
 template <typename T, int DMAX> void launch_fwd(const FlashArgs& a, hipStream_t st) {
@@ -435,7 +470,11 @@ template <typename T, int DMAX> void launch_bwd(const FlashArgs& a, hipStream_t 
     const int64_t total = (int64_t)a.B * a.H * a.Nq;
     hipLaunchKernelGGL((flash_prep_kernel<T>), dim3((unsigned)cdiv64(total, NT)), dim3(NT), 0, st, a);
     hipLaunchKernelGGL((flash_dq_kernel<T, DMAX>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX>), dim3((a.Nk + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    if (a.qsplit > 1) {
+        const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
+        hipLaunchKernelGGL((flash_kv_reduce_kernel<T>), dim3((unsigned)cdiv64(slab, NT)), dim3(NT), 0, st, a);
+    }
 }
 
 template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
@@ -485,7 +524,8 @@ extern "C" int comat_flash_attn_fwd(const void* Q, const void* K, const void* V,
 extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                                     const float* lse, float* Dbuf, void* dQ, void* dK, void* dV, int32_t B, int32_t H,
                                     int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv,
-                                    int64_t ldo, float scale, int32_t dtype, void* stream) {
+                                    int64_t ldo, float scale, int32_t dtype, float* ws, int64_t ws_bytes,
+                                    void* stream) {
     if (int rc = check_args("comat_flash_attn_bwd", Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
     COMAT_REQUIRE(O && dO && lse && Dbuf && dQ && dK && dV, "comat_flash_attn_bwd: null pointer");
     COMAT_REQUIRE((((uintptr_t)dO | (uintptr_t)O) & 15) == 0, "comat_flash_attn_bwd: O and dO must be 16-byte aligned");
@@ -494,6 +534,18 @@ extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V,
     a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    // few key blocks (cross-attention): cut the query loop into ranges so that the grid fills the chip
+    a.qsplit = 1;
+    a.part = ws;
+    const int64_t base_blocks = (int64_t)((Nk + 127) / 128) * B * H, ntq = (Nq + 31) / 32;
+    if (ws && base_blocks < 256 && ntq >= 8) {
+        int64_t qs = cdiv64(512, base_blocks);
+        if (qs > ntq / 4) qs = ntq / 4;
+        const int64_t cap = ws_bytes / (2 * (int64_t)B * H * Nk * d * 4);
+        if (qs > cap) qs = cap;
+        if (qs > 64) qs = 64;
+        if (qs >= 2) a.qsplit = (int)qs;
+    }
     const int rc = dtype == COMAT_BF16 ? dispatch<bf16_t>(a, true, (hipStream_t)stream)
                                        : dispatch<float>(a, true, (hipStream_t)stream);
     COMAT_REQUIRE(rc == 0, "comat_flash_attn_bwd: unsupported head dim");

@@ -138,7 +138,9 @@ int comat_softmax_bwd(const void* P, const void* dP, void* dS, int64_t rows, int
  * (batch, head), scores never written to HBM.  Q: [B*Nq, ldq], K/V: [B*Nk, ldk/ldv], O: [B*Nq, ldo] with head h in
  * columns h*d .. (h+1)*d; lse: [B, H, Nq] fp32 log-sum-exp of the scaled scores (saved for backward).
  * Head dim d <= 160, multiple of 8 (bf16) / 4 (fp32); leading dims and base pointers 16-byte aligned.
- * bwd: Dbuf [B, H, Nq] fp32 caller workspace; dO has the layout of O; dQ/dK/dV the layouts of Q/K/V.
+ * bwd: Dbuf [B, H, Nq] fp32 caller workspace; dO has the layout of O; dQ/dK/dV the layouts of Q/K/V.  ws (optional,
+ * fp32, ws_bytes): when there are few keys (cross-attention to 77 text tokens) the dK/dV pass cuts its query loop
+ * into ranges that write fp32 partials here and are summed in fixed order (bit-reproducible); NULL: never split.
  * Replaces the materialised softmax(QK^T)V of the reference's patched Attention.forward
  * (attn_utils/tc_attn_utils.py:126-146) for self-attention (268 MB of fp16 scores per layer per sample at 64x64).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -148,7 +150,7 @@ int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, f
 int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                          const float* lse, float* Dbuf, void* dQ, void* dK, void* dV, int32_t B, int32_t H,
                          int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                         float scale, int32_t dtype, void* stream);
+                         float scale, int32_t dtype, float* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Elementwise family (HBM-bound, 16-byte vectorised).

@@ -220,6 +220,7 @@ def test_attention(dev, dtype, cfg):
     (2, 4096, 4096, 8, 40),   # SD1.5 self-attention at 64x64 latents (bf16 run is the full-size property check)
     (2, 70, 70, 2, 40), (1, 300, 77, 8, 80), (2, 64, 200, 2, 160), (1, 577, 577, 3, 64), (2, 16, 37, 2, 16),
     (1, 130, 33, 1, 32), (1, 5, 577, 2, 96),
+    (2, 1024, 77, 8, 40),     # cross-attention at 32x32 latents: dK/dV pass split over query ranges
 ])
 def test_flash_attention(dev, dtype, cfg):
     B_, Nq, Nk, H, d = cfg
