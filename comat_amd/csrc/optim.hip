@@ -30,6 +30,9 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s,
                                                    const float* __restrict__ gnorm_sq, float max_norm) {
     float clip = 1.0f;
+    // a non-finite gradient norm (overflow / NaN somewhere in backward) skips the update, like the GradScaler step
+    // of the reference's mixed-precision run (accelerate, training_script.py:661-664): parameters and moments stay
+    if (gnorm_sq && !isfinite(*gnorm_sq)) return;
     if (gnorm_sq && max_norm > 0.f) {
         const float c = max_norm / (sqrtf(*gnorm_sq) + 1e-6f);
         clip = c < 1.0f ? c : 1.0f;

@@ -106,7 +106,8 @@ class TrainableSDPipeline:
                 negative_pooled_prompt_embeds=None, add_time_ids=None):
         """prompt_embeds / negative_prompt_embeds: (bs, L, cross_dim) text-encoder outputs (the CLIP text encoder is
         a no-grad preprocessing step outside this path).  Returns image/2+0.5 as (bs,3,H,W) [output_type 'image'] or
-        as channels-last tokens ([bs*H*W,3], H, W) ['tokens'], plus the final latents when `return_latents`."""
+        as channels-last tokens ([bs*H*W,3], H, W) ['tokens'], plus the final latents when `return_latents`;
+        output_type 'latent' returns the final latents (bs,4,h,w) fp32 without decoding."""
         if early_exit or double_laststep or fast_training or not (detach_gradient and bp_on_trained):
             raise NotImplementedError("only the trainer's flag set (training_script.py:558-567) is supported")
         if guidance_scale <= 1.0:
@@ -159,6 +160,8 @@ class TrainableSDPipeline:
             cx, ce, sigma = self.scheduler.step_coefficients(int(t))
             with torch.set_grad_enabled(len(training_timesteps) == 0 or i >= tmin):
                 lat = ops.cfg_ddpm_step(lat, eps2, z, guidance_scale, cx, ce, sigma)
+        if output_type == "latent":  # TrainableSDPipeline.py:224-225: the final latents, no decode
+            return ops.tokens_to_nchw(lat, bs, h, w)
         z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), T)
         img, H, W = self.vae(z0, bs, h, w)
         if not (self.is_sdxl and return_latents):  # SDXL + return_latents returns the raw decode (:838-840)

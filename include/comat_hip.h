@@ -261,7 +261,8 @@ int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float
 /* out[0] += sum(x^2)  (caller zeroes out); ws: >= 1024 floats.  Fixed summation order: every data-parallel rank gets
  * the bit-identical norm (and clip factor) from the all-reduced gradient. */
 int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
-/* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)). */
+/* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)).  A non-finite
+ * *gnorm_sq skips the update entirely (p, m, v untouched): the inf/NaN check of a mixed-precision optimizer step. */
 int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, void* stream);
 

@@ -347,6 +347,8 @@ class SimKernels:
 
     def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
         clip = 1.0
+        if gnorm_sq is not None and not math.isfinite(float(gnorm_sq[0])):
+            return  # non-finite gradient norm: the update is skipped
         if gnorm_sq is not None and max_norm > 0:
             clip = min(1.0, max_norm / (math.sqrt(float(gnorm_sq[0])) + 1e-6))
         gg = g * clip

@@ -167,3 +167,31 @@ def test_graphed_nograd_unet_matches_eager(hip):
         bank.flat.mul_(1.01)  # an optimizer update ...
         bank.mark_updated()   # ... invalidates the compute copy; the graph must pick the new values up
     assert len(gu.graphs) == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gt_latent_producer(dev, dtype, tmp_path):
+    """SURVEY.md 8f-3 (tools/gan_gt_generate.py:171-193): no-grad CFG sampler -> final latents (output_type='latent')
+    -> fp32 .pt records + jsonl index, read back the way Gan_Dataset does."""
+    from comat_amd import gt_latents
+    usd, vsd, _ = tiny_weights(dtype)
+    ocfg, ovc = oracle_cfgs()
+    bs, h, w, L = 2, 8, 8, 7
+    cd = config.TINY_UNET.cross_attention_dim
+    lat = rnd(bs, 4, h, w, seed=10)
+    cu, cc = rnd(bs, L, cd, seed=11, dtype=dtype), rnd(bs, L, cd, seed=12, dtype=dtype)
+    noises = [rnd(bs, 4, h, w, seed=20 + i) for i in range(3)]
+    with torch.no_grad():
+        _, lat_o, _ = O.sample_with_grad(usd, ocfg, vsd, ovc, None, cu, cc, lat, noises, 3, [], 7.5)
+    pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, dev, None), VAEDecoder(config.TINY_VAE, vsd, dtype, dev))
+    out = gt_latents.generate_gt_latents(pipe, cc, cu, height=8 * h, width=8 * w, num_inference_steps=3,
+                                         guidance_scale=7.5, latents=lat, noises=noises)
+    assert out.shape == (bs, 4, h, w) and out.dtype == torch.float32 and not out.requires_grad
+    check(out, lat_o, dtype, "GT latents", factor=3)
+    index = str(tmp_path / "gt.jsonl")
+    paths = gt_latents.write_gt_records(out, ["a red cube", "two dogs"], str(tmp_path), index)
+    assert len(paths) == 2 and all(p.endswith(".pt") for p in paths)
+    lines = open(index).read().strip().split("\n")
+    rec = gt_latents.read_gt_record(lines[1])
+    assert rec["text"] == "two dogs" and rec["latents"].dtype == torch.float32 and rec["latents"].shape == (4, h, w)
+    assert torch.equal(rec["latents"], out[1].cpu())

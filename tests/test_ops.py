@@ -544,3 +544,14 @@ def test_adamw_with_clip(dev):
         check(nsq, (g.double() ** 2).sum().float().reshape(1), torch.float32, "sumsq", factor=5)
         ops.kernels().adamw(p, gd, m, v, n, 5e-3, 0.9, 0.999, 1e-8, 1e-2, step, nsq, 0.1)
     check(p, pr, torch.float32, "adamw", factor=0.5)
+    # a non-finite gradient (norm inf / NaN) skips the update: parameters and moments stay bit-identical
+    before = (p.clone(), m.clone(), v.clone())
+    for bad in (float("inf"), float("nan")):
+        gb = g0.clone()
+        gb[17] = bad
+        gd = dv(gb, dev)
+        nsq = torch.zeros(1, device=dev)
+        ops.kernels().sumsq(gd, n, nsq)
+        assert not torch.isfinite(nsq).item()
+        ops.kernels().adamw(p, gd, m, v, n, 5e-3, 0.9, 0.999, 1e-8, 1e-2, 4, nsq, 0.1)
+        assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v)))
