@@ -14,7 +14,15 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .resize import aa_taps, dense_from_taps
+from .resize import aa_taps
+
+
+def _apply_taps(x: np.ndarray, start: np.ndarray, wts: np.ndarray) -> np.ndarray:
+    """x [n, S, W] -> [n, res, W]: out[:, o] = sum_t wts[o, t] * x[:, start[o] + t]  (taps beyond the source carry
+    weight 0).  <= 17 taps per output row: a gather + small contraction, no dense [res, S] GEMM on the host."""
+    kt = wts.shape[1]
+    idx = np.minimum(start[:, None].astype(np.int64) + np.arange(kt)[None], x.shape[1] - 1)  # [res, kt]
+    return np.einsum("ok,nokw->now", wts.astype(np.float64), x[:, idx, :])
 
 
 def resize_masks(masks: np.ndarray, res: int) -> np.ndarray:
@@ -23,9 +31,9 @@ def resize_masks(masks: np.ndarray, res: int) -> np.ndarray:
     n, H, W = masks.shape
     ys, yw, _ = aa_taps(H, res, "bilinear")
     xs, xw, _ = aa_taps(W, res, "bilinear")
-    My, Mx = dense_from_taps(ys, yw, H), dense_from_taps(xs, xw, W)
-    out = np.einsum("oh,nhw,pw->nop", My, masks.astype(np.float64), Mx)
-    return (out > 0.0).astype(np.float32).reshape(n, res * res)
+    rows = _apply_taps(masks.astype(np.float64), ys, yw)                              # [n, res, W]
+    out = _apply_taps(np.ascontiguousarray(rows.transpose(0, 2, 1)), xs, xw)          # [n, res(x), res(y)]
+    return (out.transpose(0, 2, 1) > 0.0).astype(np.float32).reshape(n, res * res)
 
 
 def grounding_loss_by_layer(masks_res: torch.Tensor, word_token_idx_ls, res, attn_maps):

@@ -68,10 +68,10 @@ class TrainableSDPipeline:
         self.scheduler = scheduler or DDPMScheduler()
         self.dtype, self.device = unet.dtype, unet.device
         self.attn_dict = {}
-        # hipGraph replay for the untrained (no-grad) denoise steps; COMAT_GRAPHS=0 disables it.  Open issue (round 1):
-        # with attribute-concentration steps in the same forward, a device fault appears from the second optimisation
-        # step on when graphs are replayed (not reproduced without attrcon, nor with syncs between phases) — until it
-        # is root-caused the graphed path is only taken when no attrcon step is requested.
+        # hipGraph replay for the untrained (no-grad) denoise steps; COMAT_GRAPHS=0 disables it (COMAT_GRAPHS_ATTRCON=0
+        # only for forwards that also capture attention maps).  History: an early build raised a hardware exception
+        # in the second optimisation step when graphs and attribute-concentration steps were combined; it has not
+        # reproduced since the attention-map gather kernel was rewritten (fixed-order, no atomics) — see DESIGN.md.
         use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
                       and not unet.cfg.addition_embed)
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
@@ -139,7 +139,8 @@ class TrainableSDPipeline:
                 xin = x2 if (train and not self.is_sdxl) else x2.detach()
                 xin = ops.cast_grad(xin, T)
                 cap = places if (train and i in attrcon_train_steps) else ()
-                if (not train and self.graphed is not None and not attrcon_train_steps
+                graph_ok = not attrcon_train_steps or os.environ.get("COMAT_GRAPHS_ATTRCON", "1") != "0"
+                if (not train and self.graphed is not None and graph_ok
                         and not torch.cuda.is_current_stream_capturing()):
                     eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
                 else:
