@@ -252,14 +252,21 @@ def main():
     value = world * args.steps / dt  # one image (prompt) per rank per step
 
     roofline = None
-    if rank == 0 and not args.no_kernel_timing:
-        timed = TimedKernels(ops.kernels())
-        ops.set_kernel_backend(timed)
+    if not args.no_kernel_timing:
+        # one extra, instrumented step.  EVERY rank runs it (the step contains the gradient all-reduce: a rank-0-only
+        # step would deadlock the collective); only rank 0 brackets its kernels with events.
+        timed = None
+        if rank == 0:
+            timed = TimedKernels(ops.kernels())
+            ops.set_kernel_backend(timed)
         ops.set_side_stream_enabled(False)  # per-kernel event timing needs one stream (no overlapping kernels)
         trainer.train_step(batch, **fixed)
-        fam = timed.summary()
+        torch.cuda.synchronize()
         ops.set_side_stream_enabled(True)
-        ops.set_kernel_backend(timed.inner)
+        if rank == 0:
+            fam = timed.summary()
+            ops.set_kernel_backend(timed.inner)
+    if rank == 0 and not args.no_kernel_timing:
         tot_t = sum(v[0] for v in fam.values())
         dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
         t_dom, f_dom, n_dom = fam[dom]
