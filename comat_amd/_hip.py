@@ -36,7 +36,8 @@ class GemmParams(C.Structure):
 
 
 class GemmSegment(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64)]
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64),
+                ("sA", C.c_int64), ("sB", C.c_int64)]
 
 
 class ConvParams(C.Structure):
@@ -193,19 +194,23 @@ class HipKernels:
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_gemm(C.byref(p), _stream()), "comat_gemm")
 
-    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0):
-        """Cout[M, N] = alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + beta * R;  segs: [(A, B, K, lda, ldb), ...]"""
+    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0, batch=1, sC=0, sR=0):
+        """Cout[M, N] = alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + beta * R;  segs: [(A, B, K, lda, ldb[, sA, sB])].
+        batch > 1: that many problems in one launch; operands advance by sA / sB, Cout / R by sC / sR elements."""
         n = len(segs)
         arr = (GemmSegment * n)()
-        for i, (A, B, K, lda, ldb) in enumerate(segs):
+        for i, sg in enumerate(segs):
+            A, B, K, lda, ldb = sg[:5]
             assert A.dtype == B.dtype == segs[0][0].dtype
             arr[i].A, arr[i].B, arr[i].K, arr[i].lda, arr[i].ldb = _ptr(A), _ptr(B), K, lda, ldb
+            arr[i].sA, arr[i].sB = (sg[5], sg[6]) if len(sg) > 5 else (0, 0)
         p = GemmParams()
         p.C, p.bias, p.R = _ptr(Cout), _ptr(bias), _ptr(R)
         if bias is not None:
             assert bias.dtype == torch.float32
         p.M, p.N, p.ldc, p.ldr = M, N, ldc, ldr
-        p.batch1 = p.batch2 = 1
+        p.batch1, p.batch2 = batch, 1
+        p.sC1, p.sR1 = sC, sR
         p.alpha, p.beta = alpha, beta
         p.in_dtype, p.out_dtype = dt(segs[0][0]), dt(Cout)
         p.r_dtype = dt(R) if R is not None else 0

@@ -144,6 +144,7 @@ struct SegTable {
     const void* A[MAXSEG];
     const void* B[MAXSEG];
     int64_t lda[MAXSEG], ldb[MAXSEG];
+    int64_t sA[MAXSEG], sB[MAXSEG];  // element stride of the operand between batch items (0: shared)
     int K[MAXSEG];
     int nseg;
 };
@@ -159,6 +160,7 @@ template <typename T, int ROWS> struct SegLoader {
     int rleft[NCH];
     int lds_off[NCH];
     int K, seg, tiles_left;
+    int64_t zb;          // batch item
     bool vec_ok, is_b;
     uint4 regs[PF][NCH];
 
@@ -171,7 +173,7 @@ template <typename T, int ROWS> struct SegLoader {
 #pragma unroll
         for (int s = 0; s < MAXSEG; ++s)
             if (s == sg) {
-                P = is_b ? t.B[s] : t.A[s];
+                P = is_b ? (const void*)((const T*)t.B[s] + zb * t.sB[s]) : (const void*)((const T*)t.A[s] + zb * t.sA[s]);
                 ld = is_b ? t.ldb[s] : t.lda[s];
                 k = t.K[s];
             }
@@ -186,8 +188,10 @@ template <typename T, int ROWS> struct SegLoader {
             ptr[i] = (const T*)P + grow[i] * ld + kpos[i];
         }
     }
-    __device__ __forceinline__ void init(const SegTable& t, bool b_operand, int64_t r0, int64_t rmax, int64_t kt0) {
+    __device__ __forceinline__ void init(const SegTable& t, bool b_operand, int64_t r0, int64_t rmax, int64_t kt0,
+                                         int64_t z) {
         is_b = b_operand;
+        zb = z;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NT;
@@ -563,6 +567,7 @@ template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_boun
 struct GemmSegArgs {
     SegTable t;
     int64_t M, N, nk;
+    int64_t sC, sR, sBias;  // batch strides (elements) of C, R and bias
     int tiles_m, tiles_n, splits;
     float* ws;
     Epi ep;
@@ -572,18 +577,25 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_seg_kernel(Gemm
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
     lin /= g.splits;
-    const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
+    const int tn = (int)(lin % g.tiles_n);
+    lin /= g.tiles_n;
+    const int tm = (int)(lin % g.tiles_m);
+    const int64_t z = lin / g.tiles_m;
     const int64_t per = (g.nk + g.splits - 1) / g.splits;
     int64_t kt0 = (int64_t)sp * per;
     const int64_t kt1 = kt0 + per < g.nk ? kt0 + per : g.nk;
     if (kt0 > g.nk) kt0 = g.nk;
-    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
+    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
     const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    Epi ep = g.ep;
+    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
+    if (ep.bias) ep.bias += z * g.sBias;
     SegLoaderRef<T, 64> al, bl;
     al.t = bl.t = &g.t;
-    al.l.init(g.t, false, m0, g.M, kt0);
-    bl.l.init(g.t, true, n0, g.N, kt0);
-    gemm_block<T, 64, 64>(al, bl, kt0, kt1, m0, n0, g.M, g.N, g.ep, slab);
+    al.l.init(g.t, false, m0, g.M, kt0, z);
+    bl.l.init(g.t, true, n0, g.N, kt0, z);
+    gemm_block<T, 64, 64>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
 }
 
 // sums the split-K slabs and applies the fused epilogue: C = act(alpha*sum + bias + bias2) + beta*R
@@ -756,8 +768,10 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     COMAT_REQUIRE(p->C && p->M > 0 && p->N > 0, "comat_gemm_segments: bad output / shape");
     COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_gemm_segments: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_gemm_segments: bad residual dtype");
-    COMAT_REQUIRE(p->batch1 <= 1 && p->batch2 <= 1 && !p->transA && !p->transB,
-                  "comat_gemm_segments: operands must be k-contiguous and unbatched");
+    COMAT_REQUIRE(p->batch2 <= 1 && !p->transA && !p->transB && p->batch1 <= 65535,
+                  "comat_gemm_segments: operands must be k-contiguous; one batch level (batch1)");
+    const int64_t batch = p->batch1 > 1 ? p->batch1 : 1;
+    COMAT_REQUIRE(batch == 1 || !p->bias2, "comat_gemm_segments: bias2 is not supported with a batch");
     COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm_segments: bias2 needs rows_per_bias2");
     COMAT_REQUIRE(p->ldc >= p->N, "comat_gemm_segments: ldc too small");
     GemmSegArgs g;
@@ -771,10 +785,12 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
                           "comat_gemm_segments: leading dimension of segment %d too small", s);
             g.t.A[s] = segs[s].A; g.t.B[s] = segs[s].B;
             g.t.lda[s] = segs[s].lda; g.t.ldb[s] = segs[s].ldb; g.t.K[s] = (int)segs[s].K;
+            g.t.sA[s] = segs[s].sA; g.t.sB[s] = segs[s].sB;
             g.nk += cdiv64(segs[s].K, bke);
         } else {
             g.t.A[s] = g.t.B[s] = nullptr;
             g.t.lda[s] = g.t.ldb[s] = 0; g.t.K[s] = 0;
+            g.t.sA[s] = g.t.sB[s] = 0;
         }
     }
     g.t.nseg = nseg;
@@ -783,17 +799,21 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     g.ep.ldc = p->ldc; g.ep.ldr = p->ldr; g.ep.rows_per_b2 = p->rows_per_bias2 > 0 ? p->rows_per_bias2 : 1;
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
-    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, 1, p->ws ? p->ws_bytes : 0);
+    g.sC = p->sC1; g.sR = p->sR1; g.sBias = p->bias ? p->N : 0;  // bias: [batch, N] when batched
+    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0);
     g.tiles_m = (int)cdiv64(p->M, 64);
     g.tiles_n = (int)cdiv64(p->N, 64);
     g.splits = plan.splits;
-    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
+    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm_segments: too many tiles");
     g.ws = (float*)p->ws;
     hipStream_t st = (hipStream_t)stream;
     if (p->in_dtype == COMAT_BF16) hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
-    if (g.splits > 1) launch_reduce(g.ws, p->M, p->N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
+    if (g.splits > 1) {
+        COMAT_REQUIRE(batch == 1 || !p->bias, "comat_gemm_segments: batched split-K with bias is not supported");
+        launch_reduce(g.ws, p->M, p->N, batch, 1, p->sC1, 0, p->sR1, 0, g.splits, g.ep, st);
+    }
     return comat_check_launch("comat_gemm_segments");
 }
 

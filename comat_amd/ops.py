@@ -91,6 +91,26 @@ class FrozenLinear:
         self.out_features, self.in_features = self.w.shape
 
 
+def frozen_linear_group(weights, biases, dtype, device):
+    """FrozenLinears of projections that read the same input (same [N, K] each), allocated as ONE [G, N, K] buffer
+    (+ one [G, K, N] for the transposes): the group's forward is then a single batched launch."""
+    G = len(weights)
+    shp = tuple(weights[0].shape)
+    assert all(tuple(w.shape) == shp for w in weights)
+    w32 = torch.stack([w.to(device=device, dtype=torch.float32) for w in weights])
+    W = w32.to(dtype).contiguous()
+    Wt = w32.transpose(1, 2).contiguous().to(dtype)
+    out = []
+    for i in range(G):
+        lin = FrozenLinear.__new__(FrozenLinear)
+        lin.w, lin.wt = W[i], Wt[i]
+        b = biases[i]
+        lin.bias = None if b is None else b.to(device=device, dtype=torch.float32).contiguous()
+        lin.out_features, lin.in_features = shp
+        out.append(lin)
+    return out
+
+
 class FrozenConv:
     """A frozen conv2d.  `w` is [Cout, KH, KW, Cin]; `wd` is the tap-flipped, channel-transposed weight
     [Cin, KH, KW, Cout] that turns the data-gradient into the same implicit-GEMM gather."""
@@ -453,6 +473,23 @@ def linear(x, lin: FrozenLinear, residual=None, act=ACT_NONE, out_dtype=None):
     return _Linear.apply(x, residual, lin, act, out_dtype)
 
 
+def _uniform_stride(ts):
+    """Element stride between equally shaped, contiguous tensors laid out at a constant spacing inside ONE allocation
+    (e.g. dQ / dK / dV of the fused attention backward, or the up factors of a LoRA group), else None."""
+    if len(ts) < 2:
+        return None
+    t0 = ts[0]
+    step = ts[1].data_ptr() - t0.data_ptr()
+    if step <= 0 or step % t0.element_size():
+        return None
+    base = t0.untyped_storage().data_ptr()
+    for i, t in enumerate(ts):
+        if (t.shape != t0.shape or t.dtype != t0.dtype or not t.is_contiguous()
+                or t.untyped_storage().data_ptr() != base or t.data_ptr() - t0.data_ptr() != i * step):
+            return None
+    return step // t0.element_size()
+
+
 class _LoRAGroupLinear(Function):
     """(y_1 .. y_G) with y_i = x W_i^T + b_i + (h_i) U_i^T (+ residual),  h = s * x [D_1; ..; D_G]^T.
     Forward: one GEMM for h, then ONE K-segmented GEMM per projection ([x | h_i] . [W_i | U_i]^T).
@@ -474,13 +511,22 @@ class _LoRAGroupLinear(Function):
         if residual is not None:
             assert G == 1
             residual = _c(residual)
-        ys = []
-        for i, lin in enumerate(lins):
-            N = lin.out_features
-            y = x.new_empty((M, N))
-            k.gemm_segments([(x, lin.w, Kd, Kd, Kd), (h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r)], y, M, N, N,
-                            bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
-            ys.append(y)
+        sw, su = _uniform_stride([lin.w for lin in lins]), _uniform_stride(ucs)
+        if sw is not None and su is not None and residual is None and all(lin.bias is None for lin in lins):
+            # co-allocated frozen weights (frozen_linear_group) + adjacent up factors: ONE batched launch for the group
+            N = lins[0].out_features
+            ys = x.new_empty((G, M, N))
+            k.gemm_segments([(x, lins[0].w, Kd, Kd, Kd, 0, sw), (h, ucs[0], r, Gr, r, r, su)], ys, M, N, N, batch=G,
+                            sC=M * N)
+            ys = list(ys.unbind(0))
+        else:
+            ys = []
+            for i, lin in enumerate(lins):
+                N = lin.out_features
+                y = x.new_empty((M, N))
+                k.gemm_segments([(x, lin.w, Kd, Kd, Kd), (h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r)], y, M, N, N,
+                                bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
+                ys.append(y)
         ctx.save_for_backward(x, h, dct, *ucs)
         ctx.grp, ctx.lins = grp, lins
         ctx.has_res = residual is not None
@@ -498,18 +544,33 @@ class _LoRAGroupLinear(Function):
         k = kernels()
         gs = [_c(g) if g is not None else x.new_zeros((M, lin.out_features)) for g, lin in zip(gs, lins)]
         u = x.new_empty((M, Gr))
-        for i, lin in enumerate(lins):  # u_i = s * g_i U_i   (U_i stored [N(k), r(n)] -> k-major B operand)
-            N = lin.out_features
-            k.gemm(gs[i], ucs[i], u[:, i * r:(i + 1) * r], M, r, N, N, r, Gr, transB=True, alpha=grp.scale)
+        N0 = lins[0].out_features
+        # when the incoming gradients sit at a constant spacing in one buffer (dQ/dK/dV of the fused attention
+        # backward) and so do the up factors, the G per-projection GEMMs below are ONE batched launch each
+        sg, su = _uniform_stride(gs), _uniform_stride(ucs)
+        sgu = _uniform_stride([grp.ups[i].grad for i in range(G)])
+        batched = sg is not None and su is not None and sgu is not None
+        if batched:  # u[:, i*r:(i+1)*r] = s * g_i U_i for all i
+            k.gemm(gs[0], ucs[0], u, M, r, N0, N0, r, Gr, transB=True, alpha=grp.scale, batch=(G, 1), sA=(sg, 0),
+                   sB=(su, 0), sC=(r, 0))
+        else:
+            for i, lin in enumerate(lins):  # u_i = s * g_i U_i   (U_i stored [N(k), r(n)] -> k-major B operand)
+                N = lin.out_features
+                k.gemm(gs[i], ucs[i], u[:, i * r:(i + 1) * r], M, r, N, N, r, Gr, transB=True, alpha=grp.scale)
         want_down = ctx.needs_input_grad[4]
         want_ups = ctx.needs_input_grad[5:]
 
         def weight_grads():
-            for i, lin in enumerate(lins):
-                if want_ups[i]:  # dU_i [N, r] += g_i^T h_i
-                    N, gu = lin.out_features, grp.ups[i].grad
-                    k.gemm(gs[i], h[:, i * r:(i + 1) * r], gu, N, r, M, N, Gr, r, transA=True, transB=True, R=gu,
-                           ldr=r, beta=1.0)
+            if batched and all(want_ups):  # dU_i [N, r] += g_i^T h_i for all i
+                gu = grp.ups[0].grad
+                k.gemm(gs[0], h, gu, N0, r, M, N0, Gr, r, transA=True, transB=True, R=gu, ldr=r, beta=1.0,
+                       batch=(G, 1), sA=(sg, 0), sB=(r, 0), sC=(sgu, 0), sR=(sgu, 0))
+            else:
+                for i, lin in enumerate(lins):
+                    if want_ups[i]:  # dU_i [N, r] += g_i^T h_i
+                        N, gu = lin.out_features, grp.ups[i].grad
+                        k.gemm(gs[i], h[:, i * r:(i + 1) * r], gu, N, r, M, N, Gr, r, transA=True, transB=True,
+                               R=gu, ldr=r, beta=1.0)
             if want_down:  # d[D_1; ..; D_G] [G*r, K] += u^T x
                 gd = grp.down_cat.grad
                 k.gemm(u, x, gd, Gr, Kd, M, Gr, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
@@ -742,7 +803,12 @@ class _FlashAttention(Function):
         B, Nq, Nk, H, d, scale = ctx.cfg
         HD = H * d
         gO = _c(gO)
-        dQ, dK, dV = torch.empty_like(q), torch.empty_like(k_), torch.empty_like(v)
+        # one allocation, constant spacing: the q/k/v (or k/v) projections' backward batches over these gradients
+        if q.shape == k_.shape:
+            dQ, dK, dV = q.new_empty((3,) + tuple(q.shape)).unbind(0)
+        else:
+            dQ = torch.empty_like(q)
+            dK, dV = k_.new_empty((2,) + tuple(k_.shape)).unbind(0)
         dbuf = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
         kernels().flash_attn_bwd(q, k_, v, O, gO, lse, dbuf, dQ, dK, dV, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
         return dQ, dK, dV, None, None, None, None, None, None

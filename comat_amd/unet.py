@@ -70,6 +70,13 @@ class _Mods:
     def lin(self, name):
         return ops.FrozenLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device)
 
+    def lin_group(self, names):
+        """projections that read the same input: one co-allocated weight buffer when their shapes agree"""
+        ws = [self.sd[n + ".weight"] for n in names]
+        if len(names) > 1 and all(tuple(w.shape) == tuple(ws[0].shape) for w in ws):
+            return ops.frozen_linear_group(ws, [self.sd.get(n + ".bias") for n in names], self.dtype, self.device)
+        return [self.lin(n) for n in names]
+
     def conv(self, name, stride=1, pad=1):
         return ops.FrozenConv(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device,
                               stride=stride, pad=pad)
@@ -123,7 +130,7 @@ class CrossAttnBlock:
             att = {}
             for a in ("attn1", "attn2"):
                 for key, projs in attention_groups(a):
-                    att[(a, key)] = ([m.lin(f"{b}.{a}.{p}") for p in projs],
+                    att[(a, key)] = (m.lin_group([f"{b}.{a}.{p}" for p in projs]),
                                      lora.group[(f"{b}.{a}", key)] if lora is not None else None)
             self.layers.append(dict(ln=[m.norm(f"{b}.norm{i}") for i in (1, 2, 3)], att=att,
                                     ff1=m.lin(f"{b}.ff.net.0.proj"), ff2=m.lin(f"{b}.ff.net.2")))

@@ -66,13 +66,16 @@ int comat_gemm(const comat_gemm_params* p, void* stream);
 
 /* K-segmented GEMM:  C = act(alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + bias2) + beta * R   (1 <= nseg <= 8).
  * Every A_s / B_s is k-contiguous (row-major [rows, K_s] with leading dimension lda / ldb); M, N, the dtypes, the
- * epilogue and the workspace come from `p` (its A, B, K, lda, ldb, trans*, batch* fields are ignored / must be 0).
+ * epilogue and the workspace come from `p` (its A, B, K, lda, ldb, trans*, batch2 fields are ignored / must be 0).
+ * p->batch1 > 1 runs that many independent problems in one launch (q/k/v projections of one activation): C and R
+ * advance by p->sC1 / p->sR1 elements, bias (if any) is [batch1, N], each segment's operands by sA / sB.
  * One launch replaces the chains  y = x W^T + b;  y += (x D^T) U^T  (LoRALinearLayer added to a frozen nn.Linear,
  * training_utils/pipeline.py:95-115) and  dx = sum_i g_i W_i + u D  (the data-gradient of q/k/v projections that
  * share one input plus their low-rank branches). */
 typedef struct {
     const void* A; const void* B;
     int64_t K, lda, ldb;
+    int64_t sA, sB;   /* element stride of A_s / B_s between batch items (p->batch1 items; 0 = shared operand) */
 } comat_gemm_segment;
 int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int32_t nseg, void* stream);
 

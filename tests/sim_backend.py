@@ -48,16 +48,18 @@ class SimKernels:
             acc = acc + beta * _v(R, (b1, b2, M, N), (sR[0], sR[1], ldr, 1)).float()
         _v(Cout, (b1, b2, M, N), (sC[0], sC[1], ldc, 1)).copy_(acc.to(Cout.dtype))
 
-    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0):
-        acc = torch.zeros((M, N), dtype=torch.float32)
-        for A, B, K, lda, ldb in segs:
-            acc = acc + _v(A, (M, K), (lda, 1)).float() @ _v(B, (N, K), (ldb, 1)).float().t()
+    def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0, batch=1, sC=0, sR=0):
+        acc = torch.zeros((batch, M, N), dtype=torch.float32)
+        for sg in segs:
+            A, B, K, lda, ldb = sg[:5]
+            sA, sB = (sg[5], sg[6]) if len(sg) > 5 else (0, 0)
+            acc = acc + _v(A, (batch, M, K), (sA, lda, 1)).float() @ _v(B, (batch, N, K), (sB, ldb, 1)).float().transpose(1, 2)
         acc = alpha * acc
         if bias is not None:
-            acc = acc + bias.float()
+            acc = acc + bias.float().reshape(batch, 1, N)
         if R is not None:
-            acc = acc + beta * _v(R, (M, N), (ldr, 1)).float()
-        _v(Cout, (M, N), (ldc, 1)).copy_(acc.to(Cout.dtype))
+            acc = acc + beta * _v(R, (batch, M, N), (sR, ldr, 1)).float()
+        _v(Cout, (batch, M, N), (sC, ldc, 1)).copy_(acc.to(Cout.dtype))
 
     def transpose_cast_tiles(self, src, dst, tiles):
         sf, df = src.reshape(-1), dst.reshape(-1)

@@ -270,6 +270,17 @@ def test_gemm_segments(dev, dtype, shape):
     k.gemm_segments([(dv(A1, dev, dtype), dv(B1, dev, dtype), 2048, 2048, 2048),
                      (dv(A2, dev, dtype), dv(B2, dev, dtype), 520, 520, 520)], out, 64, 48, 48)
     check(out, A1 @ B1.t() + A2 @ B2.t(), dtype, "gemm_segments split-K")
+    # batched: 3 problems in one launch — shared first A operand, column-sliced second A operand, stacked B operands
+    Gb, Mb, Nb, K1, rb = 3, M, 72, 40, 8
+    X, H = rnd(Mb, K1, dtype=dtype, seed=41), rnd(Mb, Gb * rb, dtype=dtype, seed=42)
+    Wb, Ub = rnd(Gb, Nb, K1, dtype=dtype, seed=43, scale=0.2), rnd(Gb, Nb, rb, dtype=dtype, seed=44, scale=0.2)
+    Rb = rnd(Gb, Mb, Nb, dtype=dtype, seed=45)
+    out = torch.empty((Gb, Mb, Nb), dtype=dtype, device=dev)
+    Hd, Wd, Ud = dv(H, dev, dtype), dv(Wb, dev, dtype), dv(Ub, dev, dtype)
+    k.gemm_segments([(dv(X, dev, dtype), Wd, K1, K1, K1, 0, Nb * K1), (Hd, Ud, rb, Gb * rb, rb, rb, Nb * rb)], out, Mb, Nb,
+                    Nb, R=dv(Rb, dev, dtype), ldr=Nb, beta=1.0, batch=Gb, sC=Mb * Nb, sR=Mb * Nb)
+    ref = torch.stack([X @ Wb[i].t() + H[:, i * rb:(i + 1) * rb] @ Ub[i].t() + Rb[i] for i in range(Gb)])
+    check(out, ref, dtype, "gemm_segments batched")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -330,6 +341,32 @@ def test_lora_group_linear(dev, dtype, G):
     check(xd.grad, 2 * xr.grad, dtype, "lora group dx", factor=2)
     if G == 1:
         check(rd.grad, 2 * rr.grad, dtype, "lora dres")
+    if G == 3:
+        # batched paths: co-allocated frozen weights (one launch for the group's forward) and output gradients at a
+        # constant spacing in one buffer (dQ/dK/dV of the fused attention backward: one launch for u, one for dU)
+        Nq = 64
+        ws = [rnd(Nq, K, dtype=dtype, seed=70 + i, scale=K ** -0.5) for i in range(3)]
+        ups = [rnd(Nq, r, seed=80 + i, scale=0.2) for i in range(3)]
+        downs = [rnd(r, K, seed=90 + i, scale=r ** -0.5) for i in range(3)]
+        gl = ops.frozen_linear_group(ws, [None] * 3, dtype, dev)
+        assert ops._uniform_stride([l.w for l in gl]) == Nq * K
+        st2 = ops.LoRAStore([[(f"d{i}", f"u{i}", downs[i], ups[i]) for i in range(3)]], dtype, dev)
+        x2r = x.clone().requires_grad_(True)
+        d2 = [d.to(dtype).float().clone().requires_grad_(True) for d in downs]
+        u2 = [u.to(dtype).float().clone().requires_grad_(True) for u in ups]
+        gbuf = rnd(3, M, Nq, dtype=dtype, seed=99)
+        y2r = [x2r @ ws[i].t() + (x2r @ d2[i].t()) @ u2[i].t() for i in range(3)]
+        torch.autograd.backward(y2r, [gbuf[i] for i in range(3)])
+        x2 = dv(x, dev, dtype, grad=True)
+        y2 = ops.lora_group_linear(x2, gl, st2.groups[0])
+        assert ops._uniform_stride(list(y2)) == M * Nq
+        gd_buf = dv(gbuf, dev, dtype)
+        torch.autograd.backward(y2, list(gd_buf.unbind(0)))
+        for i in range(3):
+            check(y2[i], y2r[i], dtype, f"batched group y{i}")
+            check(st2.params[f"d{i}"].grad, d2[i].grad, dtype, f"batched group d_down{i}", factor=2)
+            check(st2.params[f"u{i}"].grad, u2[i].grad, dtype, f"batched group d_up{i}", factor=2)
+        check(x2.grad, x2r.grad, dtype, "batched group dx", factor=2)
     # frozen factors (the generator-side pass through the discriminator): dx only, gradient buffer untouched
     store.zero_grad()
     store.set_requires_grad(False)
