@@ -46,14 +46,20 @@ def set_side_stream_enabled(flag: bool):
     _side_enabled = bool(flag)
 
 
+def side_streams_enabled():
+    return _side_enabled
+
+
 def _side_stream(dev):
-    """A second HIP stream per device (None on CPU / when disabled): the K = B*H*W split-K GEMMs of the LoRA weight
-    gradients have few tiles each and no consumer until the optimizer, so they overlap the main backward chain."""
+    """A second HIP stream (None on CPU / when disabled), one per stream that issues backward work: the K = B*H*W
+    split-K GEMMs of the LoRA weight gradients have few tiles each and no consumer until the optimizer, so they
+    overlap the main backward chain."""
     if dev.type != "cuda" or not _side_enabled:
         return None
-    st = _side.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    st = _side.get(key)
     if st is None:
-        st = _side[dev] = torch.cuda.Stream(device=dev)
+        st = _side[key] = torch.cuda.Stream(device=dev)
     return st
 
 
@@ -65,7 +71,7 @@ def join_side_streams():
     end-of-backward callback, so LoRA gradients are complete (in stream order) when `.backward()` returns."""
     global _join_queued
     _join_queued = False
-    for dev, st in _side.items():
+    for (dev, _), st in _side.items():
         torch.cuda.current_stream(dev).wait_stream(st)
     _side_keep.clear()
 

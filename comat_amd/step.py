@@ -114,7 +114,8 @@ class CoMatTrainer:
                                    cfg.max_grad_norm_D)
         self.rng = random.Random(seed)
         self.reducer = GradReducer()
-        self.device = pipeline.device
+        self.device = torch.device(pipeline.device)
+        self._d_stream = None
 
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
@@ -161,27 +162,48 @@ class CoMatTrainer:
         out["image"] = (img, H, W)
         return out
 
+    def _d_step(self, out, batch):
+        """D forward + backward on [fake.detach(); real] (training_script.py:683-690)."""
+        cfg = self.cfg
+        h = w = cfg.resolution // 8
+        self.D.zero_grad()
+        real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
+        D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
+                                              negative_prompt_embeds=batch["gan_null_embeds"],
+                                              num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
+        D_loss.backward()
+        return D_loss.detach()
+
     def _forward_backward(self, batch, fixed):
-        """G forward + backward, then the D forward + backward (everything of the step that precedes the exchange and
-        the optimizer updates).  Returns a dict of device scalars (no host sync)."""
+        """G forward + backward and the D forward + backward (everything of the step that precedes the exchange and
+        the optimizer updates).  Returns a dict of device scalars (no host sync).
+
+        The D step needs only the detached final latents, and it touches only the discriminator's gradient buffers:
+        it is issued on its own HIP stream right after the G forward, so its ~1.2 k small kernels run concurrently
+        with the G backward chain instead of after it (both are latency-bound at bs=1, neither fills the chip).  The
+        results are bit-identical to the serial order (no atomics anywhere); COMAT_D_STREAM=0 restores it."""
         cfg = self.cfg
         self.bank.set_requires_grad(True)
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
-        out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
-        _dbg("G backward")
         logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
         logs["step_loss"] = out["loss"].detach()
         self._last = (out["training_steps"], out["crop"])
-        if cfg.gan_loss:
-            h = w = cfg.resolution // 8
-            self.D.zero_grad()
-            real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
-            D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
-                                                  negative_prompt_embeds=batch["gan_null_embeds"],
-                                                  num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
-            D_loss.backward()
-            logs["D_loss"] = D_loss.detach()
+        concurrent = (cfg.gan_loss and self.device.type == "cuda" and ops.side_streams_enabled()
+                      and os.environ.get("COMAT_D_STREAM", "1") != "0")
+        if concurrent:
+            main = torch.cuda.current_stream(self.device)
+            if self._d_stream is None:
+                self._d_stream = torch.cuda.Stream(device=self.device)
+            self._d_stream.wait_stream(main)  # the G forward (latents, the discriminator's compute copies) is queued
+            with torch.cuda.stream(self._d_stream):
+                logs["D_loss"] = self._d_step(out, batch)
+        out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
+        _dbg("G backward")
+        if concurrent:
+            main.wait_stream(self._d_stream)
+        elif cfg.gan_loss:
+            logs["D_loss"] = self._d_step(out, batch)
         return logs
 
     def _apply_updates(self):
