@@ -28,7 +28,9 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")  # before the HIP runtime initialises (see comat_amd/__init__.py)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
