@@ -41,9 +41,15 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARC
 F_UNET, F_VAE, F_BLIP = 0.839, 2.515, 0.408
 
 
-def step_tflop(total_step, K, gan):
-    nograd = (total_step - K) * 2 * F_UNET
-    train = K * 2 * F_UNET * 2
+F_UNET_SDXL = 1.678  # SDXL UNet @64x64 latent incl. LoRA r=128, per sample forward
+
+
+def step_tflop(total_step, K, gan, sdxl=False):
+    """Algorithmic TFLOP of one step (SURVEY.md 8d counting convention).  The discriminator is the SD1.5 UNet in every
+    configuration (scripts of the reference)."""
+    fu = F_UNET_SDXL if sdxl else F_UNET
+    nograd = (total_step - K) * 2 * fu
+    train = K * 2 * fu * 2
     f = nograd + train + F_VAE * 2 + F_BLIP * 2
     if gan:
         f += F_UNET * 2 + 2 * F_UNET * 2
@@ -130,7 +136,13 @@ def build_world(device, dtype, rank, cfg_name):
     from comat_amd.unet import LoRABank, UNet, VAEDecoder
 
     ucfg, vcfg, bcfg = config.SD15_UNET, config.SD15_VAE, config.BLIP_LARGE
-    if cfg_name == "c2":
+    sdxl = cfg_name == "c4"
+    if sdxl:  # BASELINE config C4: SDXL generator at 512^2 (64^2 latents), SD1.5 discriminator, full CoMat losses
+        from comat_amd.pipeline import TrainableSDXLPipeline
+        ucfg, vcfg = config.SDXL_UNET, config.SDXL_VAE
+        scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True,
+                          train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
+    elif cfg_name == "c2":
         scfg = StepConfig(resolution=512, total_step=5, K=5, gan_loss=True, attrcon=False)
     elif cfg_name == "c3":
         scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True,
@@ -145,13 +157,15 @@ def build_world(device, dtype, rank, cfg_name):
     keep_for_cpu = usd if (rank == 0) else None
     vae = VAEDecoder(vcfg, weights.make_vae_weights(vcfg, seed=2345), dtype, device)
     blip = Blip(bcfg, weights.make_blip_weights(bcfg, seed=3456), dtype, device)
-    dsd = weights.make_unet_weights(ucfg, seed=1235)
-    dbank = LoRABank(ucfg, weights.make_lora_weights(ucfg, seed=4322), dtype, device)
+    dcfg = config.SD15_UNET  # the discriminator is the SD1.5 UNet in every configuration
+    dsd = weights.make_unet_weights(dcfg, seed=1235)
+    dbank = LoRABank(dcfg, weights.make_lora_weights(dcfg, seed=4322), dtype, device)
     g = torch.Generator().manual_seed(99)
-    disc = D_sd(UNet(ucfg, dsd, dtype, device, dbank), dbank, torch.randn(4, generator=g) * 0.5,
+    disc = D_sd(UNet(dcfg, dsd, dtype, device, dbank), dbank, torch.randn(4, generator=g) * 0.5,
                 torch.randn(1, generator=g) * 0.1)
     del dsd
-    trainer = CoMatTrainer(TrainableSDPipeline(unet, vae), bank, blip, disc, scfg, seed=rank)
+    pipe = TrainableSDXLPipeline(unet, vae) if sdxl else TrainableSDPipeline(unet, vae)
+    trainer = CoMatTrainer(pipe, bank, blip, disc, scfg, seed=rank)
     if scfg.total_step > scfg.K and os.environ.get("COMAT_PRECAPTURE", "0") != "0":
         trainer.pipe.prepare_graphs(1, scfg.resolution, scfg.resolution, 77, scfg.total_step)
     # synthetic batch; per-rank seeds differ (each rank has its own prompt)
@@ -162,12 +176,16 @@ def build_world(device, dtype, rank, cfg_name):
     batch = dict(
         prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
         negative_prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
-        gan_null_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
+        gan_null_embeds=torch.randn(1, L, dcfg.cross_attention_dim, generator=g),
         latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42 + rank)),
         noises=[torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(100 + i)).to(device)
                 for i in range(scfg.total_step)],
         real_latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
         blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids))
+    if sdxl:
+        batch.update(pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
+                     negative_pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
+                     add_time_ids=(512, 512, 0, 0, 512, 512))
     if scfg.attrcon:
         import numpy as np
         m = np.zeros((2, 512, 512), dtype=bool)
@@ -213,7 +231,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -228,7 +246,11 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank, args.config)
 
-    run_step = lambda: trainer.train_step(batch, **fixed)
+    last_logs = {}
+
+    def run_step():
+        last_logs.update(trainer.train_step(batch, **fixed))
+
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()
@@ -272,7 +294,7 @@ def main():
         tot_t = sum(v[0] for v in fam.values())
         dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
         t_dom, f_dom, n_dom = fam[dom]
-        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
+        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config == "c4")
         roofline = {
             "bound": "mfma", "kernel": {"gemm": "gemm_kernel<bf16>", "gemm_segments": "gemm_seg_kernel<bf16>",
                                      "conv2d": "conv_kernel<bf16> (implicit GEMM)"}.get(dom, dom),
@@ -286,15 +308,19 @@ def main():
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]},
         }
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "c4":  # the port is SD1.5-shaped
         cpu = cpu_baseline(usd_cpu, scfg)
+    if rank == 0 and os.environ.get("COMAT_BENCH_LOGS"):  # loss terms of the last timed step (sanity evidence)
+        print({k: (float(v) if torch.is_tensor(v) else v) for k, v in last_logs.items()}, file=sys.stderr)
     if rank == 0:
         out = {
-            "metric": "CoMat train-step images/sec (SD1.5 512^2, bs=1/GPU)", "value": value, "unit": "images/sec",
+            "metric": f"CoMat train-step images/sec ({'SDXL' if args.config == 'c4' else 'SD1.5'} 512^2, bs=1/GPU)",
+            "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config.upper()}: SD1.5 512x512 bs=1/GPU, N={scfg.total_step} denoise steps "
+            "config": {"workload": f"{args.config.upper()}: {'SDXL (SD1.5 discriminator)' if args.config == 'c4' else 'SD1.5'} "
+                                   f"512x512 bs=1/GPU, N={scfg.total_step} denoise steps "
                                    f"(K={scfg.K} with grad), CFG 7.5, LoRA r=128, concept-matching (BLIP-large) + GAN "
                                    f"fidelity (G+D step)" + (" + attribute concentration" if scfg.attrcon else "") +
                                    ", clip+AdamW for G and D",

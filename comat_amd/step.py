@@ -120,7 +120,8 @@ class CoMatTrainer:
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
         (bs,L,C); blip_input_ids, blip_attention_mask (bs,T); optional latents (bs,4,h,w), noises [N x (bs,4,h,w)],
-        gan_null_embeds (bs,L,C), real_latents (bs,4,h,w), masks (list of [n_obj,H,W] bool arrays), attributes."""
+        gan_null_embeds (bs,L,C_D), real_latents (bs,4,h,w), masks (list of [n_obj,H,W] bool arrays), attributes;
+        SDXL pipelines also take pooled_prompt_embeds / negative_pooled_prompt_embeds (bs,1280) [+ add_time_ids]."""
         cfg = self.cfg
         res = cfg.resolution
         if training_steps is None:
@@ -130,6 +131,10 @@ class CoMatTrainer:
             if attrcon_steps is None:  # random.choices samples WITH replacement (training_script.py:590)
                 attrcon_steps = self.rng.choices(training_steps, k=min(cfg.attrcon_train_steps, len(training_steps)))
             kw = dict(attrcon_train_steps=attrcon_steps, train_layer_ls=cfg.train_layer_ls, attn_reses=cfg.attn_reses)
+        if "pooled_prompt_embeds" in batch:  # SDXL conditioning (TrainableSDPipeline.py:772-784)
+            kw.update(pooled_prompt_embeds=batch["pooled_prompt_embeds"],
+                      negative_pooled_prompt_embeds=batch["negative_pooled_prompt_embeds"],
+                      add_time_ids=batch.get("add_time_ids"))
         (img, H, W), lat = self.pipe.forward(
             batch["prompt_embeds"], batch["negative_prompt_embeds"], height=res, width=res,
             training_timesteps=training_steps, num_inference_steps=cfg.total_step, guidance_scale=cfg.cfg_scale,

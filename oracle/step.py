@@ -12,11 +12,15 @@ from . import sd as O
 
 
 def g_loss_terms(W, batch, cfg, training_steps, crop, attrcon_steps=()):
-    """W: dict(unet, vae, blip, lora, d_unet, d_lora, head_w, head_b, ucfg, vcfg, bcfg).  cfg: the product's StepConfig
+    """W: dict(unet, vae, blip, lora, d_unet, d_lora, head_w, head_b, ucfg, vcfg, bcfg[, d_ucfg: the discriminator's
+    UNet config when it differs from the generator's — SDXL generator + SD1.5 discriminator]).  cfg: the product's StepConfig
     (duck-typed).  Returns dict with loss, Blip (reward), G_loss, token_loss, pixel_loss, image, latents, logp."""
     kw = {}
     if cfg.attrcon:
         kw = dict(attrcon_steps=attrcon_steps, train_layer_ls=cfg.train_layer_ls, reses=cfg.attn_reses)
+    if "pooled_prompt_embeds" in batch:  # SDXL generator (TrainableSDPipeline.py:657-846)
+        kw["sdxl_cond"] = (batch["negative_pooled_prompt_embeds"], batch["pooled_prompt_embeds"],
+                           torch.tensor([list(batch["add_time_ids"])], dtype=torch.float32))
     img, lat, attn_dict = O.sample_with_grad(W["unet"], W["ucfg"], W["vae"], W["vcfg"], W["lora"],
                                              batch["negative_prompt_embeds"], batch["prompt_embeds"],
                                              batch["latents"], batch["noises"], cfg.total_step, training_steps,
@@ -27,7 +31,7 @@ def g_loss_terms(W, batch, cfg, training_steps, crop, attrcon_steps=()):
     out = dict(Blip=reward, token_logp=logp, image=img, latents=lat)
     loss = -reward
     if cfg.gan_loss:
-        G = OL.gan_g_loss(W["d_unet"], W["ucfg"], W["d_lora"], W["head_w"], W["head_b"], lat, batch["gan_null_embeds"],
+        G = OL.gan_g_loss(W["d_unet"], W.get("d_ucfg", W["ucfg"]), W["d_lora"], W["head_w"], W["head_b"], lat, batch["gan_null_embeds"],
                           cfg.total_step)
         loss = loss + cfg.gan_loss_weight * G
         out["G_loss"] = G
@@ -42,7 +46,7 @@ def g_loss_terms(W, batch, cfg, training_steps, crop, attrcon_steps=()):
 
 
 def d_loss(W, batch, cfg, fake_latents):
-    return OL.gan_d_loss(W["d_unet"], W["ucfg"], W["d_lora"], W["head_w"], W["head_b"], fake_latents,
+    return OL.gan_d_loss(W["d_unet"], W.get("d_ucfg", W["ucfg"]), W["d_lora"], W["head_w"], W["head_b"], fake_latents,
                          batch["real_latents"], batch["gan_null_embeds"], cfg.total_step)
 
 

@@ -133,3 +133,62 @@ def test_side_stream_overlap_is_bit_exact(hip):
     ops.set_side_stream_enabled(True)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_train_step_sdxl_matches_oracle(dev, dtype):
+    """BASELINE config C4 in miniature: SDXL generator (text_time conditioning, UNet input always detached, raw VAE
+    decode into the reward) + SD1.5-layout discriminator + attribute concentration, one full optimisation step."""
+    from comat_amd.pipeline import TrainableSDXLPipeline
+    from oracle import sd as O
+    ucfg = config.TINY_SDXL_UNET
+    vcfg = dataclasses.replace(config.TINY_VAE, scaling_factor=0.13025)
+    q = lambda d: {k: v.to(dtype).float() for k, v in d.items()}
+    up5 = lambda d: {k: (v * 5 if k.endswith("up.weight") else v) for k, v in d.items()}
+    usd = q(weights.make_unet_weights(ucfg, perturb_norms=True))
+    vsd = q(weights.make_vae_weights(vcfg, perturb_norms=True))
+    lsd = q(up5(weights.make_lora_weights(ucfg)))
+    bsd = q(weights.make_blip_weights(config.TINY_BLIP, perturb_norms=True))
+    dsd = q(weights.make_unet_weights(config.TINY_UNET, seed=77, perturb_norms=True))
+    dl = q(up5(weights.make_lora_weights(config.TINY_UNET, seed=78)))
+    g = torch.Generator().manual_seed(6)
+    r = lambda *s: torch.randn(*s, generator=g)
+    head_w, head_b = r(4) * 0.5, r(1) * 0.1
+    cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=True, attrcon_train_steps=1,
+                     train_layer_ls=("mid_2", "up_2", "up_4"), attn_reses=(8, 4, 2), lr=1e-2, lr_D=1e-2,
+                     mask_token_loss_weight=0.5, mask_pixel_loss_weight=0.1)
+    bs, L, T = 1, 7, 9
+    ids = torch.randint(1, config.TINY_BLIP.vocab_size, (bs, T), generator=g)
+    m = np.zeros((2, 64, 64), dtype=bool)
+    m[0, 5:30, 8:40] = True
+    m[1, 34:60, 20:64] = True
+    rq = lambda *s: r(*s).to(dtype).float()
+    batch = dict(prompt_embeds=rq(bs, L, ucfg.cross_attention_dim), negative_prompt_embeds=rq(bs, L, ucfg.cross_attention_dim),
+                 pooled_prompt_embeds=rq(bs, ucfg.pooled_dim), negative_pooled_prompt_embeds=rq(bs, ucfg.pooled_dim),
+                 add_time_ids=(64, 64, 0, 0, 64, 64),
+                 gan_null_embeds=rq(bs, L, config.TINY_UNET.cross_attention_dim), latents=r(bs, 4, 8, 8),
+                 noises=[r(bs, 4, 8, 8) for _ in range(3)], real_latents=r(bs, 4, 8, 8),
+                 blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids), masks=[m], attributes=[[[2, 3], [5]]])
+    W = dict(unet=usd, vae=vsd, blip=bsd, d_unet=dsd, ucfg=O.UNetConfig(**dataclasses.asdict(ucfg)),
+             d_ucfg=O.UNetConfig(**dataclasses.asdict(config.TINY_UNET)), vcfg=O.VAEConfig(**dataclasses.asdict(vcfg)),
+             bcfg=OB.BlipConfig(**dataclasses.asdict(config.TINY_BLIP)),
+             lora={k: v.clone().requires_grad_(True) for k, v in lsd.items()},
+             d_lora={k: v.clone().requires_grad_(True) for k, v in dl.items()},
+             head_w=head_w.clone().requires_grad_(True), head_b=head_b.clone().requires_grad_(True))
+    bank = LoRABank(ucfg, lsd, dtype, dev)
+    pipe = TrainableSDXLPipeline(UNet(ucfg, usd, dtype, dev, bank), VAEDecoder(vcfg, vsd, dtype, dev))
+    dbank = LoRABank(config.TINY_UNET, dl, dtype, dev)
+    disc = D_sd(UNet(config.TINY_UNET, dsd, dtype, dev, dbank), dbank, head_w, head_b)
+    trainer = CoMatTrainer(pipe, bank, Blip(config.TINY_BLIP, bsd, dtype, dev), disc, cfg, seed=0)
+    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
+    ref = OS.train_step(W, batch, cfg, ts, crop, acs)
+    logs = trainer.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    f = 1.0 if dtype == torch.float32 else 4.0
+    for key, rk in (("Blip", "Blip"), ("G_loss", "G_loss"), ("D_loss", "D_loss"), ("step_loss", "loss"),
+                    ("token_loss", "token_loss"), ("pixel_loss", "pixel_loss")):
+        check(logs[key], ref[rk], dtype, key, factor=f)
+    g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
+    d_ref = torch.cat([ref["d_grads"][n].reshape(-1) for n in dbank.names])
+    lim = 1e-3 if dtype == torch.float32 else 0.15
+    assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
+    assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
