@@ -200,9 +200,9 @@ def build_world(device, dtype, rank, cfg_name):
 
 
 def cpu_baseline(usd, scfg):
-    """Oracle (CPU fp32 port) on a bounded sample: one no-grad SD1.5 UNet forward of the oracle at CFG batch 2 on a
-    32x32 latent (a quarter of the tokens), FLOPs counted by torch's FlopCounterMode, extrapolated to the whole step
-    by algorithmic FLOPs."""
+    """Oracle (CPU fp32 port) on a bounded sample of the same workload: ONE no-grad SD1.5 UNet forward of the oracle at
+    the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens) — 1/14 of the UNet calls of a C2 step — with
+    FLOPs counted by torch's FlopCounterMode, extrapolated to the whole step by algorithmic FLOPs."""
     from torch.utils.flop_counter import FlopCounterMode
 
     from oracle import sd as O
@@ -211,7 +211,7 @@ def cpu_baseline(usd, scfg):
     torch.set_num_threads(threads)
     ocfg = O.UNetConfig()
     g = torch.Generator().manual_seed(0)
-    x, ctx = torch.randn(2, 4, 32, 32, generator=g), torch.randn(2, 77, 768, generator=g)
+    x, ctx = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g)
     with torch.no_grad():
         with FlopCounterMode(display=False) as fc:
             t0 = time.time()
@@ -221,7 +221,7 @@ def cpu_baseline(usd, scfg):
     total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
     est_step_s = dt * total / sample_tflop
     return {"value": 1.0 / est_step_s, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle/sd.py unet_forward (SD1.5, fp32, CFG batch 2, 32x32 latent): {sample_tflop:.3f} TFLOP in "
+            "sample": f"oracle/sd.py unet_forward (SD1.5, fp32, CFG batch 2, 64x64 latent): {sample_tflop:.3f} TFLOP in "
                       f"{dt:.1f} s = {sample_tflop / dt:.3f} TFLOP/s on {threads} of {cores} host threads; step time "
                       f"extrapolated by algorithmic FLOPs ({total:.1f} TFLOP/step)"}
 
