@@ -15,7 +15,7 @@ from __future__ import annotations
 import os
 import random
 import sys
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import torch
 

@@ -17,7 +17,7 @@ Weights arrive as a flat dict with diffusers state-dict names (conv weights OIHW
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import torch
 import torch.nn.functional as F
