@@ -665,21 +665,26 @@ template <typename T, int BM, int BN> int launch_gemm_t(const GemmArgs& g, int t
 // put several on every CU (the k-loop is latency-bound otherwise) — first through the tile size, then through
 // split-K with fp32 slabs in the caller's workspace (>= 8 k-tiles per split so the slab traffic stays small).
 struct TilePlan {
-    bool big;
+    int bm, bn;   // block tile: 64x64 (default), or 128x128 / 128x64 / 64x128 through COMAT_FORCE_TILE (experiments)
     int splits;
 };
 TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
     TilePlan p;
-    const int64_t t128 = cdiv64(M, 128) * cdiv64(N, 128) * batch;
-    const int64_t t64 = cdiv64(M, 64) * cdiv64(N, 64) * batch;
-    p.big = false;  // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128
-    (void)t128;     // (2/CU) on every shape of this workload; the big tile is kept for COMAT_FORCE_TILE experiments
-    const int64_t blocks = p.big ? t128 : t64;
-    const int64_t nk = cdiv64(K, bke);
+    // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128 (2/CU) on every
+    // shape of this workload; the larger tiles (bf16 only) are kept for COMAT_FORCE_TILE experiments:
+    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128
+    p.bm = p.bn = 64;
     p.splits = 1;
     static const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py)
     static const char* force_split = getenv("COMAT_FORCE_SPLITS");
-    if (force_tile) p.big = atoi(force_tile) >= 128 && M > 0;
+    if (force_tile) {
+        const int v = atoi(force_tile);
+        if (v == 128) p.bm = p.bn = 128;
+        else if (v == 12864) p.bm = 128;
+        else if (v == 64128) p.bn = 128;
+    }
+    const int64_t blocks = cdiv64(M, p.bm) * cdiv64(N, p.bn) * batch;
+    const int64_t nk = cdiv64(K, bke);
     if (force_split) {
         int64_t s = atoi(force_split);
         const int64_t cap = ws_bytes > 0 ? ws_bytes / (batch * M * N * 4) : 1;
@@ -738,10 +743,11 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int64_t batch = p->batch1 * p->batch2;
     const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
     const TilePlan plan = plan_tiles(p->M, p->N, p->K, bke, batch, p->ws ? p->ws_bytes : 0);
-    const bool big = plan.big;
-    const int bm = big ? 128 : 64;
+    const bool bf = p->in_dtype == COMAT_BF16;
+    const int tile = (plan.bm == 128 ? 2 : 0) | (plan.bn == 128 ? 1 : 0);  // 0: 64x64, 1: 64x128, 2: 128x64, 3: 128x128
+    const int bm = (tile == 1 || tile == 2) && !bf ? 64 : plan.bm, bn = (tile == 1 || tile == 2) && !bf ? 64 : plan.bn;
     g.tiles_m = (int)cdiv64(p->M, bm);
-    g.tiles_n = (int)cdiv64(p->N, bm);
+    g.tiles_n = (int)cdiv64(p->N, bn);
     g.splits = plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
@@ -749,11 +755,13 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
-    if (p->in_dtype == COMAT_BF16) {
-        if (big) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
+    if (bf) {
+        if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
+        else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
+        else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
         else launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
     } else {
-        if (big) launch_gemm_t<float, 128, 128>(g, trans, grid, st);
+        if (bm == 128) launch_gemm_t<float, 128, 128>(g, trans, grid, st);
         else launch_gemm_t<float, 64, 64>(g, trans, grid, st);
     }
     if (g.splits > 1)
@@ -844,21 +852,24 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
     const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
     const TilePlan plan = plan_tiles(g.M, g.N, g.K, bke, 1, p->ws ? p->ws_bytes : 0);
-    const bool big = plan.big;
-    const int bm = big ? 128 : 64;
+    const bool bf = p->in_dtype == COMAT_BF16;
+    const bool mixed = plan.bm != plan.bn;
+    const int bm = mixed && !bf ? 64 : plan.bm, bn = mixed && !bf ? 64 : plan.bn;
     g.tiles_m = (int)cdiv64(g.M, bm);
-    g.tiles_n = (int)cdiv64(g.N, bm);
+    g.tiles_n = (int)cdiv64(g.N, bn);
     g.splits = plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
     g.ws = (float*)p->ws;
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (p->in_dtype == COMAT_BF16) {
-        if (big) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
+    if (bf) {
+        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
+        else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
+        else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
         else hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);
     } else {
-        if (big) hipLaunchKernelGGL((conv_kernel<float, 128, 128>), grid, dim3(NT), 0, st, g);
+        if (bm == 128) hipLaunchKernelGGL((conv_kernel<float, 128, 128>), grid, dim3(NT), 0, st, g);
         else hipLaunchKernelGGL((conv_kernel<float, 64, 64>), grid, dim3(NT), 0, st, g);
     }
     if (g.splits > 1) launch_reduce(g.ws, g.M, g.N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
