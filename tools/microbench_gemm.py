@@ -1,5 +1,7 @@
 """Per-shape microbenchmark of comat_gemm / comat_conv2d on the GPU (HIP events around N back-to-back launches).
-Tuning knobs: COMAT_FORCE_TILE=64|128, COMAT_FORCE_SPLITS=n (read once per process by the library)."""
+Tuning knobs (read once per process by the library): COMAT_FORCE_TILE=64|128|12864|64128 (block tile 64x64, 128x128,
+128x64, 64x128), COMAT_FORCE_SPLITS=n.  Sweep:  for t in 64 12864 64128 128; do COMAT_FORCE_TILE=$t python
+tools/microbench_gemm.py; done"""
 import os
 import sys
 
@@ -56,6 +58,7 @@ if __name__ == "__main__":
     conv(2, 16, 16, 1280, 1280)
     conv(2, 8, 8, 1280, 1280)
     conv(1, 128, 128, 512, 512)
+    conv(1, 256, 256, 256, 256)
     conv(1, 512, 512, 128, 128)
     gemm(8192, 320, 320)
     gemm(2048, 640, 640)
