@@ -144,7 +144,15 @@ def _ptr(t: torch.Tensor | None):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """raw handle of torch's current HIP stream on the current device (every kernel is enqueued on it).  The C-level
+    accessors avoid building a torch.cuda.Stream object per launch (~2 us of the ~8 us host cost of a launch)."""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 
