@@ -49,11 +49,11 @@ union Vec16 {
 // ---------------------------------------------------------------------------------------------------------------
 // All index arithmetic that does not change along k is done once in init(); load() only advances running
 // pointers / tap counters by one k-tile (the k-loop of the small tiles is otherwise VALU-bound on address math).
-template <typename T, int ROWS, bool TRANS> struct PlainLoader {
+template <typename T, int ROWS, bool TRANS, int NTH = NT> struct PlainLoader {
     static constexpr bool kTrans = TRANS;
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
-    static constexpr int NCH = ROWS * CPR / NT;
+    static constexpr int NCH = ROWS * CPR / NTH;
     static constexpr int VPR = ROWS / EPV;               // 16-byte vectors per k-row (k-major image)
     static constexpr int RS = ROWS * (int)sizeof(T) + 16;  // k-major LDS row stride in bytes
     const T* ptr[NCH];   // running source pointer of each 16-byte chunk
@@ -72,7 +72,7 @@ template <typename T, int ROWS, bool TRANS> struct PlainLoader {
         step = TRANS ? (int64_t)BKE * ld : (int64_t)BKE;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
+            const int c = threadIdx.x + i * NTH;
             if (!TRANS) {
                 const int row = c / CPR, kv = c % CPR;
                 const int64_t gr = r0 + row;
@@ -259,11 +259,11 @@ struct ConvGeom {
 
 // im2col gather of a channels-last activation: row m = (b, oy, ox), k = (ky, kx, ci).  Per chunk the output position
 // is decoded once; along k a running (ky, kx, ci) counter replaces the divisions.
-template <typename T, int ROWS> struct ConvLoader {
+template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
     static constexpr bool kTrans = false;
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
-    static constexpr int NCH = ROWS * CPR / NT;
+    static constexpr int NCH = ROWS * CPR / NTH;
     const T* X;
     ConvGeom g;
     bool vec_ok;
@@ -278,7 +278,7 @@ template <typename T, int ROWS> struct ConvLoader {
         vec_ok = ((g.Cin % EPV) == 0) && ((((uintptr_t)x) & 15) == 0);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
+            const int c = threadIdx.x + i * NTH;
             const int64_t gm = r0 + (c / CPR);
             rvalid[i] = gm < M;
             const int hw = g.Hout * g.Wout;
@@ -362,7 +362,7 @@ template <typename T, int ROWS> struct ConvLoader {
     __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
+            const int c = threadIdx.x + i * NTH;
             *(uint4*)(lds + (c / CPR) * ROWB + (c % CPR) * 16) = regs[slot][i];
         }
     }
@@ -407,17 +407,20 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const f32x4_t& a, const f32x4
 // ---------------------------------------------------------------------------------------------------------------
 // Block-level main loop + fused epilogue
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, typename AL, typename BL>
+template <typename T, int BM, int BN, typename AL, typename BL, int NTH = NT>
 __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t kt1, int64_t m0, int64_t n0, int64_t M,
                                            int64_t N, const Epi& ep, float* slab) {
-    constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+    // waves are arranged (NTH / 128) x 2: 4 waves -> 2 x 2, 8 waves -> 4 x 2 (rows x columns of the block tile)
+    constexpr int WR = NTH / 128;
+    constexpr int WTM = BM / WR, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM >= 1 && TN >= 1, "block tile too small for the wave grid");
     typedef typename FragOf<T>::type F;
     constexpr int OPB = (BM > 64 || BN > 64) ? 128 * ROWB : 64 * ROWB;  // bytes per operand per stage (>= any image)
     __shared__ __attribute__((aligned(16))) char smem[2][2][OPB];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;  // wr in [0, WR)
 
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -538,7 +541,8 @@ __device__ __forceinline__ void split_range(int64_t K, int bke, int splits, int 
     if (kt0 > nk) kt0 = nk;
 }
 
-template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
+template <typename T, int BM, int BN, bool TA, bool TB, int NTH = NT>
+__global__ __launch_bounds__(NTH) void gemm_kernel(GemmArgs g) {
     // linear work id = ((z * tiles_m + tm) * tiles_n + tn) * splits + split
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
@@ -557,11 +561,12 @@ template <typename T, int BM, int BN, bool TA, bool TB> __global__ __launch_boun
     const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
     ep.C = (char*)ep.C + coff * (ep.out_dt == COMAT_F32 ? 4 : 2);
     if (ep.R) ep.R = (const char*)ep.R + roff * (ep.r_dt == COMAT_F32 ? 4 : 2);
-    PlainLoader<T, BM, TA> al;
-    PlainLoader<T, BN, TB> bl;
+    PlainLoader<T, BM, TA, NTH> al;
+    PlainLoader<T, BN, TB, NTH> bl;
     al.init(A, g.lda, m0, g.M, g.K, kt0);
     bl.init(B, g.ldb, n0, g.N, g.K, kt0);
-    gemm_block<T, BM, BN>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
+    gemm_block<T, BM, BN, PlainLoader<T, BM, TA, NTH>, PlainLoader<T, BN, TB, NTH>, NTH>(al, bl, kt0, kt1, m0, n0, g.M, g.N,
+                                                                                       ep, slab);
 }
 
 struct GemmSegArgs {
@@ -635,7 +640,7 @@ struct ConvArgs {
     Epi ep;
 };
 
-template <typename T, int BM, int BN> __global__ __launch_bounds__(NT) void conv_kernel(ConvArgs g) {
+template <typename T, int BM, int BN, int NTH = NT> __global__ __launch_bounds__(NTH) void conv_kernel(ConvArgs g) {
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
     lin /= g.splits;
@@ -644,19 +649,21 @@ template <typename T, int BM, int BN> __global__ __launch_bounds__(NT) void conv
     int64_t kt0, kt1;
     split_range(g.K, KTB / (int)sizeof(T), g.splits, sp, kt0, kt1);
     float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
-    ConvLoader<T, BM> al;
-    PlainLoader<T, BN, false> bl;
+    ConvLoader<T, BM, NTH> al;
+    PlainLoader<T, BN, false, NTH> bl;
     al.init(g.X, g.geo, m0, g.M, kt0);
     bl.init(g.W, g.K, n0, g.N, g.K, kt0);
-    gemm_block<T, BM, BN>(al, bl, kt0, kt1, m0, n0, g.M, g.N, g.ep, slab);
+    gemm_block<T, BM, BN, ConvLoader<T, BM, NTH>, PlainLoader<T, BN, false, NTH>, NTH>(al, bl, kt0, kt1, m0, n0, g.M, g.N,
+                                                                                     g.ep, slab);
 }
 
-template <typename T, int BM, int BN> int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
+template <typename T, int BM, int BN, int NTH = NT>
+int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
     switch (trans) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false>), grid, dim3(NT), 0, st, g); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, false>), grid, dim3(NT), 0, st, g); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true>), grid, dim3(NT), 0, st, g); break;
-        default: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true>), grid, dim3(NT), 0, st, g); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, NTH>), grid, dim3(NTH), 0, st, g); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, false, NTH>), grid, dim3(NTH), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, NTH>), grid, dim3(NTH), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, NTH>), grid, dim3(NTH), 0, st, g); break;
     }
     return 0;
 }
@@ -666,20 +673,23 @@ template <typename T, int BM, int BN> int launch_gemm_t(const GemmArgs& g, int t
 // split-K with fp32 slabs in the caller's workspace (>= 8 k-tiles per split so the slab traffic stays small).
 struct TilePlan {
     int bm, bn;   // block tile: 64x64 (default), or 128x128 / 128x64 / 64x128 through COMAT_FORCE_TILE (experiments)
+    int nth;      // threads per block: 256, or 512 (8 waves, 4 x 2) for the experimental 128x128 variant "1288"
     int splits;
 };
 TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
     TilePlan p;
     // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128 (2/CU) on every
     // shape of this workload; the larger tiles (bf16 only) are kept for COMAT_FORCE_TILE experiments:
-    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128
+    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128, 1288 -> 128x128 with 8 waves per block
     p.bm = p.bn = 64;
+    p.nth = NT;
     p.splits = 1;
     static const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py)
     static const char* force_split = getenv("COMAT_FORCE_SPLITS");
     if (force_tile) {
         const int v = atoi(force_tile);
         if (v == 128) p.bm = p.bn = 128;
+        else if (v == 1288) { p.bm = p.bn = 128; p.nth = 512; }
         else if (v == 12864) p.bm = 128;
         else if (v == 64128) p.bn = 128;
     }
@@ -756,7 +766,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
     if (bf) {
-        if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
+        if (bm == 128 && bn == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
+        else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
         else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
         else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
         else launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
@@ -864,7 +875,9 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     if (bf) {
-        if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
+        if (bm == 128 && bn == 128 && plan.nth == 512)
+            hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
+        else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
         else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
         else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
         else hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);
