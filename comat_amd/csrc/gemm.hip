@@ -53,7 +53,10 @@ template <typename T, int ROWS, bool TRANS, int NTH = NT> struct PlainLoader {
     static constexpr bool kTrans = TRANS;
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
-    static constexpr int NCH = ROWS * CPR / NTH;
+    static constexpr int TOTAL = ROWS * CPR;             // 16-byte chunks of one k-tile image
+    static constexpr int NCH = TOTAL >= NTH ? TOTAL / NTH : 1;
+    static constexpr bool PARTIAL = TOTAL < NTH;          // more threads than chunks: the surplus threads idle here
+    static_assert(TOTAL % NTH == 0 || TOTAL < NTH, "chunks must divide evenly over the block");
     static constexpr int VPR = ROWS / EPV;               // 16-byte vectors per k-row (k-major image)
     static constexpr int RS = ROWS * (int)sizeof(T) + 16;  // k-major LDS row stride in bytes
     const T* ptr[NCH];   // running source pointer of each 16-byte chunk
@@ -73,6 +76,13 @@ template <typename T, int ROWS, bool TRANS, int NTH = NT> struct PlainLoader {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NTH;
+            if (PARTIAL && c >= TOTAL) {  // no chunk for this thread
+                kpos[i] = 0;
+                rleft[i] = 0;
+                ptr[i] = P;
+                lds_off[i] = -1;
+                continue;
+            }
             if (!TRANS) {
                 const int row = c / CPR, kv = c % CPR;
                 const int64_t gr = r0 + row;
@@ -132,7 +142,8 @@ template <typename T, int ROWS, bool TRANS, int NTH = NT> struct PlainLoader {
     }
     __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) *(uint4*)(lds + lds_off[i]) = regs[slot][i];
+        for (int i = 0; i < NCH; ++i)
+            if (!PARTIAL || lds_off[i] >= 0) *(uint4*)(lds + lds_off[i]) = regs[slot][i];
     }
 };
 
@@ -264,6 +275,7 @@ template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
     static constexpr int NCH = ROWS * CPR / NTH;
+    static_assert(ROWS * CPR % NTH == 0 && NCH >= 1, "conv A operand: chunks must divide evenly over the block");
     const T* X;
     ConvGeom g;
     bool vec_ok;
@@ -680,16 +692,17 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
     TilePlan p;
     // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128 (2/CU) on every
     // shape of this workload; the larger tiles (bf16 only) are kept for COMAT_FORCE_TILE experiments:
-    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128, 1288 -> 128x128 with 8 waves per block
+    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128; with 8 waves per block: 1288 -> 128x128, 128648 -> 128x64
     p.bm = p.bn = 64;
     p.nth = NT;
     p.splits = 1;
-    static const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py)
-    static const char* force_split = getenv("COMAT_FORCE_SPLITS");
+    const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py), read per
+    const char* force_split = getenv("COMAT_FORCE_SPLITS");   // call so that tests can switch variants in-process
     if (force_tile) {
         const int v = atoi(force_tile);
         if (v == 128) p.bm = p.bn = 128;
         else if (v == 1288) { p.bm = p.bn = 128; p.nth = 512; }
+        else if (v == 128648) { p.bm = 128; p.nth = 512; }
         else if (v == 12864) p.bm = 128;
         else if (v == 64128) p.bn = 128;
     }
@@ -768,6 +781,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     if (bf) {
         if (bm == 128 && bn == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
         else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
+        else if (bm == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 64, 512>(g, trans, grid, st);
         else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
         else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
         else launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
@@ -878,6 +892,8 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
         if (bm == 128 && bn == 128 && plan.nth == 512)
             hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
         else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
+        else if (bm == 128 && plan.nth == 512)
+            hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64, 512>), grid, dim3(512), 0, st, g);
         else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
         else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
         else hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);

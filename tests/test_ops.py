@@ -592,3 +592,41 @@ def test_adamw_with_clip(dev):
         assert not torch.isfinite(nsq).item()
         ops.kernels().adamw(p, gd, m, v, n, 5e-3, 0.9, 0.999, 1e-8, 1e-2, 4, nsq, 0.1)
         assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", ["64", "128", "12864", "64128", "1288", "128648"])
+def test_block_tile_variants_match_default(hip, tile, monkeypatch):
+    """Every COMAT_FORCE_TILE block-tile variant of the GEMM / conv kernels (4 or 8 waves per block) reproduces the
+    default 64x64 tile on ragged shapes: same operands, same k order per output element -> same fp32 sums up to the
+    split-K grouping, compared with bf16 tolerance against an fp32 matmul / conv reference."""
+    dtype = torch.bfloat16
+    k = ops.kernels()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    monkeypatch.setenv("COMAT_FORCE_TILE", tile)
+    for (M, N, K_, tA, tB) in ((300, 200, 328, False, False), (257, 129, 100, True, False), (130, 260, 72, False, True),
+                               (515, 140, 1030, True, True), (2048, 384, 640, False, False)):
+        A = rnd(*((K_, M) if tA else (M, K_)), dtype=dtype, seed=1, scale=0.5)
+        B = rnd(*((K_, N) if tB else (N, K_)), dtype=dtype, seed=2, scale=0.5)
+        bias, R = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
+        out = torch.empty((M, N), dtype=dtype, device=hip)
+        k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M if tA else K_, N if tB else K_, N, transA=tA,
+               transB=tB, bias=dv(bias, hip), R=dv(R, hip, dtype), ldr=N, beta=1.0)
+        ref = (A.t() if tA else A) @ (B if tB else B.t()) + bias + R
+        check(out, ref, dtype, f"gemm tile={tile} M={M} N={N} K={K_} tA={tA} tB={tB}")
+    for (Bn, H, W, Cin, Cout, stride, ups) in ((2, 13, 9, 40, 72, 1, 1), (1, 16, 16, 64, 136, 2, 1), (1, 8, 8, 48, 64, 1, 2),
+                                               (1, 64, 64, 64, 128, 1, 1)):
+        x = rnd(Bn, Cin, H, W, dtype=dtype, seed=5)
+        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=6, scale=(9 * Cin) ** -0.5)
+        b = rnd(Cout, seed=7)
+        conv = ops.FrozenConv(w, b, dtype, hip, stride=stride, pad=1)
+        xd = dv(tok(x), hip, dtype, grad=True)
+        y = ops.conv2d(xd, conv, Bn, H, W, ups=ups)
+        xr = x.clone().requires_grad_(True)
+        xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups == 2 else xr
+        yr = F.conv2d(xin, w, b, stride=stride, padding=1)
+        g = rnd(*yr.shape, dtype=dtype, seed=8)
+        yr.backward(g)
+        y.backward(dv(tok(g), hip, dtype))
+        check(y, tok(yr), dtype, f"conv tile={tile} {Bn}x{H}x{W} {Cin}->{Cout} s={stride} ups={ups}")
+        check(xd.grad, tok(xr.grad), dtype, f"conv dgrad tile={tile}", factor=2)
