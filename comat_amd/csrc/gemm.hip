@@ -688,7 +688,8 @@ struct TilePlan {
     int nth;      // threads per block: 256, or 512 (8 waves, 4 x 2) for the experimental 128x128 variant "1288"
     int splits;
 };
-TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
+TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes,
+                    bool allow_variants = true) {
     TilePlan p;
     // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128 (2/CU) on every
     // shape of this workload; the larger tiles (bf16 only) are kept for COMAT_FORCE_TILE experiments:
@@ -698,7 +699,7 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
     p.splits = 1;
     const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py), read per
     const char* force_split = getenv("COMAT_FORCE_SPLITS");   // call so that tests can switch variants in-process
-    if (force_tile) {
+    if (force_tile && allow_variants) {
         const int v = atoi(force_tile);
         if (v == 128) p.bm = p.bn = 128;
         else if (v == 1288) { p.bm = p.bn = 128; p.nth = 512; }
@@ -709,7 +710,7 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
     // COMAT_TILE_AUTO=1 (experimental): the 8-wave 128x128 block where there are enough of
     // them to fill the chip twice over (measured: VAE convs 295 -> 423 TFLOP/s), the 64x64 block elsewhere
     const char* tile_auto = getenv("COMAT_TILE_AUTO");
-    if (!force_tile && tile_auto && atoi(tile_auto) == 1 && bke == KTB / 2 &&
+    if (allow_variants && !force_tile && tile_auto && atoi(tile_auto) == 1 && bke == KTB / 2 &&
         cdiv64(M, 128) * cdiv64(N, 128) * batch >= 512) {
         p.bm = p.bn = 128;
         p.nth = 512;
@@ -841,7 +842,7 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
     g.sC = p->sC1; g.sR = p->sR1; g.sBias = p->bias ? p->N : 0;  // bias: [batch, N] when batched
-    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0);
+    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0, false);
     g.tiles_m = (int)cdiv64(p->M, 64);
     g.tiles_n = (int)cdiv64(p->N, 64);
     g.splits = plan.splits;
