@@ -68,14 +68,18 @@ template <typename T, int ROWS, bool TRANS, int NTH = NT> struct PlainLoader {
     bool vec_ok;
     uint4 regs[PF][NCH];
 
-    __device__ __forceinline__ void init(const void* p, int64_t ld, int64_t r0, int64_t rmax, int64_t k_, int64_t kt0) {
+    // `tid`: index of the thread among the NTH threads that fill this image (threadIdx.x unless the block holds
+    // several wave groups with an image each)
+    __device__ __forceinline__ void init(const void* p, int64_t ld, int64_t r0, int64_t rmax, int64_t k_, int64_t kt0,
+                                         int tid = -1) {
         const T* P = (const T*)p;
+        if (tid < 0) tid = threadIdx.x;
         K = (int)k_;
         vec_ok = ((ld % EPV) == 0) && ((((uintptr_t)p) & 15) == 0);
         step = TRANS ? (int64_t)BKE * ld : (int64_t)BKE;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NTH;
+            const int c = tid + i * NTH;
             if (PARTIAL && c >= TOTAL) {  // no chunk for this thread
                 kpos[i] = 0;
                 rleft[i] = 0;
@@ -270,7 +274,7 @@ struct ConvGeom {
 
 // im2col gather of a channels-last activation: row m = (b, oy, ox), k = (ky, kx, ci).  Per chunk the output position
 // is decoded once; along k a running (ky, kx, ci) counter replaces the divisions.
-template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
+template <typename T, int ROWS, int NTH = NT, bool LIMIT = false> struct ConvLoader {
     static constexpr bool kTrans = false;
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
@@ -282,15 +286,20 @@ template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
     int base_y[NCH], base_x[NCH], brow[NCH];  // oy*stride - pad (mode 0) or oy - pad (mode 1); b*Hin
     int ky[NCH], kx[NCH], ci[NCH];            // running tap / channel of the chunk's first element
     bool rvalid[NCH];
+    int tid0;         // index of the thread among the NTH threads that fill this image
+    int tiles_left;   // LIMIT: k-tiles this loader may still deliver (zeros afterwards)
     uint4 regs[PF][NCH];
 
-    __device__ __forceinline__ void init(const void* x, const ConvGeom& g_, int64_t r0, int64_t M, int64_t kt0) {
+    __device__ __forceinline__ void init(const void* x, const ConvGeom& g_, int64_t r0, int64_t M, int64_t kt0,
+                                         int tid = -1, int ntiles = 0x7fffffff) {
         X = (const T*)x;
         g = g_;
+        tid0 = tid < 0 ? (int)threadIdx.x : tid;
+        tiles_left = ntiles;
         vec_ok = ((g.Cin % EPV) == 0) && ((((uintptr_t)x) & 15) == 0);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NTH;
+            const int c = tid0 + i * NTH;
             const int64_t gm = r0 + (c / CPR);
             rvalid[i] = gm < M;
             const int hw = g.Hout * g.Wout;
@@ -335,7 +344,7 @@ template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
         for (int i = 0; i < NCH; ++i) {
             Vec16 v;
             v.u = make_uint4(0, 0, 0, 0);
-            if (rvalid[i] && ky[i] < g.KH) {
+            if (rvalid[i] && ky[i] < g.KH && (!LIMIT || tiles_left > 0)) {
                 if (vec_ok) {
                     const int off = src_off(i, ky[i], kx[i], ci[i]);
                     if (off >= 0) v.u = *(const uint4*)(X + off);
@@ -370,11 +379,12 @@ template <typename T, int ROWS, int NTH = NT> struct ConvLoader {
                 }
             }
         }
+        if (LIMIT) --tiles_left;
     }
     __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NTH;
+            const int c = tid0 + i * NTH;
             *(uint4*)(lds + (c / CPR) * ROWB + (c % CPR) * 16) = regs[slot][i];
         }
     }
@@ -523,6 +533,108 @@ __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// In-block split-K (experimental, COMAT_KSPLIT): KS groups of 4 waves share ONE 64x64 output tile.  Group g streams
+// its own contiguous slice of the k-range through its own LDS buffers (so a block keeps KS times as many loads in
+// flight and its serial k-loop is KS times shorter); at the end groups 1..KS-1 park their accumulators in LDS and
+// group 0 adds them in group order and runs the epilogue.  Same arithmetic as a global split-K of KS, without the
+// fp32 slab round trip through HBM and without the reduce launch.  All groups run the same number of iterations
+// (the loaders deliver zeros past a group's slice), so the block-wide barriers stay uniform.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, typename AL, typename BL, int KS>
+__device__ __forceinline__ void gemm_block_ks(AL& al, BL& bl, int64_t niter, int grp, int64_t m0, int64_t n0, int64_t M,
+                                              int64_t N, const Epi& ep, float* slab) {
+    typedef typename FragOf<T>::type F;
+    constexpr int OPB = 64 * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[KS][2][2][OPB];
+    static_assert(2 * 2 * OPB >= 64 * 64 * 4, "a group's LDS must hold its 64x64 fp32 partial tile");
+    char(*sm)[2][OPB] = smem[grp];
+
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < niter) {
+            al.load(u);
+            bl.load(u);
+        }
+    al.store(sm[0][0], 0);
+    bl.store(sm[0][1], 0);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t kt = 0; kt < niter; kt += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int64_t t = kt + u;
+            if (t < niter) {
+                if (t + PF < niter) {
+                    al.load(u);
+                    bl.load(u);
+                }
+                const char* la = sm[cur][0];
+                const char* lb = sm[cur][1];
+#pragma unroll
+                for (int s2 = 0; s2 < KTB / 32; ++s2) {
+                    const F af = read_frag<T, 64, AL::kTrans>(la, wr * 32 + r, s2, h);
+                    const F bf = read_frag<T, 64, BL::kTrans>(lb, wc * 32 + r, s2, h);
+                    mma(acc, af, bf);
+                }
+                if (t + 1 < niter) {
+                    al.store(sm[cur ^ 1][0], (u + 1) % PF);
+                    bl.store(sm[cur ^ 1][1], (u + 1) % PF);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+    }
+    // combine the groups' partial tiles in LDS, in group order (fixed summation order)
+    if (KS > 1) {
+        float* red = (float*)smem[grp];
+        if (grp > 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                red[(wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + wc * 32 + r] = acc[i];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g2 = 1; g2 < KS; ++g2) {
+            const float* rg = (const float*)smem[g2];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] += rg[(wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + wc * 32 + r];
+        }
+    }
+    const int64_t col = n0 + wc * 32 + r;
+    if (slab) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < M && col < N) slab[row * N + col] = acc[i];
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t row = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < M && col < N) {
+            float v = ep.alpha * acc[i];
+            if (ep.bias) v += ep.bias[col];
+            if (ep.bias2) v += ep.bias2[(row / ep.rows_per_b2) * N + col];
+            if (ep.act == COMAT_ACT_SILU) v = silu_f(v);
+            else if (ep.act == COMAT_ACT_GELU) v = gelu_f(v);
+            if (ep.R) v += ep.beta * ld_dt(ep.R, row * ep.ldr + col, ep.r_dt);
+            st_dt(ep.C, row * ep.ldc + col, v, ep.out_dt);
+        }
+    }
+}
+
 struct GemmArgs {
     const void* A;
     const void* B;
@@ -669,6 +781,66 @@ template <typename T, int BM, int BN, int NTH = NT> __global__ __launch_bounds__
                                                                                      g.ep, slab);
 }
 
+// in-block split-K variants of gemm_kernel / conv_kernel (64x64 tile, KS wave groups, NT*KS threads per block)
+template <typename T, bool TA, bool TB, int KS> __global__ __launch_bounds__(NT * KS) void gemm_ks_kernel(GemmArgs g) {
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n);
+    lin /= g.tiles_n;
+    const int tm = (int)(lin % g.tiles_m);
+    const int64_t z = lin / g.tiles_m, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
+    constexpr int BKE = KTB / (int)sizeof(T);
+    int64_t kt0, kt1;
+    split_range(g.K, BKE, g.splits, sp, kt0, kt1);
+    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    const T* A = (const T*)g.A + b1 * g.sA1 + b2 * g.sA2;
+    const T* B = (const T*)g.B + b1 * g.sB1 + b2 * g.sB2;
+    Epi ep = g.ep;
+    const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
+    ep.C = (char*)ep.C + coff * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    if (ep.R) ep.R = (const char*)ep.R + roff * (ep.r_dt == COMAT_F32 ? 4 : 2);
+    // this group's slice of the block's k-range
+    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
+    const int64_t gk0 = kt0 + grp * per;
+    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
+    if (gk1 < gk0) gk1 = gk0;
+    int64_t klim = gk1 * BKE < g.K ? gk1 * BKE : g.K;  // the loaders deliver zeros from here on
+    if (gk1 == gk0) klim = 0;
+    PlainLoader<T, 64, TA> al;
+    PlainLoader<T, 64, TB> bl;
+    al.init(A, g.lda, m0, g.M, klim, gk0, tid);
+    bl.init(B, g.ldb, n0, g.N, klim, gk0, tid);
+    gemm_block_ks<T, PlainLoader<T, 64, TA>, PlainLoader<T, 64, TB>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, ep, slab);
+}
+
+template <typename T, int KS> __global__ __launch_bounds__(NT * KS) void conv_ks_kernel(ConvArgs g) {
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    constexpr int BKE = KTB / (int)sizeof(T);
+    int64_t kt0, kt1;
+    split_range(g.K, BKE, g.splits, sp, kt0, kt1);
+    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
+    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
+    const int64_t gk0 = kt0 + grp * per;
+    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
+    if (gk1 < gk0) gk1 = gk0;
+    int64_t klim = gk1 * BKE < g.K ? gk1 * BKE : g.K;
+    if (gk1 == gk0) klim = 0;
+    ConvLoader<T, 64, NT, true> al;
+    PlainLoader<T, 64, false> bl;
+    al.init(g.X, g.geo, m0, g.M, gk0, tid, (int)(gk1 - gk0));
+    bl.init(g.W, g.K, n0, g.N, klim, gk0, tid);
+    gemm_block_ks<T, ConvLoader<T, 64, NT, true>, PlainLoader<T, 64, false>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, g.ep,
+                                                                                slab);
+}
+
 template <typename T, int BM, int BN, int NTH = NT>
 int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
     switch (trans) {
@@ -738,6 +910,23 @@ TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int
     return p;
 }
 
+// COMAT_KSPLIT=2|4 (experimental): turn (part of) a planned global split-K into an in-block split over KS wave groups
+int inblock_ksplit(int planned_splits) {
+    const char* e = getenv("COMAT_KSPLIT");
+    const int ks = e ? atoi(e) : 1;
+    if ((ks != 2 && ks != 4) || planned_splits < 2) return 1;
+    return (ks == 4 && planned_splits >= 4) ? 4 : 2;
+}
+
+template <typename T, int KS> void launch_gemm_ks(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
+    switch (trans) {
+        case 0: hipLaunchKernelGGL((gemm_ks_kernel<T, false, false, KS>), grid, dim3(NT * KS), 0, st, g); break;
+        case 1: hipLaunchKernelGGL((gemm_ks_kernel<T, true, false, KS>), grid, dim3(NT * KS), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_ks_kernel<T, false, true, KS>), grid, dim3(NT * KS), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_ks_kernel<T, true, true, KS>), grid, dim3(NT * KS), 0, st, g); break;
+    }
+}
+
 void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t batch2, int64_t sC1, int64_t sC2,
                    int64_t sR1, int64_t sR2, int splits, const Epi& ep, hipStream_t st) {
     ReduceArgs r;
@@ -780,14 +969,23 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int bm = (tile == 1 || tile == 2) && !bf ? 64 : plan.bm, bn = (tile == 1 || tile == 2) && !bf ? 64 : plan.bn;
     g.tiles_m = (int)cdiv64(p->M, bm);
     g.tiles_n = (int)cdiv64(p->N, bn);
-    g.splits = plan.splits;
+    const int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
     g.ws = (float*)p->ws;
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
-    if (bf) {
+    if (ks > 1) {
+        if (bf) {
+            if (ks == 4) launch_gemm_ks<bf16_t, 4>(g, trans, grid, st);
+            else launch_gemm_ks<bf16_t, 2>(g, trans, grid, st);
+        } else {
+            if (ks == 4) launch_gemm_ks<float, 4>(g, trans, grid, st);
+            else launch_gemm_ks<float, 2>(g, trans, grid, st);
+        }
+    } else if (bf) {
         if (bm == 128 && bn == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
         else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
         else if (bm == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 64, 512>(g, trans, grid, st);
@@ -891,13 +1089,22 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     const int bm = mixed && !bf ? 64 : plan.bm, bn = mixed && !bf ? 64 : plan.bn;
     g.tiles_m = (int)cdiv64(g.M, bm);
     g.tiles_n = (int)cdiv64(g.N, bn);
-    g.splits = plan.splits;
+    const int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
     g.ws = (float*)p->ws;
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (bf) {
+    if (ks > 1) {
+        if (bf) {
+            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
+            else hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
+        } else {
+            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<float, 4>), grid, dim3(NT * 4), 0, st, g);
+            else hipLaunchKernelGGL((conv_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
+        }
+    } else if (bf) {
         if (bm == 128 && bn == 128 && plan.nth == 512)
             hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
         else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);

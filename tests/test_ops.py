@@ -633,3 +633,41 @@ def test_block_tile_variants_match_default(hip, tile, monkeypatch):
         y.backward(dv(tok(g), hip, dtype))
         check(y, tok(yr), dtype, f"conv tile={tile} {Bn}x{H}x{W} {Cin}->{Cout} s={stride} ups={ups}")
         check(xd.grad, tok(xr.grad), dtype, f"conv dgrad tile={tile}", factor=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("COMAT_TEST_TILES") != "1",
+                    reason="experimental in-block split-K (not selected by default): run with COMAT_TEST_TILES=1")
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ks", ["2", "4"])
+def test_inblock_split_k_matches_reference(hip, ks, dtype, monkeypatch):
+    """COMAT_KSPLIT: wave groups of one block split the k-range of a 64x64 tile and combine in LDS.  Shapes are the
+    short-on-tiles / long-in-K kind that the planner splits (LoRA weight gradients, low-resolution projections and
+    convs), with ragged M / N / K and every operand layout."""
+    k = ops.kernels()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    monkeypatch.setenv("COMAT_KSPLIT", ks)
+    for (M, N, K_, tA, tB) in ((320, 128, 8192, True, True), (130, 70, 4100, False, False), (512, 1280, 1280, False, False),
+                               (64, 64, 1000, False, True), (200, 136, 2055, True, False), (2048, 640, 640, False, False)):
+        A = rnd(*((K_, M) if tA else (M, K_)), dtype=dtype, seed=1, scale=0.5)
+        B = rnd(*((K_, N) if tB else (N, K_)), dtype=dtype, seed=2, scale=0.5)
+        bias, R = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
+        out = torch.empty((M, N), dtype=torch.float32, device=hip)
+        k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M if tA else K_, N if tB else K_, N, transA=tA,
+               transB=tB, bias=dv(bias, hip), R=dv(R, hip, dtype), ldr=N, beta=1.0, alpha=0.25)
+        ref = 0.25 * ((A.t() if tA else A) @ (B if tB else B.t())) + bias + R
+        check(out, ref, dtype, f"gemm ks={ks} M={M} N={N} K={K_} tA={tA} tB={tB}")
+    for (Bn, H, W, Cin, Cout, stride) in ((2, 8, 8, 320, 200, 1), (2, 16, 16, 256, 128, 1), (1, 16, 16, 128, 136, 2)):
+        x = rnd(Bn, Cin, H, W, dtype=dtype, seed=5)
+        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=6, scale=(9 * Cin) ** -0.5)
+        b = rnd(Cout, seed=7)
+        conv = ops.FrozenConv(w, b, dtype, hip, stride=stride, pad=1)
+        xd = dv(tok(x), hip, dtype, grad=True)
+        y = ops.conv2d(xd, conv, Bn, H, W)
+        xr = x.clone().requires_grad_(True)
+        yr = F.conv2d(xr, w, b, stride=stride, padding=1)
+        g = rnd(*yr.shape, dtype=dtype, seed=8)
+        yr.backward(g)
+        y.backward(dv(tok(g), hip, dtype))
+        check(y, tok(yr), dtype, f"conv ks={ks} {Bn}x{H}x{W} {Cin}->{Cout} s={stride}")
+        check(xd.grad, tok(xr.grad), dtype, f"conv dgrad ks={ks}", factor=2)
