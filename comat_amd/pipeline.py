@@ -72,8 +72,10 @@ class TrainableSDPipeline:
         # only for forwards that also capture attention maps).  History: an early build raised a hardware exception
         # in the second optimisation step when graphs and attribute-concentration steps were combined; it has not
         # reproduced since the attention-map gather kernel was rewritten (fixed-order, no atomics) — see DESIGN.md.
+        # SDXL (prompt-dependent time embedding = an extra graph input): implemented, not yet validated on a GPU ->
+        # opt-in through COMAT_SDXL_GRAPHS=1
         use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
-                      and not unet.cfg.addition_embed)
+                      and (not unet.cfg.addition_embed or os.environ.get("COMAT_SDXL_GRAPHS") == "1"))
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
 
     def prepare_graphs(self, batch_size, height, width, L, num_inference_steps):
@@ -85,8 +87,11 @@ class TrainableSDPipeline:
         B = 2 * batch_size
         x = torch.zeros((B * h * w, self.unet.cfg.in_channels), dtype=self.dtype, device=self.device)
         ctx = torch.zeros((B * L, self.unet.cfg.cross_attention_dim), dtype=self.dtype, device=self.device)
+        added = None
+        if self.unet.cfg.addition_embed:
+            added = torch.zeros((B, self.unet.cfg.time_embed_dim), dtype=self.dtype, device=self.device)
         for t in self.scheduler.set_timesteps(num_inference_steps):
-            self.graphed(x, B, h, w, int(t), ctx, L)
+            self.graphed(x, B, h, w, int(t), ctx, L, added=added)
         torch.cuda.synchronize()
         return len(self.graphed.graphs)
 
@@ -121,7 +126,8 @@ class TrainableSDPipeline:
             if add_time_ids is None:
                 add_time_ids = (height, width, 0, 0, height, width)  # original_size + crop_top_left + target_size
             text_embeds = torch.cat([negative_pooled_prompt_embeds, pooled_prompt_embeds]).to(dev, torch.float32)
-            added = (text_embeds, [list(add_time_ids)] * (2 * bs))
+            # prompt-level constant: computed once here, shared by every denoise step (and a graph input)
+            added = self.unet.added_embedding(text_embeds, [list(add_time_ids)] * (2 * bs))
         timesteps = self.scheduler.set_timesteps(num_inference_steps)
         lat, h, w = self.prepare_latents(bs, height, width, generator, latents)
         training_timesteps = list(training_timesteps)
@@ -142,7 +148,7 @@ class TrainableSDPipeline:
                 graph_ok = not attrcon_train_steps or os.environ.get("COMAT_GRAPHS_ATTRCON", "1") != "0"
                 if (not train and self.graphed is not None and graph_ok
                         and not torch.cuda.is_current_stream_capturing()):
-                    eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L), {}
+                    eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L, added=added), {}
                 else:
                     eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added,
                                            kv_cache=kv_cache)

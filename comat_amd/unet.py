@@ -43,6 +43,10 @@ def attention_groups(path):
     return ATTN1_GROUPS if path.endswith("attn1") else ATTN2_GROUPS
 
 
+def _capturing(device):
+    return torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
 class LoRABank(ops.LoRAStore):
     """The LoRA factors of one UNet (training_utils/pipeline.py:84-144: rank-r LoRALinearLayers on to_q / to_k / to_v
     / to_out.0 of every Attention; the same parameter set, keyed by the same names) in the flat-buffer store of
@@ -203,37 +207,52 @@ class UNet:
         self.norm_out = m.norm("conv_norm_out")
         self.conv_out = m.conv("conv_out")
         self._temb_cache = {}
+        self._te_cache = {}
 
-    def _time_embedding(self, t, B, added):
-        """{"silu_temb": SiLU(emb)} plus, lazily, each ResBlock's projection of it.  SD1.5: depends on (t, batch)
-        and frozen weights only -> memoised.  SDXL: emb = temb(t) + add_embedding([pooled text | sinusoid(time_ids)])
-        (TrainableSDPipeline.py:772-784,807) depends on the prompt -> recomputed per call."""
+    def added_embedding(self, text_embeds, time_ids):
+        """SDXL `text_time` conditioning (TrainableSDPipeline.py:772-784,807): add_embedding([pooled text |
+        sinusoid(time_ids)]) -> [B, time_embed_dim] in the compute dtype.  It depends on the prompt only, not on the
+        timestep: the sampler computes it ONCE per call and hands it to every UNet call (and to the captured graphs
+        as an input buffer).  text_embeds: [B, pooled] tensor; time_ids: [B, 6] host values."""
         cfg = self.cfg
-        if not cfg.addition_embed:
-            temb_act = self._temb_cache.get((int(t), B))
-            if temb_act is not None:
-                return temb_act
+        B = text_embeds.shape[0]
         with torch.no_grad():
-            te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
-            te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
-            if not cfg.addition_embed:
-                temb_act = {"silu_temb": ops.linear(te, self.t2, act=ops.ACT_SILU)}
-                if len(self._temb_cache) < 128:
-                    self._temb_cache[(int(t), B)] = temb_act
-                return temb_act
-            text_embeds, time_ids = added  # [B, pooled] device tensor, [B, 6] host values
             tid = np.concatenate([timestep_embedding(float(v), cfg.addition_time_embed_dim, 1).numpy()
                                   for v in np.asarray(time_ids, dtype=np.float32).reshape(-1)], axis=1)
             tid = torch.from_numpy(tid.reshape(B, -1)).to(self.device)
             add = ops.concat_cols(ops.cast(text_embeds.to(self.device), self.dtype), ops.cast(tid, self.dtype))
-            aug = ops.linear(ops.linear(add, self.a1, act=ops.ACT_SILU), self.a2)
+            return ops.linear(ops.linear(add, self.a1, act=ops.ACT_SILU), self.a2)
+
+    def _time_embedding(self, t, B, added):
+        """{"silu_temb": SiLU(emb)} plus, lazily, each ResBlock's projection of it.  SD1.5: depends on (t, batch)
+        and frozen weights only -> memoised.  SDXL: emb = temb(t) + added_embedding(prompt): the timestep half is
+        memoised, the sum and the ResBlock projections are recomputed per call (they depend on the prompt)."""
+        cfg = self.cfg
+        key = (int(t), B)
+        if not cfg.addition_embed:
+            temb_act = self._temb_cache.get(key)
+            if temb_act is not None:
+                return temb_act
+        with torch.no_grad():
+            te = self._te_cache.get(key) if cfg.addition_embed else None
+            if te is None:
+                te = timestep_embedding(t, cfg.block_out_channels[0], B).to(self.device)
+                te = ops.linear(ops.cast(te, self.dtype), self.t1, act=ops.ACT_SILU)
+                if cfg.addition_embed and len(self._te_cache) < 128 and not _capturing(self.device):
+                    self._te_cache[key] = te
+            if not cfg.addition_embed:
+                temb_act = {"silu_temb": ops.linear(te, self.t2, act=ops.ACT_SILU)}
+                if len(self._temb_cache) < 128:
+                    self._temb_cache[key] = temb_act
+                return temb_act
+            aug = added if torch.is_tensor(added) else self.added_embedding(*added)
             emb = ops.linear(te, self.t2, residual=aug)
             return {"silu_temb": ops.silu(emb)}
 
     def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=(), added=None, kv_cache=None):
         """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
         maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}.
-        SDXL: added = (text_embeds [B, pooled], time_ids [B, 6]).
+        SDXL: added = (text_embeds [B, pooled], time_ids [B, 6]), or the precomputed `added_embedding(...)` tensor.
         kv_cache: a dict owned by the caller for ONE sampler invocation (LoRA factors and `ctx` must not change while
         it lives): the cross-attention key / value projections of `ctx` are computed once and shared by its calls."""
         cfg = self.cfg
@@ -284,25 +303,31 @@ class GraphedUNetForward:
         self.unet = unet
         self.graphs = {}
 
-    def __call__(self, x, B, H, W, t, ctx, L):
+    def __call__(self, x, B, H, W, t, ctx, L, added=None):
+        """`added`: SDXL only — the precomputed UNet.added_embedding(...) tensor (a graph input like x and ctx)."""
         key = (int(t), B, H, W, L)
         ent = self.graphs.get(key)
         if ent is None:
             u = self.unet
             sx, sc = torch.empty_like(x), torch.empty_like(ctx)
+            sa = None if added is None else torch.empty_like(added)
             sx.copy_(x)
             sc.copy_(ctx)
+            if sa is not None:
+                sa.copy_(added)
             with torch.no_grad():
-                u(sx, B, H, W, t, sc, L)  # eager warm-up: fills the temb memo, LoRA compute copy, split-K workspace
+                u(sx, B, H, W, t, sc, L, added=sa)  # eager warm-up: temb memo, LoRA compute copy, split-K workspace
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    out, _ = u(sx, B, H, W, t, sc, L)
-            ent = self.graphs[key] = (g, sx, sc, out)
-        g, sx, sc, out = ent
+                    out, _ = u(sx, B, H, W, t, sc, L, added=sa)
+            ent = self.graphs[key] = (g, sx, sc, sa, out)
+        g, sx, sc, sa, out = ent
         k = ops.kernels()
         k.unary(ops.UN_COPY, x, sx, x.numel())
         k.unary(ops.UN_COPY, ctx, sc, ctx.numel())
+        if sa is not None:
+            k.unary(ops.UN_COPY, added, sa, added.numel())
         if self.unet.lora is not None:
             self.unet.lora.ensure_compute_copy()
         g.replay()

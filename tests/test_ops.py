@@ -596,8 +596,8 @@ def test_adamw_with_clip(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("COMAT_TEST_TILES") != "1",
-                    reason="experimental block tiles (not selected by default): run with COMAT_TEST_TILES=1")
+@pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
+                    reason="experimental block tiles (not selected by default): run with COMAT_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("tile", ["64", "128", "12864", "64128", "1288", "128648"])
 def test_block_tile_variants_match_default(hip, tile, monkeypatch):
     """Every COMAT_FORCE_TILE block-tile variant of the GEMM / conv kernels (4 or 8 waves per block) reproduces the
@@ -636,8 +636,8 @@ def test_block_tile_variants_match_default(hip, tile, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("COMAT_TEST_TILES") != "1",
-                    reason="experimental in-block split-K (not selected by default): run with COMAT_TEST_TILES=1")
+@pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
+                    reason="experimental in-block split-K (not selected by default): run with COMAT_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ks", ["2", "4"])
 def test_inblock_split_k_matches_reference(hip, ks, dtype, monkeypatch):

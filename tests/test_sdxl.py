@@ -99,3 +99,33 @@ def test_sdxl_attrcon_sampler(dev, dtype):
     check(img, img_o, dtype, "raw image (no /2+0.5)", factor=f)
     total = rel_l2(bank.flat_grad, torch.cat([lo[n].grad.reshape(-1) for n in bank.names]))
     assert total < (1e-3 if dtype == torch.float32 else 0.15), f"LoRA grad rel-L2 {total:.3e}"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(__import__("os").environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
+                    reason="SDXL graph replay is opt-in (COMAT_SDXL_GRAPHS=1) until validated: COMAT_TEST_EXPERIMENTAL=1")
+def test_sdxl_graphed_nograd_unet_matches_eager(hip):
+    """hipGraph replay of the SDXL no-grad UNet forward with the prompt embedding as a graph INPUT: replays with
+    different latents / text / pooled embeddings match eager launches bit for bit, with one captured graph."""
+    from comat_amd.unet import GraphedUNetForward
+    dtype = torch.bfloat16
+    usd, _, lsd, _, _ = world(dtype)
+    bank = LoRABank(UCFG, lsd, dtype, hip)
+    unet = UNet(UCFG, usd, dtype, hip, bank)
+    gu = GraphedUNetForward(unet)
+    B, h, w, L = 2, 8, 8, 7
+    time_ids = [[64.0, 64.0, 0.0, 0.0, 64.0, 64.0]] * B
+    for it in range(3):
+        x = tok(rnd(B, 4, h, w, seed=40 + it, dtype=dtype)).to(hip, dtype)
+        ctx = rnd(B * L, UCFG.cross_attention_dim, seed=50 + it, dtype=dtype).to(hip, dtype)
+        pooled = rnd(B, UCFG.pooled_dim, seed=60 + it, dtype=dtype).to(hip)
+        with torch.no_grad():
+            aug = unet.added_embedding(pooled, time_ids)
+            ref, _ = unet(x, B, h, w, 334, ctx, L, added=aug)
+            ref2, _ = unet(x, B, h, w, 334, ctx, L, added=(pooled, time_ids))
+            got = gu(x, B, h, w, 334, ctx, L, added=aug).clone()
+        assert torch.equal(ref, ref2), "precomputed added embedding == tuple form"
+        assert torch.equal(got, ref), f"iteration {it}: graph replay != eager"
+        bank.flat.mul_(1.01)
+        bank.mark_updated()
+    assert len(gu.graphs) == 1
