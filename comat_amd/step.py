@@ -5,9 +5,9 @@
     gradient -> clip(0.1) + AdamW (one fused pass)  ||  D step: D_loss on [fake.detach(); real] -> backward ->
     all-reduce -> clip(1.0) + AdamW.
 
-MI355X-first scheduling: the G-gradient all-reduce (RCCL over xGMI) is launched asynchronously right after
-G-backward and overlaps the whole D forward/backward; the per-step barrier of the reference
-(training_script.py:716) is dropped.  Optimizer state lives in flat fp32 buffers next to the flat parameter and
+MI355X-first scheduling: the D step runs on its own HIP stream under the G backward chain; the G-gradient all-reduce
+(RCCL over xGMI) is launched asynchronously as soon as the G backward is queued and overlaps the tail of the D step;
+the per-step barrier of the reference (training_script.py:716) is dropped.  Optimizer state lives in flat fp32 buffers next to the flat parameter and
 gradient buffers, so clip + AdamW is one HBM pass per buffer.
 """
 from __future__ import annotations
@@ -21,7 +21,7 @@ import torch
 
 from . import ops
 from .blip import Blip
-from .dist import GradReducer, world_size
+from .dist import GradReducer
 from .gan import D_sd
 from .losses import mask_loss
 from .pipeline import TrainableSDPipeline
@@ -116,6 +116,7 @@ class CoMatTrainer:
         self.reducer = GradReducer()
         self.device = torch.device(pipeline.device)
         self._d_stream = None
+        self._d_pending = False
 
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
@@ -205,15 +206,19 @@ class CoMatTrainer:
                 logs["D_loss"] = self._d_step(out, batch)
         out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
         _dbg("G backward")
-        if concurrent:
-            main.wait_stream(self._d_stream)
-        elif cfg.gan_loss:
+        self._d_pending = concurrent  # joined in _apply_updates, after the G all-reduce has been launched
+        if not concurrent and cfg.gan_loss:
             logs["D_loss"] = self._d_step(out, batch)
         return logs
 
     def _apply_updates(self):
-        """all-reduce(mean) of the flat gradient buffers (RCCL, async) + clip + AdamW for G and D."""
+        """all-reduce(mean) of the flat gradient buffers (RCCL, async) + clip + AdamW for G and D.  The G all-reduce is
+        launched as soon as the G backward is queued, i.e. before the concurrently running D step is joined: on
+        several GPUs it overlaps the tail of the D step; the D buffers follow once that stream has been joined."""
         self.reducer.start(self.bank.flat_grad)
+        if self._d_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self._d_stream)
+            self._d_pending = False
         if self.cfg.gan_loss:
             self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
         self.reducer.finish()
@@ -225,40 +230,9 @@ class CoMatTrainer:
 
     def train_step(self, batch, **fixed):
         """Full step: G forward/backward, D forward/backward, gradient exchange, G and D updates.  Returns a dict of
-        detached device scalars (no host sync here) plus `training_steps` / `crop`."""
-        if world_size() > 1:
-            # multi-GPU: start the G all-reduce right after G-backward so that it overlaps the whole D step
-            return self._train_step_overlapped(batch, fixed)
+        detached device scalars (no host sync here) plus `training_steps` / `crop`.  The same schedule serves one GPU
+        and data-parallel runs (the exchange is a no-op in a single-process run)."""
         logs = self._forward_backward(batch, fixed)
         self._apply_updates()
         logs["training_steps"], logs["crop"] = self._last
-        return logs
-
-    def _train_step_overlapped(self, batch, fixed):
-        cfg = self.cfg
-        self.bank.set_requires_grad(True)
-        self.bank.zero_grad()
-        out = self.compute_losses(batch, **fixed)
-        out["loss"].backward()
-        self.reducer.start(self.bank.flat_grad)  # async RCCL all-reduce; overlaps the D step below
-        logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
-        logs["step_loss"] = out["loss"].detach()
-        logs["training_steps"], logs["crop"] = out["training_steps"], out["crop"]
-        if cfg.gan_loss:
-            h = w = cfg.resolution // 8
-            self.D.zero_grad()
-            real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
-            D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
-                                                  negative_prompt_embeds=batch["gan_null_embeds"],
-                                                  num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
-            D_loss.backward()
-            logs["D_loss"] = D_loss.detach()
-        self.reducer.finish()
-        self.opt.step()
-        self.bank.mark_updated()
-        if cfg.gan_loss:
-            self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
-            self.reducer.finish()
-            self.opt_D.step()
-            self.D.bank.mark_updated()
         return logs
