@@ -727,6 +727,7 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_seg_kernel(Gemm
     gemm_block<T, 64, 64>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
 }
 
+#ifndef COMAT_GEMM_EXP_TU  // the reduce pass is launched by the default translation unit only
 // sums the split-K slabs and applies the fused epilogue: C = act(alpha*sum + bias + bias2) + beta*R
 struct ReduceArgs {
     const float* ws;
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(NT) void splitk_reduce_kernel(ReduceArgs g) {
         st_dt(g.ep.C, coff + row * g.ep.ldc + col, v, g.ep.out_dt);
     }
 }
+#endif
 
 struct ConvArgs {
     const void* X;
@@ -927,6 +929,7 @@ template <typename T, int KS> void launch_gemm_ks(const GemmArgs& g, int trans, 
     }
 }
 
+#ifndef COMAT_GEMM_EXP_TU
 void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t batch2, int64_t sC1, int64_t sC2,
                    int64_t sR1, int64_t sR2, int splits, const Epi& ep, hipStream_t st) {
     ReduceArgs r;
@@ -936,8 +939,71 @@ void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)batch), dim3(NT), 0, st, r);
 }
+#endif
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// Experimental kernel variants (non-default block tiles, 8-wave blocks, in-block split-K) are instantiated in a second
+// translation unit — gemm_exp.hip compiles this file with COMAT_GEMM_EXP_TU defined — so that the two halves build in
+// parallel.  The argument structs live in the anonymous namespace of each unit (same source, same layout), hence the
+// `const void*` hand-over.
+// ---------------------------------------------------------------------------------------------------------------
+bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
+                               void* stream);
+bool comat_conv_launch_variant(const void* cargs, int bf, int bm, int bn, int nth, int ks, unsigned tiles, void* stream);
+
+#ifdef COMAT_GEMM_EXP_TU
+
+bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
+                               void* stream) {
+    const GemmArgs& g = *(const GemmArgs*)gargs;
+    dim3 grid(tiles, 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (ks > 1) {
+        if (bf) {
+            if (ks == 4) launch_gemm_ks<bf16_t, 4>(g, trans, grid, st);
+            else launch_gemm_ks<bf16_t, 2>(g, trans, grid, st);
+        } else {
+            launch_gemm_ks<float, 2>(g, trans, grid, st);
+        }
+        return true;
+    }
+    if (!bf) return false;
+    if (bm == 128 && bn == 128 && nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
+    else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
+    else if (bm == 128 && nth == 512) launch_gemm_t<bf16_t, 128, 64, 512>(g, trans, grid, st);
+    else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
+    else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
+    else return false;
+    return true;
+}
+
+bool comat_conv_launch_variant(const void* cargs, int bf, int bm, int bn, int nth, int ks, unsigned tiles, void* stream) {
+    const ConvArgs& g = *(const ConvArgs*)cargs;
+    dim3 grid(tiles, 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (ks > 1) {
+        if (bf) {
+            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
+            else hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
+        } else {
+            hipLaunchKernelGGL((conv_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
+        }
+        return true;
+    }
+    if (!bf) return false;
+    if (bm == 128 && bn == 128 && nth == 512)
+        hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
+    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
+    else if (bm == 128 && nth == 512) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64, 512>), grid, dim3(512), 0, st, g);
+    else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
+    else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
+    else return false;
+    return true;
+}
+
+#else  // the default translation unit: entry points + the default (64x64, 4 waves) kernels
 
 extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p != nullptr, "comat_gemm: null params");
@@ -966,10 +1032,12 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const TilePlan plan = plan_tiles(p->M, p->N, p->K, bke, batch, p->ws ? p->ws_bytes : 0);
     const bool bf = p->in_dtype == COMAT_BF16;
     const int tile = (plan.bm == 128 ? 2 : 0) | (plan.bn == 128 ? 1 : 0);  // 0: 64x64, 1: 64x128, 2: 128x64, 3: 128x128
-    const int bm = (tile == 1 || tile == 2) && !bf ? 64 : plan.bm, bn = (tile == 1 || tile == 2) && !bf ? 64 : plan.bn;
+    (void)tile;
+    const int bm = bf ? plan.bm : 64, bn = bf ? plan.bn : 64;  // the larger tiles exist for bf16 only
     g.tiles_m = (int)cdiv64(p->M, bm);
     g.tiles_n = (int)cdiv64(p->N, bn);
-    const int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    if (!bf && ks > 2) ks = 2;  // fp32 (parity mode): two wave groups at most
     g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
@@ -977,24 +1045,14 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
-    if (ks > 1) {
-        if (bf) {
-            if (ks == 4) launch_gemm_ks<bf16_t, 4>(g, trans, grid, st);
-            else launch_gemm_ks<bf16_t, 2>(g, trans, grid, st);
-        } else {
-            if (ks == 4) launch_gemm_ks<float, 4>(g, trans, grid, st);
-            else launch_gemm_ks<float, 2>(g, trans, grid, st);
-        }
+    const bool variant = ks > 1 || bm != 64 || bn != 64;
+    if (variant) {
+        COMAT_REQUIRE(comat_gemm_launch_variant(&g, bf ? 1 : 0, trans, bm, bn, plan.nth, ks, (unsigned)tiles, stream),
+                      "comat_gemm: unsupported kernel variant");
     } else if (bf) {
-        if (bm == 128 && bn == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
-        else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
-        else if (bm == 128 && plan.nth == 512) launch_gemm_t<bf16_t, 128, 64, 512>(g, trans, grid, st);
-        else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
-        else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
-        else launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
+        launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
     } else {
-        if (bm == 128) launch_gemm_t<float, 128, 128>(g, trans, grid, st);
-        else launch_gemm_t<float, 64, 64>(g, trans, grid, st);
+        launch_gemm_t<float, 64, 64>(g, trans, grid, st);
     }
     if (g.splits > 1)
         launch_reduce(g.ws, p->M, p->N, batch, p->batch2, p->sC1, p->sC2, p->sR1, p->sR2, g.splits, g.ep, st);
@@ -1085,38 +1143,28 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
     const TilePlan plan = plan_tiles(g.M, g.N, g.K, bke, 1, p->ws ? p->ws_bytes : 0);
     const bool bf = p->in_dtype == COMAT_BF16;
-    const bool mixed = plan.bm != plan.bn;
-    const int bm = mixed && !bf ? 64 : plan.bm, bn = mixed && !bf ? 64 : plan.bn;
+    const int bm = bf ? plan.bm : 64, bn = bf ? plan.bn : 64;  // the larger tiles exist for bf16 only
     g.tiles_m = (int)cdiv64(g.M, bm);
     g.tiles_n = (int)cdiv64(g.N, bn);
-    const int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
+    if (!bf && ks > 2) ks = 2;
     g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
     g.ws = (float*)p->ws;
     dim3 grid((unsigned)tiles, 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (ks > 1) {
-        if (bf) {
-            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
-            else hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
-        } else {
-            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<float, 4>), grid, dim3(NT * 4), 0, st, g);
-            else hipLaunchKernelGGL((conv_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
-        }
+    const bool variant = ks > 1 || bm != 64 || bn != 64;
+    if (variant) {
+        COMAT_REQUIRE(comat_conv_launch_variant(&g, bf ? 1 : 0, bm, bn, plan.nth, ks, (unsigned)tiles, stream),
+                      "comat_conv2d: unsupported kernel variant");
     } else if (bf) {
-        if (bm == 128 && bn == 128 && plan.nth == 512)
-            hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
-        else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
-        else if (bm == 128 && plan.nth == 512)
-            hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64, 512>), grid, dim3(512), 0, st, g);
-        else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
-        else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
-        else hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);
+        hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);
     } else {
-        if (bm == 128) hipLaunchKernelGGL((conv_kernel<float, 128, 128>), grid, dim3(NT), 0, st, g);
-        else hipLaunchKernelGGL((conv_kernel<float, 64, 64>), grid, dim3(NT), 0, st, g);
+        hipLaunchKernelGGL((conv_kernel<float, 64, 64>), grid, dim3(NT), 0, st, g);
     }
     if (g.splits > 1) launch_reduce(g.ws, g.M, g.N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
     return comat_check_launch("comat_conv2d");
 }
+
+#endif  // COMAT_GEMM_EXP_TU
