@@ -10,6 +10,8 @@ Tokenisation is outside the hot path: `score` takes input ids.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -46,9 +48,15 @@ class _PrependClassToken(Function):
 
 
 class Blip:
-    def __init__(self, cfg: BlipConfig, sd: dict, dtype=torch.bfloat16, device="cuda"):
+    def __init__(self, cfg: BlipConfig, sd: dict, dtype=torch.bfloat16, device="cuda", fused_qkv=None):
         self.cfg, self.dtype, self.device = cfg, dtype, device
         T = dtype
+        # ViT q/k/v as one GEMM + strided fused attention (ops.fused_qkv_attention): implemented, not yet validated
+        # on a GPU -> opt-in (COMAT_BLIP_FUSED_QKV=1 or fused_qkv=True)
+        if fused_qkv is None:
+            fused_qkv = os.environ.get("COMAT_BLIP_FUSED_QKV") == "1"
+        hd = cfg.v_hidden // cfg.v_heads
+        self.fused_qkv = bool(fused_qkv) and ops.flash_ok(hd, dtype)
 
         def lin(name):
             return ops.FrozenLinear(sd[name + ".weight"], sd.get(name + ".bias"), T, device)
@@ -68,7 +76,10 @@ class Blip:
         for i in range(cfg.v_layers):
             L = f"{v}encoder.layers.{i}."
             wqkv, bqkv = sd[L + "self_attn.qkv.weight"], sd[L + "self_attn.qkv.bias"]
-            qkv = [ops.FrozenLinear(wqkv[j * d:(j + 1) * d], bqkv[j * d:(j + 1) * d], T, device) for j in range(3)]
+            if self.fused_qkv:  # one Linear(d -> 3d), as the checkpoint stores it
+                qkv = ops.FrozenLinear(wqkv, bqkv, T, device)
+            else:
+                qkv = [ops.FrozenLinear(wqkv[j * d:(j + 1) * d], bqkv[j * d:(j + 1) * d], T, device) for j in range(3)]
             self.vlayers.append(dict(ln1=norm(L + "layer_norm1"), qkv=qkv, proj=lin(L + "self_attn.projection"),
                                      ln2=norm(L + "layer_norm2"), fc1=lin(L + "mlp.fc1"), fc2=lin(L + "mlp.fc2")))
         self.post_ln = norm(v + "post_layernorm")
@@ -119,8 +130,11 @@ class Blip:
         h = ops.add_rowvec(h.reshape(B, N * d), self.pos[: N * d]).reshape(B * N, d)
         for Lr in self.vlayers:
             x = ops.layer_norm(h, *Lr["ln1"], eps=cfg.v_eps)
-            q, k, v = (ops.linear(x, w) for w in Lr["qkv"])
-            o, _ = ops.attention(q, k, v, B, N, N, nh, d // nh, need_probs=False)
+            if self.fused_qkv:
+                o = ops.fused_qkv_attention(x, Lr["qkv"], B, N, nh)
+            else:
+                q, k, v = (ops.linear(x, w) for w in Lr["qkv"])
+                o, _ = ops.attention(q, k, v, B, N, N, nh, d // nh, need_probs=False)
             h = ops.linear(o, Lr["proj"], residual=h)
             x = ops.layer_norm(h, *Lr["ln2"], eps=cfg.v_eps)
             h = ops.linear(ops.gelu(ops.linear(x, Lr["fc1"])), Lr["fc2"], residual=h)

@@ -824,6 +824,55 @@ def flash_ok(dim, dtype):
     return dim <= 160 and dim % (8 if dtype == torch.bfloat16 else 4) == 0
 
 
+class _FusedQKVAttention(Function):
+    """Self-attention whose q / k / v projections are one frozen Linear(d -> 3d) (BLIP's ViT, modeling_blip
+    BlipAttention.qkv): ONE GEMM writes [M, 3D], the fused attention kernels read q / k / v as column slices of it
+    (leading dimension 3D), the backward kernels write dQ / dK / dV into the column slices of one [M, 3D] buffer and
+    ONE GEMM (K = 3D) turns it into the input gradient — 2 launches instead of 6, no gradient-accumulation adds."""
+
+    @staticmethod
+    def forward(ctx, x, lin, B, N, H, d, scale):
+        x = _c(x)
+        M, Kd = x.shape
+        D = H * d
+        assert lin.out_features == 3 * D
+        k = kernels()
+        qkv = x.new_empty((M, 3 * D))
+        k.gemm(x, lin.w, qkv, M, 3 * D, Kd, Kd, Kd, 3 * D, bias=lin.bias)
+        O = x.new_empty((M, D))
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=x.device)
+        k.flash_attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], O, lse, B, H, N, N, d, 3 * D, 3 * D, 3 * D, D, scale)
+        ctx.save_for_backward(qkv, O, lse)
+        ctx.cfg = (lin, B, N, H, d, scale, Kd)
+        return O
+
+    @staticmethod
+    def backward(ctx, gO):
+        qkv, O, lse = ctx.saved_tensors
+        lin, B, N, H, d, scale, Kd = ctx.cfg
+        D = H * d
+        M = qkv.shape[0]
+        k = kernels()
+        gO = _c(gO)
+        dqkv = torch.empty_like(qkv)
+        dbuf = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        k.flash_attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], O, gO, lse, dbuf, dqkv[:, :D], dqkv[:, D:2 * D],
+                         dqkv[:, 2 * D:], B, H, N, N, d, 3 * D, 3 * D, 3 * D, D, scale)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = qkv.new_empty((M, Kd))
+            k.gemm(dqkv, lin.wt, dx, M, Kd, 3 * D, 3 * D, 3 * D, Kd)
+        return dx, None, None, None, None, None, None
+
+
+def fused_qkv_attention(x, lin_qkv: "FrozenLinear", B, N, heads, scale=None):
+    """x: [B*N, in] -> attention output [B*N, heads*dim] with q, k, v = split(x W_qkv^T + b_qkv)."""
+    D = lin_qkv.out_features // 3
+    dim = D // heads
+    assert flash_ok(dim, x.dtype), "fused qkv attention needs a head dim the fused kernels support"
+    return _FusedQKVAttention.apply(x, lin_qkv, B, N, heads, dim, float(scale if scale is not None else dim ** -0.5))
+
+
 def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None, need_probs=True):
     """q: [B*Nq, heads*dim], k/v: [B*Nk, heads*dim] -> (out [B*Nq, heads*dim], probs [B, heads, Nq, Nk] or None).
     `need_probs=False` selects the fused kernel (no probability map in HBM) when the layer allows it."""

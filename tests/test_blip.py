@@ -64,3 +64,29 @@ def test_score_with_crop_matches_oracle(dev, dtype):
     check(reward, reward_o, dtype, "reward", factor=f)
     check(lp, lp_o, dtype, "token log-probs", factor=f)
     check(idv.grad, tok(io.grad), dtype, "d reward / d image", factor=3 * f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_qkv_vit_matches_split_projections(dev, dtype):
+    if dev.type == "cuda" and __import__("os").environ.get("COMAT_TEST_EXPERIMENTAL") != "1":
+        pytest.skip("fused-qkv ViT is opt-in until validated on a GPU: run with COMAT_TEST_EXPERIMENTAL=1")
+    """BLIP ViT with q/k/v as ONE GEMM + strided fused attention (opt-in) == the three-projection path: reward,
+    token log-probs and the gradient that flows back into the image."""
+    from comat_amd import config, weights
+    from comat_amd.blip import Blip
+    bsd = {k: v.to(dtype).float() for k, v in weights.make_blip_weights(config.TINY_BLIP, perturb_norms=True).items()}
+    g = torch.Generator().manual_seed(3)
+    B, S = 2, 40
+    img = torch.rand(B * S * S, 3, generator=g).to(dtype)
+    ids = torch.randint(1, config.TINY_BLIP.vocab_size, (B, 9), generator=g)
+    outs = []
+    for fused in (False, True):
+        blip = Blip(config.TINY_BLIP, bsd, dtype, dev, fused_qkv=fused)
+        assert blip.fused_qkv == fused
+        x = img.clone().to(dev).requires_grad_(True)
+        reward, logp = blip.score(x, B, S, S, ids, torch.ones_like(ids), crop=(1, 2, 36, 36), label_smoothing=0.1)
+        reward.backward()
+        outs.append((reward.detach().float().cpu(), logp.detach().float().cpu(), x.grad.float().cpu()))
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    for a, b, name in zip(outs[0], outs[1], ("reward", "token log-probs", "d reward / d image")):
+        assert (a - b).abs().max() <= tol * max(float(a.abs().max()), 1e-6), name
