@@ -18,6 +18,7 @@
 //   flash_dq    : same geometry as forward; dQ^T += K^T dS^T
 //   flash_dkdv  : block = 4 waves x 32 keys, loops over 32-query tiles; dV^T += dO^T P, dK^T += Q^T dS
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -117,12 +118,12 @@ template <typename T> __device__ __forceinline__ typename FragOf<T>::type pack_a
     return out;
 }
 // per-lane fragment (column = this lane's row of the global matrix, chunk 2s+hh of the head dim) straight from HBM
-template <typename T, int DMAX>
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
 __device__ __forceinline__ void load_col_frags(typename FragOf<T>::type* f, const T* base, int64_t ld, int row,
                                                int nrows, int d, int hh) {
     typedef Geo<T, DMAX> G;
 #pragma unroll
-    for (int s = 0; s < G::NKS; ++s) {
+    for (int s = 0; s < NK; ++s) {
         const int col = (2 * s + hh) * G::KC;
         V16 v;
         v.u = make_uint4(0, 0, 0, 0);
@@ -143,7 +144,9 @@ struct FlashArgs {
     float* part;   // [2][qsplit][B*H][Nk][d] fp32 partial dK / dV (qsplit > 1)
 };
 
-template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
+// NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+__global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
@@ -157,8 +160,8 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_
     T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
     const int q = blockIdx.x * 128 + wave * 32 + r;
 
-    F qf[G::NKS];
-    load_col_frags<T, DMAX>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    F qf[NK];
+    load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     f32x16_t oT[G::NT32];
 #pragma unroll
     for (int t = 0; t < G::NT32; ++t)
@@ -183,7 +186,7 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_fwd_
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < G::NKS; ++s) mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
+        for (int s = 0; s < NK; ++s) mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
         float mt = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -256,7 +259,9 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_prep_kernel(Fl
     a.Dbuf[((int64_t)b * a.H + h) * a.Nq + q] = acc;
 }
 
-template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
+// NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+__global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
@@ -270,9 +275,9 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_k
     const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
     T* dQb = (T*)a.dQ + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const int q = blockIdx.x * 128 + wave * 32 + r;
-    F qf[G::NKS], gf[G::NKS];
-    load_col_frags<T, DMAX>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
-    load_col_frags<T, DMAX>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
+    F qf[NK], gf[NK];
+    load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
     const float lse_q = q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
     const float D_q = q < a.Nq ? a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
     f32x16_t dqT[G::NT32];
@@ -297,7 +302,7 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_k
 #pragma unroll
         for (int i = 0; i < 16; ++i) { st[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < G::NKS; ++s) {
+        for (int s = 0; s < NK; ++s) {
             mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
             mma(dp, frag_kc<T, DMAX>(Vt, r, s, hh), gf[s]);
         }
@@ -330,7 +335,9 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dq_k
     }
 }
 
-template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
+// NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+__global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + 256];
@@ -347,9 +354,9 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv
     T* dKb = (T*)a.dK + (int64_t)b * a.Nk * a.ldk + h * a.d;
     T* dVb = (T*)a.dV + (int64_t)b * a.Nk * a.ldv + h * a.d;
     const int key = blockIdx.x * 128 + wave * 32 + r;
-    F kf[G::NKS], vf[G::NKS];
-    load_col_frags<T, DMAX>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
-    load_col_frags<T, DMAX>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
+    F kf[NK], vf[NK];
+    load_col_frags<T, DMAX, NK>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
+    load_col_frags<T, DMAX, NK>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
     f32x16_t dkT[G::NT32], dvT[G::NT32];
 #pragma unroll
     for (int t = 0; t < G::NT32; ++t)
@@ -391,7 +398,7 @@ template <typename T, int DMAX> __global__ __launch_bounds__(NT) void flash_dkdv
 #pragma unroll
         for (int i = 0; i < 16; ++i) { sc[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
-        for (int s = 0; s < G::NKS; ++s) {
+        for (int s = 0; s < NK; ++s) {
             mma(sc, frag_kc<T, DMAX>(Qt, r, s, hh), kf[s]);
             mma(dp, frag_kc<T, DMAX>(Gt, r, s, hh), vf[s]);
         }
@@ -463,14 +470,14 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kern
     stf<T>((T*)a.dV + ((int64_t)b * a.Nk + key) * a.ldv + h * a.d + n, sv);
 }
 
-template <typename T, int DMAX> void launch_fwd(const FlashArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS> void launch_fwd(const FlashArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
 }
-template <typename T, int DMAX> void launch_bwd(const FlashArgs& a, hipStream_t st) {
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS> void launch_bwd(const FlashArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.B * a.H * a.Nq;
     hipLaunchKernelGGL((flash_prep_kernel<T>), dim3((unsigned)cdiv64(total, NT)), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
     if (a.qsplit > 1) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
         hipLaunchKernelGGL((flash_kv_reduce_kernel<T>), dim3((unsigned)cdiv64(slab, NT)), dim3(NT), 0, st, a);
@@ -478,6 +485,21 @@ template <typename T, int DMAX> void launch_bwd(const FlashArgs& a, hipStream_t 
 }
 
 template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
+    // COMAT_FLASH_TRIM=1 (experimental): skip the MFMA k-steps whose head-dim chunk is pure zero padding (head dim 40
+    // in a 64-wide tile: 3 of 4 steps; 80 in 96: 5 of 6) — same sums, the skipped products are exactly zero
+    const char* e = getenv("COMAT_FLASH_TRIM");
+    const bool trim = e && atoi(e) == 1;
+    constexpr int KC2 = 2 * (16 / (int)sizeof(T));
+    if (trim && a.d > 32 && a.d <= 48) {
+        if (bwd) launch_bwd<T, 64, 48 / KC2>(a, st);
+        else launch_fwd<T, 64, 48 / KC2>(a, st);
+        return 0;
+    }
+    if (trim && a.d > 64 && a.d <= 80) {
+        if (bwd) launch_bwd<T, 96, 80 / KC2>(a, st);
+        else launch_fwd<T, 96, 80 / KC2>(a, st);
+        return 0;
+    }
 #define FA_CASE(D)                     \
     if (a.d <= D) {                    \
         if (bwd) launch_bwd<T, D>(a, st); \
