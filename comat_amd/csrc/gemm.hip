@@ -1038,7 +1038,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     g.tiles_n = (int)cdiv64(p->N, bn);
     int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
     if (!bf && ks > 2) ks = 2;  // fp32 (parity mode): two wave groups at most
-    g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
+    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;  // nearest: prefer no global reduce pass
+    if (g.splits < 1) g.splits = 1;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
     g.ws = (float*)p->ws;
@@ -1148,7 +1149,8 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     g.tiles_n = (int)cdiv64(g.N, bn);
     int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
     if (!bf && ks > 2) ks = 2;
-    g.splits = ks > 1 ? (int)cdiv64(plan.splits, ks) : plan.splits;
+    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;  // nearest: prefer no global reduce pass
+    if (g.splits < 1) g.splits = 1;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
     g.ws = (float*)p->ws;
