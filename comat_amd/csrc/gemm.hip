@@ -164,7 +164,8 @@ struct SegTable {
     int nseg;
 };
 
-template <typename T, int ROWS> struct SegLoader {
+// LIMIT: the loader delivers at most `total_left` k-tiles and zeros afterwards (a wave group's slice of the k-range)
+template <typename T, int ROWS, bool LIMIT = false> struct SegLoader {
     static constexpr bool kTrans = false;
     static constexpr int EPV = 16 / sizeof(T);
     static constexpr int BKE = KTB / sizeof(T);
@@ -175,6 +176,8 @@ template <typename T, int ROWS> struct SegLoader {
     int rleft[NCH];
     int lds_off[NCH];
     int K, seg, tiles_left;
+    int tid0;            // index of the thread among the NT threads that fill this image
+    int64_t total_left;  // LIMIT only
     int64_t zb;          // batch item
     bool vec_ok, is_b;
     uint4 regs[PF][NCH];
@@ -198,18 +201,22 @@ template <typename T, int ROWS> struct SegLoader {
         vec_ok = ((ld % EPV) == 0) && ((((uintptr_t)P) & 15) == 0);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int kv = (threadIdx.x + i * NT) % CPR;
+            const int kv = ((LIMIT ? tid0 : (int)threadIdx.x) + i * NT) % CPR;
             kpos[i] = toff * BKE + kv * EPV;
             ptr[i] = (const T*)P + grow[i] * ld + kpos[i];
         }
     }
     __device__ __forceinline__ void init(const SegTable& t, bool b_operand, int64_t r0, int64_t rmax, int64_t kt0,
-                                         int64_t z) {
+                                         int64_t z, int tid = -1, int64_t ntiles = 0) {
         is_b = b_operand;
         zb = z;
+        if (LIMIT) {
+            tid0 = tid < 0 ? (int)threadIdx.x : tid;
+            total_left = ntiles;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = threadIdx.x + i * NT;
+            const int c = (LIMIT ? tid0 : (int)threadIdx.x) + i * NT;
             const int row = c / CPR, kv = c % CPR;
             const int64_t gr = r0 + row;
             rleft[i] = gr < rmax ? 1 : 0;
@@ -235,7 +242,7 @@ template <typename T, int ROWS> struct SegLoader {
             Vec16 v;
             v.u = make_uint4(0, 0, 0, 0);
             const T* src = ptr[i];
-            if (rleft[i] && kpos[i] < K) {
+            if (rleft[i] && kpos[i] < K && (!LIMIT || total_left > 0)) {
                 if (vec_ok && kpos[i] + EPV <= K) {
                     v.u = *(const uint4*)src;
                 } else {
@@ -252,6 +259,7 @@ template <typename T, int ROWS> struct SegLoader {
             kpos[i] += BKE;
         }
         --tiles_left;
+        if (LIMIT) --total_left;
     }
     __device__ __forceinline__ void store(char* lds, int slot) const {
 #pragma unroll
@@ -260,9 +268,9 @@ template <typename T, int ROWS> struct SegLoader {
 };
 
 // adapter: gives a SegLoader the load(slot) interface of the other loaders
-template <typename T, int ROWS> struct SegLoaderRef {
+template <typename T, int ROWS, bool LIMIT = false> struct SegLoaderRef {
     static constexpr bool kTrans = false;
-    SegLoader<T, ROWS> l;
+    SegLoader<T, ROWS, LIMIT> l;
     const SegTable* t;
     __device__ __forceinline__ void load(int slot) { l.load(*t, slot); }
     __device__ __forceinline__ void store(char* lds, int slot) const { l.store(lds, slot); }
@@ -843,6 +851,37 @@ template <typename T, int KS> __global__ __launch_bounds__(NT * KS) void conv_ks
                                                                                 slab);
 }
 
+template <typename T, int KS> __global__ __launch_bounds__(NT * KS) void gemm_seg_ks_kernel(GemmSegArgs g) {
+    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = (int)(lin % g.splits);
+    lin /= g.splits;
+    const int tn = (int)(lin % g.tiles_n);
+    lin /= g.tiles_n;
+    const int tm = (int)(lin % g.tiles_m);
+    const int64_t z = lin / g.tiles_m;
+    const int64_t sper = (g.nk + g.splits - 1) / g.splits;
+    int64_t kt0 = (int64_t)sp * sper;
+    const int64_t kt1 = kt0 + sper < g.nk ? kt0 + sper : g.nk;
+    if (kt0 > g.nk) kt0 = g.nk;
+    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    Epi ep = g.ep;
+    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
+    if (ep.bias) ep.bias += z * g.sBias;
+    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
+    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
+    int64_t gk0 = kt0 + grp * per;
+    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
+    if (gk0 > kt1) gk0 = kt1;
+    if (gk1 < gk0) gk1 = gk0;
+    SegLoaderRef<T, 64, true> al, bl;
+    al.t = bl.t = &g.t;
+    al.l.init(g.t, false, m0, g.M, gk0, z, tid, gk1 - gk0);
+    bl.l.init(g.t, true, n0, g.N, gk0, z, tid, gk1 - gk0);
+    gemm_block_ks<T, SegLoaderRef<T, 64, true>, SegLoaderRef<T, 64, true>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, ep, slab);
+}
+
 template <typename T, int BM, int BN, int NTH = NT>
 int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
     switch (trans) {
@@ -952,8 +991,20 @@ void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t
 bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
                                void* stream);
 bool comat_conv_launch_variant(const void* cargs, int bf, int bm, int bn, int nth, int ks, unsigned tiles, void* stream);
+bool comat_gemm_seg_launch_variant(const void* sargs, int bf, int ks, unsigned tiles, void* stream);
 
 #ifdef COMAT_GEMM_EXP_TU
+
+bool comat_gemm_seg_launch_variant(const void* sargs, int bf, int ks, unsigned tiles, void* stream) {
+    const GemmSegArgs& g = *(const GemmSegArgs*)sargs;
+    dim3 grid(tiles, 1, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (bf && ks == 4) hipLaunchKernelGGL((gemm_seg_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
+    else if (bf && ks == 2) hipLaunchKernelGGL((gemm_seg_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
+    else if (!bf && ks == 2) hipLaunchKernelGGL((gemm_seg_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
+    else return false;
+    return true;
+}
 
 bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
                                void* stream) {
@@ -1102,13 +1153,22 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0, false);
     g.tiles_m = (int)cdiv64(p->M, 64);
     g.tiles_n = (int)cdiv64(p->N, 64);
-    g.splits = plan.splits;
+    int ks = inblock_ksplit(plan.splits);
+    if (p->in_dtype != COMAT_BF16 && ks > 2) ks = 2;
+    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;
+    if (g.splits < 1) g.splits = 1;
     const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
     COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm_segments: too many tiles");
     g.ws = (float*)p->ws;
     hipStream_t st = (hipStream_t)stream;
-    if (p->in_dtype == COMAT_BF16) hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
-    else hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
+    if (ks > 1) {
+        COMAT_REQUIRE(comat_gemm_seg_launch_variant(&g, p->in_dtype == COMAT_BF16 ? 1 : 0, ks, (unsigned)tiles, stream),
+                      "comat_gemm_segments: unsupported kernel variant");
+    } else if (p->in_dtype == COMAT_BF16) {
+        hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
+    } else {
+        hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
+    }
     if (g.splits > 1) {
         COMAT_REQUIRE(batch == 1 || !p->bias, "comat_gemm_segments: batched split-K with bias is not supported");
         launch_reduce(g.ws, p->M, p->N, batch, 1, p->sC1, 0, p->sR1, 0, g.splits, g.ep, st);

@@ -671,6 +671,13 @@ def test_inblock_split_k_matches_reference(hip, ks, dtype, monkeypatch):
         y.backward(dv(tok(g), hip, dtype))
         check(y, tok(yr), dtype, f"conv ks={ks} {Bn}x{H}x{W} {Cin}->{Cout} s={stride}")
         check(xd.grad, tok(xr.grad), dtype, f"conv dgrad ks={ks}", factor=2)
+    # K-segmented GEMM (long first segment + LoRA-sized second one, and a batched launch)
+    A1, B1 = rnd(512, 1280, dtype=dtype, seed=31, scale=0.3), rnd(200, 1280, dtype=dtype, seed=32, scale=0.3)
+    A2, B2 = rnd(512, 136, dtype=dtype, seed=33, scale=0.3), rnd(200, 136, dtype=dtype, seed=34, scale=0.3)
+    out = torch.empty((512, 200), dtype=torch.float32, device=hip)
+    k.gemm_segments([(dv(A1, hip, dtype), dv(B1, hip, dtype), 1280, 1280, 1280),
+                     (dv(A2, hip, dtype), dv(B2, hip, dtype), 136, 136, 136)], out, 512, 200, 200)
+    check(out, A1 @ B1.t() + A2 @ B2.t(), dtype, f"gemm_segments ks={ks}")
 
 
 @pytest.mark.gpu
