@@ -11,11 +11,14 @@ from .config import BlipConfig, UNetConfig, VAEConfig
 
 class _Init:
     def __init__(self, seed, perturb_norms=False):
-        self.g = torch.Generator().manual_seed(seed)
+        self.g = torch.Generator().manual_seed(seed if seed is not None else 0)
         self.sd = {}
         self.perturb = perturb_norms
+        self.shapes_only = seed is None  # seed=None: meta tensors (layer shapes / parameter counts without memory)
 
     def randn(self, *shape, std=1.0):
+        if self.shapes_only:
+            return torch.empty(*shape, device="meta")
         return torch.randn(*shape, generator=self.g) * std
 
     def linear(self, name, fin, fout, bias=True):
@@ -32,8 +35,9 @@ class _Init:
             self.sd[name + ".weight"] = 1.0 + self.randn(c, std=0.1)
             self.sd[name + ".bias"] = self.randn(c, std=0.1)
         else:
-            self.sd[name + ".weight"] = torch.ones(c)
-            self.sd[name + ".bias"] = torch.zeros(c)
+            dev = "meta" if self.shapes_only else "cpu"
+            self.sd[name + ".weight"] = torch.ones(c, device=dev)
+            self.sd[name + ".bias"] = torch.zeros(c, device=dev)
 
 
 def attention_names(cfg: UNetConfig):
