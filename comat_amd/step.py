@@ -202,6 +202,7 @@ class CoMatTrainer:
             if self._d_stream is None:
                 self._d_stream = torch.cuda.Stream(device=self.device)
             self._d_stream.wait_stream(main)  # the G forward (latents, the discriminator's compute copies) is queued
+            out["training_latents"].record_stream(self._d_stream)  # read there: the allocator must not recycle it early
             with torch.cuda.stream(self._d_stream):
                 logs["D_loss"] = self._d_step(out, batch)
         out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
