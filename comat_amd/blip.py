@@ -118,6 +118,9 @@ class Blip:
     def preprocess(self, img_tokens, B, H, W, crop=None):
         """crop (y0, x0, h, w) + Resize(bicubic, antialias) + Normalize in one kernel; -> [B*S*S, 3]."""
         crop = crop or (0, 0, H, W)
+        y0, x0, ch, cw = crop
+        if not (0 <= y0 and 0 <= x0 and ch > 0 and cw > 0 and y0 + ch <= H and x0 + cw <= W):
+            raise ValueError(f"crop {crop} does not fit the {H}x{W} image (training_script.py:606-609 keeps it inside)")
         return ops.resample(img_tokens, self.tables(H, W, crop), B, 3, scale=self.norm_scale, shift=self.norm_shift)
 
     # ---- vision encoder ----------------------------------------------------------------------------------------

@@ -22,3 +22,6 @@ COMAT_TILE_AUTO=1 COMAT_KSPLIT=2 COMAT_BLIP_FUSED_QKV=1 COMAT_FLASH_TRIM=1 timeo
 C4="python bench.py --config c4 --no-cpu-baseline --no-kernel-timing --steps 2 --warmup 1"
 timeout 300 $C4 > gpurun_out/exp_c4_base.log 2>&1 < /dev/null;                          echo "c4 baseline      $(ms gpurun_out/exp_c4_base.log)"
 COMAT_SDXL_GRAPHS=1 timeout 300 $C4 > gpurun_out/exp_c4_graphs.log 2>&1 < /dev/null;    echo "c4 SDXL_GRAPHS=1 $(ms gpurun_out/exp_c4_graphs.log)"
+
+# full-size C1 parity (north-star acceptance numbers): a few minutes of host time for the CPU oracle
+timeout 1500 python tools/parity_c1.py > gpurun_out/parity_c1.log 2>&1 < /dev/null; tail -1 gpurun_out/parity_c1.log
