@@ -23,5 +23,6 @@ C4="python bench.py --config c4 --no-cpu-baseline --no-kernel-timing --steps 2 -
 timeout 300 $C4 > gpurun_out/exp_c4_base.log 2>&1 < /dev/null;                          echo "c4 baseline      $(ms gpurun_out/exp_c4_base.log)"
 COMAT_SDXL_GRAPHS=1 timeout 300 $C4 > gpurun_out/exp_c4_graphs.log 2>&1 < /dev/null;    echo "c4 SDXL_GRAPHS=1 $(ms gpurun_out/exp_c4_graphs.log)"
 
+COMAT_TEST_FULLSIZE=1 timeout 600 python -m pytest tests/test_zz_fullsize_c1.py -m gpu -q > gpurun_out/exp_c1_golden.log 2>&1 < /dev/null; tail -2 gpurun_out/exp_c1_golden.log
 # full-size C1 parity (north-star acceptance numbers): a few minutes of host time for the CPU oracle
 timeout 1500 python tools/parity_c1.py > gpurun_out/parity_c1.log 2>&1 < /dev/null; tail -1 gpurun_out/parity_c1.log
