@@ -136,12 +136,17 @@ def build_world(device, dtype, rank, cfg_name):
     from comat_amd.unet import LoRABank, UNet, VAEDecoder
 
     ucfg, vcfg, bcfg = config.SD15_UNET, config.SD15_VAE, config.BLIP_LARGE
+    tiny = cfg_name == "selftest"
+    if tiny:
+        ucfg, vcfg, bcfg = config.TINY_UNET, config.TINY_VAE, config.TINY_BLIP
     sdxl = cfg_name == "c4"
     if sdxl:  # BASELINE config C4: SDXL generator at 512^2 (64^2 latents), SD1.5 discriminator, full CoMat losses
         from comat_amd.pipeline import TrainableSDXLPipeline
         ucfg, vcfg = config.SDXL_UNET, config.SDXL_VAE
         scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True,
                           train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
+    elif tiny:
+        scfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=False)
     elif cfg_name == "c2":
         scfg = StepConfig(resolution=512, total_step=5, K=5, gan_loss=True, attrcon=False)
     elif cfg_name == "c3":
@@ -157,7 +162,7 @@ def build_world(device, dtype, rank, cfg_name):
     keep_for_cpu = usd if (rank == 0) else None
     vae = VAEDecoder(vcfg, weights.make_vae_weights(vcfg, seed=2345), dtype, device)
     blip = Blip(bcfg, weights.make_blip_weights(bcfg, seed=3456), dtype, device)
-    dcfg = config.SD15_UNET  # the discriminator is the SD1.5 UNet in every configuration
+    dcfg = config.TINY_UNET if tiny else config.SD15_UNET  # the discriminator is the SD1.5 UNet in every configuration
     dsd = weights.make_unet_weights(dcfg, seed=1235)
     dbank = LoRABank(dcfg, weights.make_lora_weights(dcfg, seed=4322), dtype, device)
     g = torch.Generator().manual_seed(99)
@@ -170,17 +175,21 @@ def build_world(device, dtype, rank, cfg_name):
         trainer.pipe.prepare_graphs(1, scfg.resolution, scfg.resolution, 77, scfg.total_step)
     # synthetic batch; per-rank seeds differ (each rank has its own prompt)
     g = torch.Generator().manual_seed(1000 + rank)
-    L, T = 77, 16
-    ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
-                     torch.tensor([102])]).reshape(1, T)
+    L, T = (7, 9) if tiny else (77, 16)
+    hl = scfg.resolution // 8
+    if tiny:
+        ids = torch.randint(1, bcfg.vocab_size, (1, T), generator=g)
+    else:
+        ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
+                         torch.tensor([102])]).reshape(1, T)
     batch = dict(
         prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
         negative_prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
         gan_null_embeds=torch.randn(1, L, dcfg.cross_attention_dim, generator=g),
-        latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42 + rank)),
-        noises=[torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(100 + i)).to(device)
+        latents=torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(42 + rank)),
+        noises=[torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(100 + i)).to(device)
                 for i in range(scfg.total_step)],
-        real_latents=torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
+        real_latents=torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
         blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids))
     if sdxl:
         batch.update(pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
@@ -193,7 +202,7 @@ def build_world(device, dtype, rank, cfg_name):
         m[1, 280:480, 260:500] = True
         batch["masks"] = [m]
         batch["attributes"] = [[[2, 3], [6, 7]]]
-    fixed = dict(crop=(1, 1, 510, 510))
+    fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, 510, 510))
     if cfg_name == "c2":
         fixed["training_steps"] = [0, 1, 2, 3, 4]
     return trainer, batch, fixed, scfg, keep_for_cpu, time.time() - t0
@@ -235,16 +244,29 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--selftest", action="store_true",
+                    help="control-flow check of this script WITHOUT a GPU (tests/test_bench_contract.py): tiny model, "
+                         "ABI simulator, gloo; its numbers mean nothing and the output is marked as such")
     args = ap.parse_args()
 
-    from comat_amd import _hip, dist, ops
+    from comat_amd import dist, ops
     rank, world, device = dist.init()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    ops.set_kernel_backend(_hip.HipKernels())
+    if args.selftest:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from sim_backend import SimKernels
+        ops.set_kernel_backend(SimKernels())
+        device = torch.device("cpu")
+        sync = lambda: None
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        from comat_amd import _hip
+        ops.set_kernel_backend(_hip.HipKernels())
+        sync = torch.cuda.synchronize
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank, args.config)
+    trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank,
+                                                                "selftest" if args.selftest else args.config)
 
     last_logs = {}
 
@@ -253,20 +275,20 @@ def main():
 
     for _ in range(args.warmup):
         run_step()
-    torch.cuda.synchronize()
+    sync()
     gc.collect()
     gc.freeze()  # the weights / module objects built above are immortal: keep the cyclic GC from rescanning them
     dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.time()
     host_s = 0.0
     for _ in range(args.steps):
         h0 = time.perf_counter()
         run_step()
         host_s += time.perf_counter() - h0  # time the host needs to ENQUEUE a step (no sync inside)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.time() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -276,7 +298,7 @@ def main():
     value = world * args.steps / dt  # one image (prompt) per rank per step
 
     roofline = None
-    if not args.no_kernel_timing:
+    if not args.no_kernel_timing and not args.selftest:
         # one extra, instrumented step.  EVERY rank runs it (the step contains the gradient all-reduce: a rank-0-only
         # step would deadlock the collective); only rank 0 brackets its kernels with events.
         timed = None
@@ -285,12 +307,12 @@ def main():
             ops.set_kernel_backend(timed)
         ops.set_side_stream_enabled(False)  # per-kernel event timing needs one stream (no overlapping kernels)
         trainer.train_step(batch, **fixed)
-        torch.cuda.synchronize()
+        sync()
         ops.set_side_stream_enabled(True)
         if rank == 0:
             fam = timed.summary()
             ops.set_kernel_backend(timed.inner)
-    if rank == 0 and not args.no_kernel_timing:
+    if rank == 0 and not args.no_kernel_timing and not args.selftest:
         tot_t = sum(v[0] for v in fam.values())
         dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
         t_dom, f_dom, n_dom = fam[dom]
@@ -308,7 +330,7 @@ def main():
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]},
         }
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "c4":  # the port is SD1.5-shaped
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "c4" and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)
     if rank == 0 and os.environ.get("COMAT_BENCH_LOGS"):  # loss terms of the last timed step (sanity evidence)
         print({k: (float(v) if torch.is_tensor(v) else v) for k, v in last_logs.items()}, file=sys.stderr)
@@ -318,7 +340,8 @@ def main():
             "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "data": "synthetic",
+            "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "data": "SELFTEST (CPU simulator, tiny model): not a measurement" if args.selftest else "synthetic",
             "config": {"workload": f"{args.config.upper()}: {'SDXL (SD1.5 discriminator)' if args.config == 'c4' else 'SD1.5'} "
                                    f"512x512 bs=1/GPU, N={scfg.total_step} denoise steps "
                                    f"(K={scfg.K} with grad), CFG 7.5, LoRA r=128, concept-matching (BLIP-large) + GAN "

@@ -1,0 +1,44 @@
+"""bench.py's control flow and output contract, checked WITHOUT a GPU through its --selftest mode (tiny model, ABI
+simulator, gloo): one JSON line from rank 0 with the required keys; the 2-rank launch (the way the driver starts
+`--gpus N`) goes through the barriers, the max-over-ranks timing and the gradient all-reduce without deadlocking."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _json_line(out):
+    lines = [line for line in out.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, f"expected exactly one JSON line, got {len(lines)}:\n{out[-2000:]}"
+    return json.loads(lines[0])
+
+
+def _check(d, n, steps, warmup):
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup
+    assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - n * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "SELFTEST" in d["data"]  # a self-test line can never be mistaken for a measurement
+
+
+def test_single_process_selftest():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    _check(_json_line(p.stdout), 1, 2, 1)
+
+
+def test_two_rank_launch_like_the_driver():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--selftest"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    _check(_json_line(p.stdout), 2, 2, 1)
