@@ -2,6 +2,8 @@
 CPU oracle step (oracle/step.py): loss terms, token-level concept scores, generator-LoRA gradients (fp32: 1e-3
 relative), discriminator gradients, and the parameters after clip + AdamW."""
 import dataclasses
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -192,3 +194,21 @@ def test_train_step_sdxl_matches_oracle(dev, dtype):
     lim = 1e-3 if dtype == torch.float32 else 0.15
     assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
     assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
+
+
+@pytest.mark.parametrize("attrcon", [False, True])
+def test_step_has_no_host_synchronisation(attrcon):
+    """The whole optimisation step must be enqueue-only: no `.item()`, no `float(tensor)`, no device->host copy anywhere
+    in the product code (every such call would stall the host behind the GPU once per step).  Checked by running the
+    step on the `meta` device with no-op kernels: any attempt to read a tensor's value raises there."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from host_overhead import NullKernels
+    from comat_amd import ops
+    ops.set_kernel_backend(NullKernels())
+    try:
+        cfg, batch, W, trainer = make_world(torch.bfloat16, torch.device("meta"), attrcon)
+        logs = trainer.train_step(batch, training_steps=[1, 2], crop=(1, 0, 63, 63), attrcon_steps=[2])
+        assert logs["step_loss"].device.type == "meta" and logs["D_loss"].device.type == "meta"
+        trainer.train_step(batch)  # second step: random step / crop sampling, optimizer state, compute-copy refresh
+    finally:
+        ops.set_kernel_backend(None)
