@@ -9,6 +9,8 @@ machine without a GPU by plugging in a simulator of the C ABI.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -186,6 +188,7 @@ class LoRAStore:
         self.flat_c = None if dtype == torch.float32 else torch.empty(total, dtype=dtype, device=device)
         self.flat_t = torch.empty(toff, dtype=dtype, device=device)
         self._fresh = False
+        self._merged = {}
 
         def leaf(o, shp):
             n = shp[0] * shp[1]
@@ -217,10 +220,50 @@ class LoRAStore:
                 k.unary(UN_COPY, self.flat, self.flat_c, self.flat.numel())
             k.transpose_cast_tiles(self.flat, self.flat_t, self._tiles)
             self._fresh = True
+            for ent in self._merged.values():  # merged inference weights that exist follow the parameters
+                self._merge_into(ent)
 
     def mark_updated(self):
         """call after an in-place update of `flat` (optimizer kernel): the derived copies are refreshed lazily."""
         self._fresh = False
+
+    # ---- merged weights for no-grad calls (opt-in, see lora_group_linear) ------------------------------------------
+    def merged_weights(self, grp, lins):
+        """[W_i + s * U_i D_i] in the compute dtype for the projections `lins` of group `grp`: persistent buffers (one
+        [G, N, K] allocation when the frozen weights are co-allocated), created at the first no-grad use and refreshed
+        in place whenever the compute copies are (i.e. once per optimizer step), so captured graphs can read them."""
+        self.ensure_compute_copy()
+        key = (grp.index, tuple(id(l) for l in lins))
+        ent = self._merged.get(key)
+        if ent is None:
+            G = len(lins)
+            shp = tuple(lins[0].w.shape)
+            if G > 1 and all(tuple(l.w.shape) == shp for l in lins):
+                buf = lins[0].w.new_empty((G,) + shp)
+                wm = list(buf.unbind(0))
+            else:
+                wm = [torch.empty_like(l.w) for l in lins]
+            ent = self._merged[key] = dict(grp=grp, lins=tuple(lins), wm=wm)
+            self._merge_into(ent)
+        return ent["wm"]
+
+    def _merge_into(self, ent):
+        grp, lins, wm = ent["grp"], ent["lins"], ent["wm"]
+        _, ucs, dct = self.group_views[grp.index]
+        G, r = grp.size, grp.rank
+        Gr = G * r
+        k = kernels()
+        N, Kd = lins[0].w.shape
+        sw, su, sm = _uniform_stride([l.w for l in lins]), _uniform_stride(ucs), _uniform_stride(wm)
+        if G > 1 and sw is not None and su is not None and sm is not None:
+            # Wm_i[N, K] = W_i + s * U_i[N, r] (D^T[K, G*r] columns i*r..)^T  for all i in one batched launch
+            k.gemm(ucs[0], dct, wm[0], N, Kd, r, r, Gr, Kd, batch=(G, 1), sA=(su, 0), sB=(r, 0), sC=(sm, 0),
+                   R=lins[0].w, ldr=Kd, sR=(sw, 0), alpha=grp.scale, beta=1.0)
+        else:
+            for i, lin in enumerate(lins):
+                N, Kd = lin.w.shape
+                k.gemm(ucs[i], dct[:, i * r:(i + 1) * r], wm[i], N, Kd, r, r, Gr, Kd, R=lin.w, ldr=Kd, alpha=grp.scale,
+                       beta=1.0)
 
     def zero_grad(self):
         self.flat_grad.zero_()
@@ -601,11 +644,40 @@ class _LoRAGroupLinear(Function):
         return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
 
 
+def _merged_nograd_forward(x, lins, grp, residual):
+    """no-grad call with merged weights: y_i = x (W_i + s U_i D_i)^T + b_i (+ residual), one plain GEMM per projection
+    or one batched GEMM for a co-allocated group; no low-rank activations, no segments."""
+    x = _c(x)
+    M, Kd = x.shape
+    wm = grp.store.merged_weights(grp, lins)
+    k = kernels()
+    G = len(lins)
+    sm = _uniform_stride(wm)
+    if G > 1 and sm is not None and residual is None and all(l.bias is None for l in lins):
+        N = lins[0].out_features
+        ys = x.new_empty((G, M, N))
+        k.gemm(x, wm[0], ys, M, N, Kd, Kd, Kd, N, batch=(G, 1), sA=(0, 0), sB=(sm, 0), sC=(M * N, 0))
+        return tuple(ys.unbind(0))
+    ys = []
+    if residual is not None:
+        residual = _c(residual)
+    for lin, w in zip(lins, wm):
+        N = lin.out_features
+        y = x.new_empty((M, N))
+        k.gemm(x, w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
+        ys.append(y)
+    return tuple(ys)
+
+
 def lora_group_linear(x, lins, grp: LoRAGroup | None, residual=None):
-    """(x W_i^T + b_i + lora_i(x)) for the projections `lins` that share the input x; a tuple of len(lins)."""
+    """(x W_i^T + b_i + lora_i(x)) for the projections `lins` that share the input x; a tuple of len(lins).
+    COMAT_NOGRAD_MERGED=1 (opt-in: changes bf16 rounding, not yet validated on a GPU): calls under torch.no_grad()
+    — the untrained denoise steps — use merged weights W + s U D, refreshed once per optimizer step."""
     if grp is None:
         assert residual is None or len(lins) == 1
         return tuple(linear(x, lin, residual) for lin in lins)
+    if not torch.is_grad_enabled() and os.environ.get("COMAT_NOGRAD_MERGED") == "1":
+        return _merged_nograd_forward(x, tuple(lins), grp, residual)
     return _LoRAGroupLinear.apply(x, residual, grp, tuple(lins), grp.down_cat, *grp.ups)
 
 

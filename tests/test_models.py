@@ -195,3 +195,32 @@ def test_gt_latent_producer(dev, dtype, tmp_path):
     rec = gt_latents.read_gt_record(lines[1])
     assert rec["text"] == "two dogs" and rec["latents"].dtype == torch.float32 and rec["latents"].shape == (4, h, w)
     assert torch.equal(rec["latents"], out[1].cpu())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_nograd_merged_lora_weights_in_the_sampler(sim, dtype, monkeypatch):
+    """COMAT_NOGRAD_MERGED=1 changes only HOW the untrained denoise steps evaluate their LoRA projections (merged
+    weights): final latents, image and the LoRA gradients of the trained steps stay within rounding of the default."""
+    usd, vsd, lsd = tiny_weights(dtype)
+    bs, h, w, L = 1, 8, 8, 7
+    cd = config.TINY_UNET.cross_attention_dim
+    lat = rnd(bs, 4, h, w, seed=10)
+    cu, cc = rnd(bs, L, cd, seed=11, dtype=dtype), rnd(bs, L, cd, seed=12, dtype=dtype)
+    noises = [rnd(bs, 4, h, w, seed=20 + i) for i in range(4)]
+    gi = rnd(bs, 3, 8 * h, 8 * w, seed=30)
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("COMAT_NOGRAD_MERGED", flag)
+        bank = LoRABank(config.TINY_UNET, lsd, dtype, sim)
+        pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, sim, bank),
+                                   VAEDecoder(config.TINY_VAE, vsd, dtype, sim))
+        img, latf = pipe.forward(cc, cu, height=8 * h, width=8 * w, training_timesteps=[2, 3], num_inference_steps=4,
+                                 guidance_scale=7.5, latents=lat, noises=noises, return_latents=True)
+        bank.zero_grad()
+        (img.float() * gi).sum().backward()
+        res.append((img.detach().float(), latf.detach().float(), bank.flat_grad.clone()))
+        assert bool(bank._merged) == (flag == "1")
+    f = 1.0 if dtype == torch.float32 else 4.0
+    check(res[1][0], res[0][0], dtype, "image", factor=f)
+    check(res[1][1], res[0][1], dtype, "latents", factor=f)
+    assert rel_l2(res[1][2], res[0][2]) < (1e-4 if dtype == torch.float32 else 0.15)

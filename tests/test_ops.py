@@ -700,3 +700,47 @@ def test_flash_trim_is_bit_identical(hip, dtype, cfg, monkeypatch):
         res.append((o.detach(), qd.grad, kd.grad, vd.grad))
     for a, b, name in zip(res[0], res[1], ("O", "dQ", "dK", "dV")):
         assert torch.equal(a, b), f"trimmed {name} differs"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("G", [1, 3])
+def test_merged_nograd_weights(dev, dtype, G, monkeypatch):
+    """COMAT_NOGRAD_MERGED=1: no-grad calls through W + s U D (merged once per optimizer step) give the unmerged result
+    (fp32: to rounding; bf16: within bf16 tolerance), follow parameter updates, and leave grad-mode calls untouched."""
+    if dev.type == "cuda" and os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1":
+        pytest.skip("merged no-grad weights are opt-in until validated on a GPU: COMAT_TEST_EXPERIMENTAL=1")
+    M, K, r, N = 130, 64, 8, 96
+    x = rnd(M, K, dtype=dtype, seed=1)
+    ws = [rnd(N, K, dtype=dtype, seed=20 + i, scale=K ** -0.5) for i in range(G)]
+    spec = [(f"p{i}.down", f"p{i}.up", rnd(r, K, seed=40 + i, scale=r ** -0.5), rnd(N, r, seed=50 + i, scale=0.2))
+            for i in range(G)]
+    res = rnd(M, N, dtype=dtype, seed=6) if G == 1 else None
+    lins = (ops.frozen_linear_group(ws, [None] * G, dtype, dev) if G > 1
+            else [ops.FrozenLinear(ws[0], rnd(N, seed=30), dtype, dev)])
+    store = ops.LoRAStore([spec], dtype, dev)
+    xd = dv(x, dev, dtype)
+    rd = dv(res, dev, dtype) if res is not None else None
+    with torch.no_grad():
+        plain = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
+        monkeypatch.setenv("COMAT_NOGRAD_MERGED", "1")
+        merged = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
+    f = 1.0 if dtype == torch.float32 else 1.5
+    for a, b in zip(merged, plain):
+        check(a, b, dtype, "merged vs unmerged", factor=f)
+    # parameter update -> merged weights refreshed in place (same buffers)
+    ptrs = [w.data_ptr() for w in store.merged_weights(store.groups[0], tuple(lins))]
+    store.flat.mul_(0.5)
+    store.mark_updated()
+    with torch.no_grad():
+        merged2 = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
+        monkeypatch.setenv("COMAT_NOGRAD_MERGED", "0")
+        plain2 = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
+    assert ptrs == [w.data_ptr() for w in store.merged_weights(store.groups[0], tuple(lins))]
+    for a, b, c in zip(merged2, plain2, plain):
+        check(a, b, dtype, "merged vs unmerged after update", factor=f)
+        assert (a.float() - c.float()).abs().max() > 0
+    # grad-mode calls never take the merged path
+    monkeypatch.setenv("COMAT_NOGRAD_MERGED", "1")
+    xg = dv(x, dev, dtype, grad=True)
+    y = ops.lora_group_linear(xg, lins, store.groups[0], residual=rd)
+    assert y[0].grad_fn is not None

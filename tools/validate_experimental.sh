@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 ms() { grep -o '"ms_per_step": [0-9.]*' "$1" | tail -1; }
 
 COMAT_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests -m gpu -q \
-    -k "tile or inblock or sdxl_graph or fused_qkv or flash_trim" > gpurun_out/exp_tests.log 2>&1 < /dev/null
+    -k "tile or inblock or sdxl_graph or fused_qkv or flash_trim or merged" > gpurun_out/exp_tests.log 2>&1 < /dev/null
 tail -3 gpurun_out/exp_tests.log
 
 B="python bench.py --no-cpu-baseline --no-kernel-timing --steps 4 --warmup 1"
@@ -19,6 +19,9 @@ COMAT_KSPLIT=4 timeout 200 $B > gpurun_out/exp_ks4.log 2>&1 < /dev/null;        
 COMAT_FLASH_TRIM=1 timeout 200 $B > gpurun_out/exp_trim.log 2>&1 < /dev/null;            echo "FLASH_TRIM=1     $(ms gpurun_out/exp_trim.log)"
 COMAT_BLIP_FUSED_QKV=1 timeout 200 $B > gpurun_out/exp_qkv.log 2>&1 < /dev/null;        echo "BLIP_FUSED_QKV=1 $(ms gpurun_out/exp_qkv.log)"
 COMAT_TILE_AUTO=1 COMAT_KSPLIT=2 COMAT_BLIP_FUSED_QKV=1 COMAT_FLASH_TRIM=1 timeout 200 $B > gpurun_out/exp_all.log 2>&1 < /dev/null; echo "all four         $(ms gpurun_out/exp_all.log)"
+C3="python bench.py --config c3 --no-cpu-baseline --no-kernel-timing --steps 3 --warmup 2"
+timeout 300 $C3 > gpurun_out/exp_c3_base.log 2>&1 < /dev/null;                          echo "c3 baseline      $(ms gpurun_out/exp_c3_base.log)"
+COMAT_NOGRAD_MERGED=1 timeout 300 $C3 > gpurun_out/exp_c3_merged.log 2>&1 < /dev/null;  echo "c3 NOGRAD_MERGED $(ms gpurun_out/exp_c3_merged.log)"
 C4="python bench.py --config c4 --no-cpu-baseline --no-kernel-timing --steps 2 --warmup 1"
 timeout 300 $C4 > gpurun_out/exp_c4_base.log 2>&1 < /dev/null;                          echo "c4 baseline      $(ms gpurun_out/exp_c4_base.log)"
 COMAT_SDXL_GRAPHS=1 timeout 300 $C4 > gpurun_out/exp_c4_graphs.log 2>&1 < /dev/null;    echo "c4 SDXL_GRAPHS=1 $(ms gpurun_out/exp_c4_graphs.log)"
