@@ -57,6 +57,11 @@ template <typename T, int DMAX> struct Geo {
     static constexpr int CPRW = DMAX * (int)sizeof(T) / 16;
     static constexpr int NCHK = (32 * CPRW + NT - 1) / NT;
     static constexpr int TILE_BYTES = 32 * RS;
+    // transposed image [DMAX head-dim columns][32 tile rows] (flag TR of the kernels): the k-major fragments become
+    // aligned 8 / 16-byte reads of 4 consecutive tile rows instead of KC scalar reads.  TRS: bytes per column; the pad
+    // spreads the 32 lanes of a half-wave (consecutive columns) over all banks (bf16: 18 dwords, fp32: 36 dwords)
+    static constexpr int TRS = 32 * (int)sizeof(T) + (sizeof(T) == 2 ? 8 : 16);
+    static constexpr int TT_BYTES = DMAX * TRS;
 };
 
 // cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
@@ -82,6 +87,24 @@ template <typename T, int DMAX> struct TileMover {
             if (c < 32 * G::CPRW) *(uint4*)(lds + (c / G::CPRW) * G::RS + (c % G::CPRW) * 16) = regs[i];
         }
     }
+    // transposed image: element (tile row rr, column col) -> ldsT[col * TRS + rr * sizeof(T)]
+    __device__ __forceinline__ void store_t(char* ldsT) const {
+#pragma unroll
+        for (int i = 0; i < G::NCHK; ++i) {
+            const int c = threadIdx.x + i * NT;
+            if (c < 32 * G::CPRW) {
+                const int rr = c / G::CPRW, col0 = (c % G::CPRW) * G::KC;
+                V16 v;
+                v.u = regs[i];
+#pragma unroll
+                for (int e = 0; e < G::KC; ++e) {
+                    char* p = ldsT + (col0 + e) * G::TRS + rr * (int)sizeof(T);
+                    if (sizeof(T) == 2) *(bf16_t*)p = v.h[e];
+                    else *(float*)p = v.f[e];
+                }
+            }
+        }
+    }
 };
 
 // fragment with rows = tile rows, k = head-dim chunk (k-contiguous 16-byte read)
@@ -102,6 +125,24 @@ __device__ __forceinline__ typename FragOf<T>::type frag_km(const char* lds, int
     }
     typename FragOf<T>::type out;
     __builtin_memcpy(&out, &v, 16);
+    return out;
+}
+// the same fragment from the transposed image: accumulator rows KC*j .. KC*j+KC-1 are runs of 4 consecutive tile rows
+// (bf16: rows 16j+4hh+{0..3} and 16j+8+4hh+{0..3}; fp32: rows 8j+4hh+{0..3}) -> two 8-byte reads / one 16-byte read
+template <typename T, int DMAX>
+__device__ __forceinline__ typename FragOf<T>::type frag_km_t(const char* ldsT, int n, int j, int hh) {
+    typedef Geo<T, DMAX> G;
+    const char* col = ldsT + n * G::TRS;
+    typename FragOf<T>::type out;
+    if (sizeof(T) == 2) {
+        const uint2 lo = *(const uint2*)(col + (16 * j + 4 * hh) * 2);
+        const uint2 hi = *(const uint2*)(col + (16 * j + 8 + 4 * hh) * 2);
+        const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        __builtin_memcpy(&out, &v, 16);
+    } else {
+        const uint4 v = *(const uint4*)(col + (8 * j + 4 * hh) * 4);
+        __builtin_memcpy(&out, &v, 16);
+    }
     return out;
 }
 // accumulator registers KC*j .. KC*j+KC-1 as a fragment of the storage type
@@ -145,13 +186,14 @@ struct FlashArgs {
 };
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+// TR: the k-major operand (V here) is staged as a TRANSPOSED LDS image and read with aligned 8 / 16-byte loads
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[G::TILE_BYTES + (TR ? G::TT_BYTES : G::TILE_BYTES)];
     char* Kt = smem;
-    char* Vt = smem + G::TILE_BYTES;
+    char* Vt = smem + G::TILE_BYTES;  // TR: the transposed image of the V tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
@@ -174,7 +216,8 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     km.load(Kb, a.ldk, 0, a.Nk, a.d);
     vm.load(Vb, a.ldv, 0, a.Nk, a.d);
     km.store(Kt);
-    vm.store(Vt);
+    if (TR) vm.store_t(Vt);
+    else vm.store(Vt);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
@@ -215,12 +258,13 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
         for (int j = 0; j < G::NJ; ++j) {
             const F pb = pack_acc<T>(st, j);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], TR ? frag_km_t<T, DMAX>(Vt, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
         }
         __syncthreads();
         if (more) {
             km.store(Kt);
-            vm.store(Vt);
+            if (TR) vm.store_t(Vt);
+            else vm.store(Vt);
             __syncthreads();
         }
     }
@@ -260,13 +304,14 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_prep_kernel(Fl
 }
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + (TR ? G::TT_BYTES : 0)];
     char* Kt = smem;
     char* Vt = smem + G::TILE_BYTES;
+    char* KtT = smem + 2 * G::TILE_BYTES;  // TR: transposed image of the K tile (for dQ^T += K^T dS^T)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
@@ -290,6 +335,7 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     km.load(Kb, a.ldk, 0, a.Nk, a.d);
     vm.load(Vb, a.ldv, 0, a.Nk, a.d);
     km.store(Kt);
+    if (TR) km.store_t(KtT);
     vm.store(Vt);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -315,11 +361,12 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
         for (int j = 0; j < G::NJ; ++j) {
             const F db = pack_acc<T>(st, j);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], TR ? frag_km_t<T, DMAX>(KtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
         }
         __syncthreads();
         if (more) {
             km.store(Kt);
+            if (TR) km.store_t(KtT);
             vm.store(Vt);
             __syncthreads();
         }
@@ -336,15 +383,17 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
 }
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + 256];
+    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + 256 + (TR ? 2 * G::TT_BYTES : 0)];
     char* Qt = smem;
     char* Gt = smem + G::TILE_BYTES;
     float* lse_s = (float*)(smem + 2 * G::TILE_BYTES);
     float* D_s = lse_s + 32;
+    char* QtT = smem + 2 * G::TILE_BYTES + 256;  // TR: transposed images of the Q and dO tiles (dK^T, dV^T products)
+    char* GtT = QtT + G::TT_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
@@ -381,6 +430,10 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     }
     qm.store(Qt);
     gm.store(Gt);
+    if (TR) {
+        qm.store_t(QtT);
+        gm.store_t(GtT);
+    }
     if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
     __syncthreads();
     for (int t = tbeg; t < ntiles; ++t) {
@@ -416,14 +469,18 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
             const F db = pack_acc<T>(dp, j);
 #pragma unroll
             for (int t2 = 0; t2 < G::NT32; ++t2) {
-                mma(dvT[t2], frag_km<T, DMAX>(Gt, t2 * 32 + r, j, hh), pb);
-                mma(dkT[t2], frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
+                mma(dvT[t2], TR ? frag_km_t<T, DMAX>(GtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Gt, t2 * 32 + r, j, hh), pb);
+                mma(dkT[t2], TR ? frag_km_t<T, DMAX>(QtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
             }
         }
         __syncthreads();
         if (more) {
             qm.store(Qt);
             gm.store(Gt);
+            if (TR) {
+                qm.store_t(QtT);
+                gm.store_t(GtT);
+            }
             if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
             __syncthreads();
         }
@@ -470,41 +527,39 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kern
     stf<T>((T*)a.dV + ((int64_t)b * a.Nk + key) * a.ldv + h * a.d + n, sv);
 }
 
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS> void launch_fwd(const FlashArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
+void launch_fwd(const FlashArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
 }
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS> void launch_bwd(const FlashArgs& a, hipStream_t st) {
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
+void launch_bwd(const FlashArgs& a, hipStream_t st) {
     const int64_t total = (int64_t)a.B * a.H * a.Nq;
     hipLaunchKernelGGL((flash_prep_kernel<T>), dim3((unsigned)cdiv64(total, NT)), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
     if (a.qsplit > 1) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
         hipLaunchKernelGGL((flash_kv_reduce_kernel<T>), dim3((unsigned)cdiv64(slab, NT)), dim3(NT), 0, st, a);
     }
 }
 
-template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
-    // COMAT_FLASH_TRIM=1 (experimental): skip the MFMA k-steps whose head-dim chunk is pure zero padding (head dim 40
-    // in a 64-wide tile: 3 of 4 steps; 80 in 96: 5 of 6) — same sums, the skipped products are exactly zero
-    const char* e = getenv("COMAT_FLASH_TRIM");
-    const bool trim = e && atoi(e) == 1;
+template <typename T, bool TR> int dispatch_tr(const FlashArgs& a, bool bwd, bool trim, hipStream_t st) {
     constexpr int KC2 = 2 * (16 / (int)sizeof(T));
     if (trim && a.d > 32 && a.d <= 48) {
-        if (bwd) launch_bwd<T, 64, 48 / KC2>(a, st);
-        else launch_fwd<T, 64, 48 / KC2>(a, st);
+        if (bwd) launch_bwd<T, 64, 48 / KC2, TR>(a, st);
+        else launch_fwd<T, 64, 48 / KC2, TR>(a, st);
         return 0;
     }
     if (trim && a.d > 64 && a.d <= 80) {
-        if (bwd) launch_bwd<T, 96, 80 / KC2>(a, st);
-        else launch_fwd<T, 96, 80 / KC2>(a, st);
+        if (bwd) launch_bwd<T, 96, 80 / KC2, TR>(a, st);
+        else launch_fwd<T, 96, 80 / KC2, TR>(a, st);
         return 0;
     }
-#define FA_CASE(D)                     \
-    if (a.d <= D) {                    \
-        if (bwd) launch_bwd<T, D>(a, st); \
-        else launch_fwd<T, D>(a, st);  \
-        return 0;                      \
+#define FA_CASE(D)                                             \
+    if (a.d <= D) {                                            \
+        if (bwd) launch_bwd<T, D, Geo<T, D>::NKS, TR>(a, st);  \
+        else launch_fwd<T, D, Geo<T, D>::NKS, TR>(a, st);      \
+        return 0;                                              \
     }
     FA_CASE(32)
     FA_CASE(64)
@@ -512,6 +567,19 @@ template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st)
     FA_CASE(160)
 #undef FA_CASE
     return -1;
+}
+
+template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
+    // experimental switches, both bit-identical to the default by construction:
+    // COMAT_FLASH_TRIM=1 skips the MFMA k-steps whose head-dim chunk is pure zero padding (head dim 40 in a 64-wide
+    //   tile: 3 of 4 steps; 80 in 96: 5 of 6) — the skipped products are exactly zero;
+    // COMAT_FLASH_TR=1 stages the k-major operand tiles (V; K in dQ; Q and dO in dK/dV) as transposed LDS images, so
+    //   their MFMA fragments are two 8-byte reads instead of eight 2-byte reads.
+    const char* e = getenv("COMAT_FLASH_TRIM");
+    const bool trim = e && atoi(e) == 1;
+    const char* e2 = getenv("COMAT_FLASH_TR");
+    if (e2 && atoi(e2) == 1) return dispatch_tr<T, true>(a, bwd, trim, st);
+    return dispatch_tr<T, false>(a, bwd, trim, st);
 }
 
 int check_args(const char* what, const void* Q, const void* K, const void* V, int B, int H, int Nq, int Nk, int d,

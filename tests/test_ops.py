@@ -684,22 +684,26 @@ def test_inblock_split_k_matches_reference(hip, ks, dtype, monkeypatch):
 @pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
                     reason="experimental zero-chunk trimming of the fused attention (COMAT_FLASH_TRIM): COMAT_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 1024, 1024, 8, 40), (1, 300, 77, 8, 80), (2, 70, 70, 2, 40), (1, 130, 33, 1, 48)])
+@pytest.mark.parametrize("cfg", [(2, 1024, 1024, 8, 40), (1, 300, 77, 8, 80), (2, 70, 70, 2, 40), (1, 130, 33, 1, 48),
+                                 (1, 577, 577, 3, 64), (2, 64, 200, 2, 160), (2, 16, 37, 2, 16)])
 def test_flash_trim_is_bit_identical(hip, dtype, cfg, monkeypatch):
-    """COMAT_FLASH_TRIM=1 skips only MFMA steps whose operands are zero padding: outputs and gradients must be
-    bit-identical to the untrimmed kernels."""
+    """COMAT_FLASH_TRIM=1 skips only MFMA steps whose operands are zero padding, COMAT_FLASH_TR=1 only changes how the
+    k-major operand tiles are staged in LDS (transposed image, wide reads): outputs and gradients of every combination
+    must be bit-identical to the default kernels."""
     B, Nq, Nk, H, d = cfg
     q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
     g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
     res = []
-    for trim in ("0", "1"):
+    for trim, tr in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
         monkeypatch.setenv("COMAT_FLASH_TRIM", trim)
+        monkeypatch.setenv("COMAT_FLASH_TR", tr)
         qd, kd, vd = (dv(t, hip, dtype, grad=True) for t in (q, k_, v))
         o, _ = ops.attention(qd, kd, vd, B, Nq, Nk, H, d, need_probs=False)
         o.backward(dv(g, hip, dtype))
         res.append((o.detach(), qd.grad, kd.grad, vd.grad))
-    for a, b, name in zip(res[0], res[1], ("O", "dQ", "dK", "dV")):
-        assert torch.equal(a, b), f"trimmed {name} differs"
+    for i, variant in enumerate(res[1:], 1):
+        for a, b, name in zip(res[0], variant, ("O", "dQ", "dK", "dV")):
+            assert torch.equal(a, b), f"variant {i}: {name} differs from the default kernels"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

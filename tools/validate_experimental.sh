@@ -17,8 +17,10 @@ COMAT_TILE_AUTO=1 timeout 200 $B > gpurun_out/exp_tile_auto.log 2>&1 < /dev/null
 COMAT_KSPLIT=2 timeout 200 $B > gpurun_out/exp_ks2.log 2>&1 < /dev/null;                echo "KSPLIT=2         $(ms gpurun_out/exp_ks2.log)"
 COMAT_KSPLIT=4 timeout 200 $B > gpurun_out/exp_ks4.log 2>&1 < /dev/null;                echo "KSPLIT=4         $(ms gpurun_out/exp_ks4.log)"
 COMAT_FLASH_TRIM=1 timeout 200 $B > gpurun_out/exp_trim.log 2>&1 < /dev/null;            echo "FLASH_TRIM=1     $(ms gpurun_out/exp_trim.log)"
+COMAT_FLASH_TR=1 timeout 200 $B > gpurun_out/exp_tr.log 2>&1 < /dev/null;                echo "FLASH_TR=1       $(ms gpurun_out/exp_tr.log)"
+COMAT_FLASH_TR=1 COMAT_FLASH_TRIM=1 timeout 200 $B > gpurun_out/exp_tr_trim.log 2>&1 < /dev/null; echo "FLASH_TR+TRIM    $(ms gpurun_out/exp_tr_trim.log)"
 COMAT_BLIP_FUSED_QKV=1 timeout 200 $B > gpurun_out/exp_qkv.log 2>&1 < /dev/null;        echo "BLIP_FUSED_QKV=1 $(ms gpurun_out/exp_qkv.log)"
-COMAT_TILE_AUTO=1 COMAT_KSPLIT=2 COMAT_BLIP_FUSED_QKV=1 COMAT_FLASH_TRIM=1 timeout 200 $B > gpurun_out/exp_all.log 2>&1 < /dev/null; echo "all four         $(ms gpurun_out/exp_all.log)"
+COMAT_TILE_AUTO=1 COMAT_KSPLIT=2 COMAT_BLIP_FUSED_QKV=1 COMAT_FLASH_TRIM=1 COMAT_FLASH_TR=1 timeout 200 $B > gpurun_out/exp_all.log 2>&1 < /dev/null; echo "all five         $(ms gpurun_out/exp_all.log)"
 C3="python bench.py --config c3 --no-cpu-baseline --no-kernel-timing --steps 3 --warmup 2"
 timeout 300 $C3 > gpurun_out/exp_c3_base.log 2>&1 < /dev/null;                          echo "c3 baseline      $(ms gpurun_out/exp_c3_base.log)"
 COMAT_NOGRAD_MERGED=1 timeout 300 $C3 > gpurun_out/exp_c3_merged.log 2>&1 < /dev/null;  echo "c3 NOGRAD_MERGED $(ms gpurun_out/exp_c3_merged.log)"
