@@ -11,7 +11,10 @@ sites:
     controller when they require grad): attn_utils/tc_attn_utils.py:104-161
   - LoRA on to_q/to_k/to_v/to_out[0] of every attention, scale 1: training_utils/pipeline.py:84-115
   - VAE decode of latents / scaling_factor, then /2 + 0.5: TrainableSDPipeline.py:219-223
-The scheduler constants are pinned by the known answers of SURVEY.md §8(c) (tests/test_oracle.py).
+The scheduler constants are pinned by the known answers of SURVEY.md §8(c) (tests/test_oracle.py); the layer set,
+state-dict names and shapes this file consumes are pinned by public totals (SD1.5 UNet 859,520,964 parameters in 686
+tensors, SDXL UNet 2,567,463,684 in 1,680, VAE decoder 49,490,179: tests/test_architectures.py).  The arithmetic of
+each layer is what remains unpinned.
 Weights arrive as a flat dict with diffusers state-dict names (conv weights OIHW, linear weights [out, in]).
 """
 from __future__ import annotations
