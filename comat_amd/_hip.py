@@ -93,8 +93,12 @@ SIGNATURES = {
     "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_attnmap_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_sumsq": [_vp, _i64, _vp, _vp, _vp],
-    "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _f, _vp],
+    "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _vp, _f, _vp],
+    "comat_adamw_tick": [_vp, _vp, _vp],
+    "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
 }
+RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
+WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
 
 _lib = None
 
@@ -115,8 +119,8 @@ def load_library(path: str | None = None):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = C.c_int
-    if lib.comat_abi_version() != 1:
+        fn.restype = RESTYPES.get(name, C.c_int)
+    if lib.comat_abi_version() != 2:
         raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -161,7 +165,9 @@ class HipKernels:
 
     name = "hip"
 
-    WS_BYTES = 256 << 20  # split-K slab workspace per device (stream-ordered reuse)
+    # split-K workspace per (device, stream): [ticket counters (zeroed once, re-armed by the kernels) | fp32 slabs].
+    # comat_gemm_workspace_bytes() of the largest split problem of this workload (SDXL 16x16-level convs) is < 200 MB.
+    WS_BYTES = 256 << 20
 
     def __init__(self):
         load_library()
@@ -172,7 +178,11 @@ class HipKernels:
         ws = self._ws.get(key)
         if ws is None:
             ws = self._ws[key] = torch.empty(self.WS_BYTES // 4, dtype=torch.float32, device=dev)
+            ws[: WS_COUNTER_BYTES // 4].zero_()  # the ABI asks for zeroed ticket counters before the first use
         return ws
+
+    def gemm_workspace_bytes(self, M, N, K, batch=1, dtype=torch.bfloat16):
+        return int(_lib.comat_gemm_workspace_bytes(M, N, K, batch, BF16 if dtype == torch.bfloat16 else F32))
 
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
@@ -389,6 +399,12 @@ class HipKernels:
         ws = self._scratch(x.device, 1024)
         _check(_lib.comat_sumsq(_ptr(x), n, _ptr(out), _ptr(ws), _stream()), "comat_sumsq")
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None):
+        """step_dev: int32 [2] device counters (applied, skipped) or None; with it the bias correction uses
+        step_dev[0] + 1 and `step` is ignored (see adamw_tick)"""
         _check(_lib.comat_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, wd, step,
-                                _ptr(gnorm_sq), max_norm, _stream()), "comat_adamw")
+                                _ptr(step_dev), _ptr(gnorm_sq), max_norm, _stream()), "comat_adamw")
+
+    def adamw_tick(self, counters, gnorm_sq):
+        assert counters.dtype == torch.int32 and counters.numel() >= 2
+        _check(_lib.comat_adamw_tick(_ptr(counters), _ptr(gnorm_sq), _stream()), "comat_adamw_tick")

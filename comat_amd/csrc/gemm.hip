@@ -12,8 +12,7 @@
 // Fragment rule: lane (r = lane&31, h = lane>>5) of k-step s holds the 16 bytes at k-offset s*32 + h*16 of row r,
 // for A and B alike, so any k-permutation inside the MFMA cancels (sum over k).  C/D mapping of the 32x32 MFMA:
 // col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-#include "common.h"
-#include <stdlib.h>
+#include "gemm_shared.h"
 
 namespace {
 
@@ -23,16 +22,6 @@ constexpr int ROWB = KTB + 16;       // bytes per LDS row, k-contiguous image (3
 constexpr int CPR = KTB / 16;        // 16-byte chunks per row
 constexpr int PF = 4;  // k-tiles kept in flight per thread (register prefetch ring): hides HBM/L2 latency when few
                         // workgroups share a CU
-
-struct Epi {
-    void* C;
-    const float* bias;
-    const float* bias2;
-    const void* R;
-    int64_t ldc, ldr, rows_per_b2;
-    float alpha, beta;
-    int act, out_dt, r_dt;
-};
 
 template <typename T> struct FragOf;
 template <> struct FragOf<bf16_t> { typedef short8_t type; };
@@ -437,28 +426,29 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const f32x4_t& a, const f32x4
 // ---------------------------------------------------------------------------------------------------------------
 // Block-level main loop + fused epilogue
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, typename AL, typename BL, int NTH = NT>
+// split-K context of one block: slice `sp` of `splits` of output tile `tile` (linear over batch x tiles_m x tiles_n)
+struct SplitCtx {
+    float* slabs;       // [splits][ntiles][4 quads][NT threads] float4
+    unsigned* counter;  // this tile's ticket counter
+    int splits, sp;
+    int64_t tile, ntiles;
+};
+
+template <typename T, typename AL, typename BL>
 __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t kt1, int64_t m0, int64_t n0, int64_t M,
-                                           int64_t N, const Epi& ep, float* slab) {
-    // waves are arranged (NTH / 128) x 2: 4 waves -> 2 x 2, 8 waves -> 4 x 2 (rows x columns of the block tile)
-    constexpr int WR = NTH / 128;
-    constexpr int WTM = BM / WR, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32;
-    static_assert(TM >= 1 && TN >= 1, "block tile too small for the wave grid");
+                                           int64_t N, const Epi& ep, const SplitCtx& sk) {
+    // 4 waves as 2 x 2, one 32x32 MFMA tile per wave
     typedef typename FragOf<T>::type F;
-    constexpr int OPB = (BM > 64 || BN > 64) ? 128 * ROWB : 64 * ROWB;  // bytes per operand per stage (>= any image)
+    constexpr int OPB = 64 * ROWB;  // bytes per operand per stage (>= any image)
     __shared__ __attribute__((aligned(16))) char smem[2][2][OPB];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;  // wr in [0, WR)
+    const int wr = wave >> 1, wc = wave & 1;
 
-    f32x16_t acc[TM][TN];
+    f32x16_t acc;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
     // prologue: PF k-tiles in flight, the first one staged to LDS
 #pragma unroll
@@ -484,16 +474,9 @@ __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t 
                 const char* lb = smem[cur][1];
 #pragma unroll
                 for (int s = 0; s < KTB / 32; ++s) {
-                    F af[TM], bfr[TN];
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) af[a] = read_frag<T, BM, AL::kTrans>(la, wr * WTM + a * 32 + r, s, h);
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        bfr[b] = read_frag<T, BN, BL::kTrans>(lb, wc * WTN + b * 32 + r, s, h);
-#pragma unroll
-                    for (int a = 0; a < TM; ++a)
-#pragma unroll
-                        for (int b = 0; b < TN; ++b) mma(acc[a][b], af[a], bfr[b]);
+                    const F af = read_frag<T, 64, AL::kTrans>(la, wr * 32 + r, s, h);
+                    const F bfr = read_frag<T, 64, BL::kTrans>(lb, wc * 32 + r, s, h);
+                    mma(acc, af, bfr);
                 }
                 if (t + 1 < kt1) {
                     al.store(smem[cur ^ 1][0], (u + 1) % PF);
@@ -505,129 +488,32 @@ __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t 
         }
     }
 
-    if (slab) {  // split-K: raw fp32 partial sums, reduced + finished by splitk_reduce_kernel
+    if (sk.splits > 1) {
+        // split-K: park the fp32 partial tile (lane-linear float4 slabs), take a ticket; the last arriver of the tile
+        // adds the slices in slice order and finishes (gemm_shared.h) - no reduce launch
+        f32x4_t* mine = (f32x4_t*)sk.slabs + ((int64_t)sk.sp * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x;
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+        for (int q = 0; q < 4; ++q) {
+            f32x4_t v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            mine[q * NT] = v;
+        }
+        if (!splitk_arrive_is_last(sk.counter, sk.splits, (unsigned*)&smem[0][0][0])) return;
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int64_t col = n0 + wc * WTN + b * 32 + r;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int s2 = 0; s2 < sk.splits; ++s2) {
+            const f32x4_t* src = (const f32x4_t*)sk.slabs + ((int64_t)s2 * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int64_t row = m0 + wr * WTM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (row < M && col < N) slab[row * N + col] = acc[a][b][i];
-                }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t v = src[q * NT];
+                acc[4 * q] += v[0];
+                acc[4 * q + 1] += v[1];
+                acc[4 * q + 2] += v[2];
+                acc[4 * q + 3] += v[3];
             }
-        return;
+        }
     }
     // epilogue: v = act(alpha*acc + bias + bias2) + beta*R
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int64_t col = n0 + wc * WTN + b * 32 + r;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t row = m0 + wr * WTM + a * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (row < M && col < N) {
-                    float v = ep.alpha * acc[a][b][i];
-                    if (ep.bias) v += ep.bias[col];
-                    if (ep.bias2) v += ep.bias2[(row / ep.rows_per_b2) * N + col];
-                    if (ep.act == COMAT_ACT_SILU) v = silu_f(v);
-                    else if (ep.act == COMAT_ACT_GELU) v = gelu_f(v);
-                    if (ep.R) v += ep.beta * ld_dt(ep.R, row * ep.ldr + col, ep.r_dt);
-                    st_dt(ep.C, row * ep.ldc + col, v, ep.out_dt);
-                }
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// In-block split-K (experimental, COMAT_KSPLIT): KS groups of 4 waves share ONE 64x64 output tile.  Group g streams
-// its own contiguous slice of the k-range through its own LDS buffers (so a block keeps KS times as many loads in
-// flight and its serial k-loop is KS times shorter); at the end groups 1..KS-1 park their accumulators in LDS and
-// group 0 adds them in group order and runs the epilogue.  Same arithmetic as a global split-K of KS, without the
-// fp32 slab round trip through HBM and without the reduce launch.  All groups run the same number of iterations
-// (the loaders deliver zeros past a group's slice), so the block-wide barriers stay uniform.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T, typename AL, typename BL, int KS>
-__device__ __forceinline__ void gemm_block_ks(AL& al, BL& bl, int64_t niter, int grp, int64_t m0, int64_t n0, int64_t M,
-                                              int64_t N, const Epi& ep, float* slab) {
-    typedef typename FragOf<T>::type F;
-    constexpr int OPB = 64 * ROWB;
-    __shared__ __attribute__((aligned(16))) char smem[KS][2][2][OPB];
-    static_assert(2 * 2 * OPB >= 64 * 64 * 4, "a group's LDS must hold its 64x64 fp32 partial tile");
-    char(*sm)[2][OPB] = smem[grp];
-
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-
-    f32x16_t acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (u < niter) {
-            al.load(u);
-            bl.load(u);
-        }
-    al.store(sm[0][0], 0);
-    bl.store(sm[0][1], 0);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t kt = 0; kt < niter; kt += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int64_t t = kt + u;
-            if (t < niter) {
-                if (t + PF < niter) {
-                    al.load(u);
-                    bl.load(u);
-                }
-                const char* la = sm[cur][0];
-                const char* lb = sm[cur][1];
-#pragma unroll
-                for (int s2 = 0; s2 < KTB / 32; ++s2) {
-                    const F af = read_frag<T, 64, AL::kTrans>(la, wr * 32 + r, s2, h);
-                    const F bf = read_frag<T, 64, BL::kTrans>(lb, wc * 32 + r, s2, h);
-                    mma(acc, af, bf);
-                }
-                if (t + 1 < niter) {
-                    al.store(sm[cur ^ 1][0], (u + 1) % PF);
-                    bl.store(sm[cur ^ 1][1], (u + 1) % PF);
-                }
-                __syncthreads();
-                cur ^= 1;
-            }
-        }
-    }
-    // combine the groups' partial tiles in LDS, in group order (fixed summation order)
-    if (KS > 1) {
-        float* red = (float*)smem[grp];
-        if (grp > 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                red[(wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + wc * 32 + r] = acc[i];
-        }
-        __syncthreads();
-        if (grp > 0) return;
-#pragma unroll
-        for (int g2 = 1; g2 < KS; ++g2) {
-            const float* rg = (const float*)smem[g2];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] += rg[(wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h) * 64 + wc * 32 + r];
-        }
-    }
     const int64_t col = n0 + wc * 32 + r;
-    if (slab) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t row = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (row < M && col < N) slab[row * N + col] = acc[i];
-        }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t row = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -650,55 +536,55 @@ struct GemmArgs {
     int64_t batch2, sA1, sA2, sB1, sB2, sC1, sC2, sR1, sR2;
     int tiles_m, tiles_n;
     int splits;
-    float* ws;
+    int64_t ntiles;  // batch * tiles_m * tiles_n
+    float* ws;       // [counters | slabs]
     Epi ep;
 };
 
-// XCD-aware workgroup -> work-item map.  Workgroup b is dispatched to XCD b % 8 (MI355X: 8 XCDs, a private 4 MiB L2
-// each).  Give every XCD one CONTIGUOUS chunk of the linear work list, ordered so that neighbours share the same
-// activation rows and stream the (small) weight panel: the chunk's operands then stay resident in that XCD's L2
-// instead of every XCD thrashing over the whole problem.  Bijective for any count; affects speed only.
-__device__ __forceinline__ int64_t xcd_chunk_map(int64_t bid, int64_t n) {
-    const int64_t q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    const int64_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + idx;
-}
-
 // k-tile range of split s
-__device__ __forceinline__ void split_range(int64_t K, int bke, int splits, int s, int64_t& kt0, int64_t& kt1) {
-    const int64_t nk = (K + bke - 1) / bke;
+__device__ __forceinline__ void split_range(int64_t nk, int splits, int s, int64_t& kt0, int64_t& kt1) {
     const int64_t per = (nk + splits - 1) / splits;
     kt0 = (int64_t)s * per;
     kt1 = kt0 + per < nk ? kt0 + per : nk;
     if (kt0 > nk) kt0 = nk;
 }
 
-template <typename T, int BM, int BN, bool TA, bool TB, int NTH = NT>
-__global__ __launch_bounds__(NTH) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ SplitCtx make_split(float* ws, int splits, int sp, int64_t tile, int64_t ntiles) {
+    SplitCtx sk;
+    sk.slabs = ws + WS_COUNTERS;
+    sk.counter = (unsigned*)ws + tile;
+    sk.splits = splits;
+    sk.sp = sp;
+    sk.tile = tile;
+    sk.ntiles = ntiles;
+    return sk;
+}
+
+template <typename T, bool TA, bool TB> __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
     // linear work id = ((z * tiles_m + tm) * tiles_n + tn) * splits + split
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
     lin /= g.splits;
+    const int64_t tile = lin;
     const int tn = (int)(lin % g.tiles_n);
     lin /= g.tiles_n;
     const int tm = (int)(lin % g.tiles_m);
     const int64_t z = lin / g.tiles_m, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
+    constexpr int BKE = KTB / (int)sizeof(T);
     int64_t kt0, kt1;
-    split_range(g.K, KTB / (int)sizeof(T), g.splits, sp, kt0, kt1);
-    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    split_range((g.K + BKE - 1) / BKE, g.splits, sp, kt0, kt1);
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
     const T* A = (const T*)g.A + b1 * g.sA1 + b2 * g.sA2;
     const T* B = (const T*)g.B + b1 * g.sB1 + b2 * g.sB2;
     Epi ep = g.ep;
     const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
     ep.C = (char*)ep.C + coff * (ep.out_dt == COMAT_F32 ? 4 : 2);
     if (ep.R) ep.R = (const char*)ep.R + roff * (ep.r_dt == COMAT_F32 ? 4 : 2);
-    PlainLoader<T, BM, TA, NTH> al;
-    PlainLoader<T, BN, TB, NTH> bl;
+    PlainLoader<T, 64, TA> al;
+    PlainLoader<T, 64, TB> bl;
     al.init(A, g.lda, m0, g.M, g.K, kt0);
     bl.init(B, g.ldb, n0, g.N, g.K, kt0);
-    gemm_block<T, BM, BN, PlainLoader<T, BM, TA, NTH>, PlainLoader<T, BN, TB, NTH>, NTH>(al, bl, kt0, kt1, m0, n0, g.M, g.N,
-                                                                                       ep, slab);
+    gemm_block<T>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, make_split(g.ws, g.splits, sp, tile, g.ntiles));
 }
 
 struct GemmSegArgs {
@@ -706,6 +592,7 @@ struct GemmSegArgs {
     int64_t M, N, nk;
     int64_t sC, sR, sBias;  // batch strides (elements) of C, R and bias
     int tiles_m, tiles_n, splits;
+    int64_t ntiles;
     float* ws;
     Epi ep;
 };
@@ -714,15 +601,13 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_seg_kernel(Gemm
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
     lin /= g.splits;
+    const int64_t tile = lin;
     const int tn = (int)(lin % g.tiles_n);
     lin /= g.tiles_n;
     const int tm = (int)(lin % g.tiles_m);
     const int64_t z = lin / g.tiles_m;
-    const int64_t per = (g.nk + g.splits - 1) / g.splits;
-    int64_t kt0 = (int64_t)sp * per;
-    const int64_t kt1 = kt0 + per < g.nk ? kt0 + per : g.nk;
-    if (kt0 > g.nk) kt0 = g.nk;
-    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
+    int64_t kt0, kt1;
+    split_range(g.nk, g.splits, sp, kt0, kt1);
     const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
     Epi ep = g.ep;
     ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
@@ -732,36 +617,8 @@ template <typename T> __global__ __launch_bounds__(NT) void gemm_seg_kernel(Gemm
     al.t = bl.t = &g.t;
     al.l.init(g.t, false, m0, g.M, kt0, z);
     bl.l.init(g.t, true, n0, g.N, kt0, z);
-    gemm_block<T, 64, 64>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, slab);
+    gemm_block<T>(al, bl, kt0, kt1, m0, n0, g.M, g.N, ep, make_split(g.ws, g.splits, sp, tile, g.ntiles));
 }
-
-#ifndef COMAT_GEMM_EXP_TU  // the reduce pass is launched by the default translation unit only
-// sums the split-K slabs and applies the fused epilogue: C = act(alpha*sum + bias + bias2) + beta*R
-struct ReduceArgs {
-    const float* ws;
-    int64_t M, N, batch2, sC1, sC2, sR1, sR2;
-    int splits;
-    Epi ep;
-};
-__global__ __launch_bounds__(NT) void splitk_reduce_kernel(ReduceArgs g) {
-    const int64_t mn = g.M * g.N;
-    const int64_t z = blockIdx.y, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
-    const float* base = g.ws + z * g.splits * mn;
-    const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < mn; i += (int64_t)gridDim.x * NT) {
-        float v = 0.f;
-        for (int s = 0; s < g.splits; ++s) v += base[s * mn + i];
-        const int64_t row = i / g.N, col = i - row * g.N;
-        v *= g.ep.alpha;
-        if (g.ep.bias) v += g.ep.bias[col];
-        if (g.ep.bias2) v += g.ep.bias2[(row / g.ep.rows_per_b2) * g.N + col];
-        if (g.ep.act == COMAT_ACT_SILU) v = silu_f(v);
-        else if (g.ep.act == COMAT_ACT_GELU) v = gelu_f(v);
-        if (g.ep.R) v += g.ep.beta * ld_dt(g.ep.R, roff + row * g.ep.ldr + col, g.ep.r_dt);
-        st_dt(g.ep.C, coff + row * g.ep.ldc + col, v, g.ep.out_dt);
-    }
-}
-#endif
 
 struct ConvArgs {
     const void* X;
@@ -770,291 +627,80 @@ struct ConvArgs {
     int64_t M, N, K;
     int tiles_m, tiles_n;
     int splits;
+    int64_t ntiles;
     float* ws;
     Epi ep;
 };
 
-template <typename T, int BM, int BN, int NTH = NT> __global__ __launch_bounds__(NTH) void conv_kernel(ConvArgs g) {
+template <typename T> __global__ __launch_bounds__(NT) void conv_kernel(ConvArgs g) {
     int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = (int)(lin % g.splits);
     lin /= g.splits;
+    const int64_t tile = lin;
     const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
+    constexpr int BKE = KTB / (int)sizeof(T);
     int64_t kt0, kt1;
-    split_range(g.K, KTB / (int)sizeof(T), g.splits, sp, kt0, kt1);
-    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
-    ConvLoader<T, BM, NTH> al;
-    PlainLoader<T, BN, false, NTH> bl;
+    split_range((g.K + BKE - 1) / BKE, g.splits, sp, kt0, kt1);
+    ConvLoader<T, 64> al;
+    PlainLoader<T, 64, false> bl;
     al.init(g.X, g.geo, m0, g.M, kt0);
     bl.init(g.W, g.K, n0, g.N, g.K, kt0);
-    gemm_block<T, BM, BN, ConvLoader<T, BM, NTH>, PlainLoader<T, BN, false, NTH>, NTH>(al, bl, kt0, kt1, m0, n0, g.M, g.N,
-                                                                                     g.ep, slab);
+    gemm_block<T>(al, bl, kt0, kt1, m0, n0, g.M, g.N, g.ep, make_split(g.ws, g.splits, sp, tile, g.ntiles));
 }
 
-// in-block split-K variants of gemm_kernel / conv_kernel (64x64 tile, KS wave groups, NT*KS threads per block)
-template <typename T, bool TA, bool TB, int KS> __global__ __launch_bounds__(NT * KS) void gemm_ks_kernel(GemmArgs g) {
-    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
-    const int sp = (int)(lin % g.splits);
-    lin /= g.splits;
-    const int tn = (int)(lin % g.tiles_n);
-    lin /= g.tiles_n;
-    const int tm = (int)(lin % g.tiles_m);
-    const int64_t z = lin / g.tiles_m, b1 = z / g.batch2, b2 = z - b1 * g.batch2;
-    constexpr int BKE = KTB / (int)sizeof(T);
-    int64_t kt0, kt1;
-    split_range(g.K, BKE, g.splits, sp, kt0, kt1);
-    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
-    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
-    const T* A = (const T*)g.A + b1 * g.sA1 + b2 * g.sA2;
-    const T* B = (const T*)g.B + b1 * g.sB1 + b2 * g.sB2;
-    Epi ep = g.ep;
-    const int64_t coff = b1 * g.sC1 + b2 * g.sC2, roff = b1 * g.sR1 + b2 * g.sR2;
-    ep.C = (char*)ep.C + coff * (ep.out_dt == COMAT_F32 ? 4 : 2);
-    if (ep.R) ep.R = (const char*)ep.R + roff * (ep.r_dt == COMAT_F32 ? 4 : 2);
-    // this group's slice of the block's k-range
-    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
-    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
-    const int64_t gk0 = kt0 + grp * per;
-    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
-    if (gk1 < gk0) gk1 = gk0;
-    int64_t klim = gk1 * BKE < g.K ? gk1 * BKE : g.K;  // the loaders deliver zeros from here on
-    if (gk1 == gk0) klim = 0;
-    PlainLoader<T, 64, TA> al;
-    PlainLoader<T, 64, TB> bl;
-    al.init(A, g.lda, m0, g.M, klim, gk0, tid);
-    bl.init(B, g.ldb, n0, g.N, klim, gk0, tid);
-    gemm_block_ks<T, PlainLoader<T, 64, TA>, PlainLoader<T, 64, TB>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, ep, slab);
-}
-
-template <typename T, int KS> __global__ __launch_bounds__(NT * KS) void conv_ks_kernel(ConvArgs g) {
-    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
-    const int sp = (int)(lin % g.splits);
-    lin /= g.splits;
-    const int tn = (int)(lin % g.tiles_n), tm = (int)(lin / g.tiles_n);
-    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
-    constexpr int BKE = KTB / (int)sizeof(T);
-    int64_t kt0, kt1;
-    split_range(g.K, BKE, g.splits, sp, kt0, kt1);
-    float* slab = g.splits > 1 ? g.ws + (int64_t)sp * g.M * g.N : nullptr;
-    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
-    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
-    const int64_t gk0 = kt0 + grp * per;
-    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
-    if (gk1 < gk0) gk1 = gk0;
-    int64_t klim = gk1 * BKE < g.K ? gk1 * BKE : g.K;
-    if (gk1 == gk0) klim = 0;
-    ConvLoader<T, 64, NT, true> al;
-    PlainLoader<T, 64, false> bl;
-    al.init(g.X, g.geo, m0, g.M, gk0, tid, (int)(gk1 - gk0));
-    bl.init(g.W, g.K, n0, g.N, klim, gk0, tid);
-    gemm_block_ks<T, ConvLoader<T, 64, NT, true>, PlainLoader<T, 64, false>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, g.ep,
-                                                                                slab);
-}
-
-template <typename T, int KS> __global__ __launch_bounds__(NT * KS) void gemm_seg_ks_kernel(GemmSegArgs g) {
-    int64_t lin = xcd_chunk_map(blockIdx.x, gridDim.x);
-    const int sp = (int)(lin % g.splits);
-    lin /= g.splits;
-    const int tn = (int)(lin % g.tiles_n);
-    lin /= g.tiles_n;
-    const int tm = (int)(lin % g.tiles_m);
-    const int64_t z = lin / g.tiles_m;
-    const int64_t sper = (g.nk + g.splits - 1) / g.splits;
-    int64_t kt0 = (int64_t)sp * sper;
-    const int64_t kt1 = kt0 + sper < g.nk ? kt0 + sper : g.nk;
-    if (kt0 > g.nk) kt0 = g.nk;
-    float* slab = g.splits > 1 ? g.ws + ((int64_t)(z * g.splits + sp)) * g.M * g.N : nullptr;
-    const int64_t m0 = (int64_t)tm * 64, n0 = (int64_t)tn * 64;
-    Epi ep = g.ep;
-    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
-    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
-    if (ep.bias) ep.bias += z * g.sBias;
-    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
-    const int64_t per = (kt1 - kt0 + KS - 1) / KS;
-    int64_t gk0 = kt0 + grp * per;
-    int64_t gk1 = gk0 + per < kt1 ? gk0 + per : kt1;
-    if (gk0 > kt1) gk0 = kt1;
-    if (gk1 < gk0) gk1 = gk0;
-    SegLoaderRef<T, 64, true> al, bl;
-    al.t = bl.t = &g.t;
-    al.l.init(g.t, false, m0, g.M, gk0, z, tid, gk1 - gk0);
-    bl.l.init(g.t, true, n0, g.N, gk0, z, tid, gk1 - gk0);
-    gemm_block_ks<T, SegLoaderRef<T, 64, true>, SegLoaderRef<T, 64, true>, KS>(al, bl, per, grp, m0, n0, g.M, g.N, ep, slab);
-}
-
-template <typename T, int BM, int BN, int NTH = NT>
-int launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
+template <typename T> void launch_gemm_t(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
     switch (trans) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, false, NTH>), grid, dim3(NTH), 0, st, g); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, false, NTH>), grid, dim3(NTH), 0, st, g); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, false, true, NTH>), grid, dim3(NTH), 0, st, g); break;
-        default: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, true, true, NTH>), grid, dim3(NTH), 0, st, g); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(NT), 0, st, g); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(NT), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, dim3(NT), 0, st, g); break;
+        default: hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(NT), 0, st, g); break;
     }
-    return 0;
 }
 
-// Tile and split-K choice.  These problems are short on tiles (M <= 16384, N <= 1280): prefer enough workgroups to
-// put several on every CU (the k-loop is latency-bound otherwise) — first through the tile size, then through
-// split-K with fp32 slabs in the caller's workspace (>= 8 k-tiles per split so the slab traffic stays small).
-struct TilePlan {
-    int bm, bn;   // block tile: 64x64 (default), or 128x128 / 128x64 / 64x128 through COMAT_FORCE_TILE (experiments)
-    int nth;      // threads per block: 256, or 512 (8 waves, 4 x 2) for the experimental 128x128 variant "1288"
-    int splits;
-};
-TilePlan plan_tiles(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes,
-                    bool allow_variants = true) {
-    TilePlan p;
-    // measured on MI355X (tools/microbench_gemm.py): the 64x64 tile (5 workgroups/CU) beats 128x128 (2/CU) on every
-    // shape of this workload; the larger tiles (bf16 only) are kept for COMAT_FORCE_TILE experiments:
-    // 128 -> 128x128, 12864 -> 128x64, 64128 -> 64x128; with 8 waves per block: 1288 -> 128x128, 128648 -> 128x64
-    p.bm = p.bn = 64;
-    p.nth = NT;
-    p.splits = 1;
-    const char* force_tile = getenv("COMAT_FORCE_TILE");      // tuning knobs (tools/microbench_gemm.py), read per
-    const char* force_split = getenv("COMAT_FORCE_SPLITS");   // call so that tests can switch variants in-process
-    if (force_tile && allow_variants) {
-        const int v = atoi(force_tile);
-        if (v == 128) p.bm = p.bn = 128;
-        else if (v == 1288) { p.bm = p.bn = 128; p.nth = 512; }
-        else if (v == 128648) { p.bm = 128; p.nth = 512; }
-        else if (v == 12864) p.bm = 128;
-        else if (v == 64128) p.bn = 128;
-    }
-    // COMAT_TILE_AUTO=1 (experimental): the 8-wave 128x128 block where there are enough of
-    // them to fill the chip twice over (measured: VAE convs 295 -> 423 TFLOP/s), the 64x64 block elsewhere
-    const char* tile_auto = getenv("COMAT_TILE_AUTO");
-    if (allow_variants && !force_tile && tile_auto && atoi(tile_auto) == 1 && bke == KTB / 2 &&
-        cdiv64(M, 128) * cdiv64(N, 128) * batch >= 512) {
-        p.bm = p.bn = 128;
-        p.nth = 512;
-    }
-    const int64_t blocks = cdiv64(M, p.bm) * cdiv64(N, p.bn) * batch;
+// Split-K choice for the 64x64 tile kernel.  These problems are short on tiles (M <= 16384, N <= 1280): prefer enough
+// workgroups to put several on every CU (the k-loop is latency-bound otherwise), >= 8 k-tiles per split so that the
+// slab traffic stays small; bounded by the caller's workspace (slabs) and by the ticket counters (one per tile).
+int plan_splits(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
+    static int force = 0;
+    static bool have = false;
+    env_int_once("COMAT_FORCE_SPLITS", 0, &force, &have);  // tuning knob (tools/microbench_gemm.py)
+    const int64_t ntiles = cdiv64(M, 64) * cdiv64(N, 64) * batch;
     const int64_t nk = cdiv64(K, bke);
-    if (force_split) {
-        int64_t s = atoi(force_split);
-        const int64_t cap = ws_bytes > 0 ? ws_bytes / (batch * M * N * 4) : 1;
-        if (s > cap) s = cap;
-        if (s > nk) s = nk;
-        p.splits = s < 1 ? 1 : (int)s;
-        return p;
-    }
-    // split when the grid leaves CUs idle and the serial k-loop is long enough (>= 8 k-tiles per split) to pay for
-    // the reduce pass; measured with tools/microbench_gemm.py on the shapes of this workload
-    if (ws_bytes > 0 && blocks < 768 && nk >= 16) {
-        int64_t s = cdiv64(1024, blocks);
+    const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
+    if (slab_bytes <= 0 || ntiles > WS_COUNTERS) return 1;
+    const int64_t cap = slab_bytes / (ntiles * 64 * 64 * 4);
+    int64_t s = 1;
+    if (force > 0) s = force;
+    else if (ntiles < 768 && nk >= 16) {
+        s = cdiv64(1024, ntiles);
         if (s > nk / 8) s = nk / 8;
-        const int64_t cap = ws_bytes / (batch * M * N * 4);
-        if (s > cap) s = cap;
-        if (s > 64) s = 64;
-        if (s >= 2) p.splits = (int)s;
     }
-    return p;
+    if (s > cap) s = cap;
+    if (s > nk) s = nk;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
 }
-
-// COMAT_KSPLIT=2|4 (experimental): turn (part of) a planned global split-K into an in-block split over KS wave groups
-int inblock_ksplit(int planned_splits) {
-    const char* e = getenv("COMAT_KSPLIT");
-    const int ks = e ? atoi(e) : 1;
-    if ((ks != 2 && ks != 4) || planned_splits < 2) return 1;
-    return (ks == 4 && planned_splits >= 4) ? 4 : 2;
-}
-
-template <typename T, int KS> void launch_gemm_ks(const GemmArgs& g, int trans, dim3 grid, hipStream_t st) {
-    switch (trans) {
-        case 0: hipLaunchKernelGGL((gemm_ks_kernel<T, false, false, KS>), grid, dim3(NT * KS), 0, st, g); break;
-        case 1: hipLaunchKernelGGL((gemm_ks_kernel<T, true, false, KS>), grid, dim3(NT * KS), 0, st, g); break;
-        case 2: hipLaunchKernelGGL((gemm_ks_kernel<T, false, true, KS>), grid, dim3(NT * KS), 0, st, g); break;
-        default: hipLaunchKernelGGL((gemm_ks_kernel<T, true, true, KS>), grid, dim3(NT * KS), 0, st, g); break;
-    }
-}
-
-#ifndef COMAT_GEMM_EXP_TU
-void launch_reduce(const float* ws, int64_t M, int64_t N, int64_t batch, int64_t batch2, int64_t sC1, int64_t sC2,
-                   int64_t sR1, int64_t sR2, int splits, const Epi& ep, hipStream_t st) {
-    ReduceArgs r;
-    r.ws = ws; r.M = M; r.N = N; r.batch2 = batch2; r.sC1 = sC1; r.sC2 = sC2; r.sR1 = sR1; r.sR2 = sR2;
-    r.splits = splits; r.ep = ep;
-    int gx = (int)cdiv64(M * N, NT);
-    if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gx, (unsigned)batch), dim3(NT), 0, st, r);
-}
-#endif
 
 }  // namespace
 
-// ---------------------------------------------------------------------------------------------------------------
-// Experimental kernel variants (non-default block tiles, 8-wave blocks, in-block split-K) are instantiated in a second
-// translation unit — gemm_exp.hip compiles this file with COMAT_GEMM_EXP_TU defined — so that the two halves build in
-// parallel.  The argument structs live in the anonymous namespace of each unit (same source, same layout), hence the
-// `const void*` hand-over.
-// ---------------------------------------------------------------------------------------------------------------
-bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
-                               void* stream);
-bool comat_conv_launch_variant(const void* cargs, int bf, int bm, int bn, int nth, int ks, unsigned tiles, void* stream);
-bool comat_gemm_seg_launch_variant(const void* sargs, int bf, int ks, unsigned tiles, void* stream);
-
-#ifdef COMAT_GEMM_EXP_TU
-
-bool comat_gemm_seg_launch_variant(const void* sargs, int bf, int ks, unsigned tiles, void* stream) {
-    const GemmSegArgs& g = *(const GemmSegArgs*)sargs;
-    dim3 grid(tiles, 1, 1);
-    hipStream_t st = (hipStream_t)stream;
-    if (bf && ks == 4) hipLaunchKernelGGL((gemm_seg_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
-    else if (bf && ks == 2) hipLaunchKernelGGL((gemm_seg_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
-    else if (!bf && ks == 2) hipLaunchKernelGGL((gemm_seg_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
-    else return false;
-    return true;
-}
-
-bool comat_gemm_launch_variant(const void* gargs, int bf, int trans, int bm, int bn, int nth, int ks, unsigned tiles,
-                               void* stream) {
-    const GemmArgs& g = *(const GemmArgs*)gargs;
-    dim3 grid(tiles, 1, 1);
-    hipStream_t st = (hipStream_t)stream;
-    if (ks > 1) {
-        if (bf) {
-            if (ks == 4) launch_gemm_ks<bf16_t, 4>(g, trans, grid, st);
-            else launch_gemm_ks<bf16_t, 2>(g, trans, grid, st);
-        } else {
-            launch_gemm_ks<float, 2>(g, trans, grid, st);
-        }
-        return true;
+extern "C" int64_t comat_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int32_t in_dtype) {
+    // counters + the slabs of the largest split the planners would pick for this problem (both kernels: <= 64 slices of
+    // the padded fp32 output)
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return COMAT_WS_COUNTER_BYTES;
+    const int bke = in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
+    const int64_t ntiles = cdiv64(M, 64) * cdiv64(N, 64) * batch;
+    const int64_t nk = cdiv64(K, bke);
+    int64_t s = 1;
+    if (ntiles < 768 && nk >= 16) {
+        s = cdiv64(1024, ntiles);
+        if (s > nk / 8) s = nk / 8;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
     }
-    if (!bf) return false;
-    if (bm == 128 && bn == 128 && nth == 512) launch_gemm_t<bf16_t, 128, 128, 512>(g, trans, grid, st);
-    else if (bm == 128 && bn == 128) launch_gemm_t<bf16_t, 128, 128>(g, trans, grid, st);
-    else if (bm == 128 && nth == 512) launch_gemm_t<bf16_t, 128, 64, 512>(g, trans, grid, st);
-    else if (bm == 128) launch_gemm_t<bf16_t, 128, 64>(g, trans, grid, st);
-    else if (bn == 128) launch_gemm_t<bf16_t, 64, 128>(g, trans, grid, st);
-    else return false;
-    return true;
+    const int64_t pm = cdiv64(M, 128) * 128, pn = cdiv64(N, 128) * 128;
+    return COMAT_WS_COUNTER_BYTES + s * batch * pm * pn * 4;
 }
-
-bool comat_conv_launch_variant(const void* cargs, int bf, int bm, int bn, int nth, int ks, unsigned tiles, void* stream) {
-    const ConvArgs& g = *(const ConvArgs*)cargs;
-    dim3 grid(tiles, 1, 1);
-    hipStream_t st = (hipStream_t)stream;
-    if (ks > 1) {
-        if (bf) {
-            if (ks == 4) hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 4>), grid, dim3(NT * 4), 0, st, g);
-            else hipLaunchKernelGGL((conv_ks_kernel<bf16_t, 2>), grid, dim3(NT * 2), 0, st, g);
-        } else {
-            hipLaunchKernelGGL((conv_ks_kernel<float, 2>), grid, dim3(NT * 2), 0, st, g);
-        }
-        return true;
-    }
-    if (!bf) return false;
-    if (bm == 128 && bn == 128 && nth == 512)
-        hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128, 512>), grid, dim3(512), 0, st, g);
-    else if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 128>), grid, dim3(NT), 0, st, g);
-    else if (bm == 128 && nth == 512) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64, 512>), grid, dim3(512), 0, st, g);
-    else if (bm == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 128, 64>), grid, dim3(NT), 0, st, g);
-    else if (bn == 128) hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 128>), grid, dim3(NT), 0, st, g);
-    else return false;
-    return true;
-}
-
-#else  // the default translation unit: entry points + the default (64x64, 4 waves) kernels
 
 extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p != nullptr, "comat_gemm: null params");
@@ -1068,6 +714,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
+    if (const int rc = comat_gemm2_try_gemm(p, stream)) return rc < 0 ? rc : comat_check_launch("comat_gemm");
     GemmArgs g;
     g.A = p->A; g.B = p->B;
     g.M = p->M; g.N = p->N; g.K = p->K; g.lda = p->lda; g.ldb = p->ldb;
@@ -1079,35 +726,20 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
     const int64_t batch = p->batch1 * p->batch2;
-    const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
-    const TilePlan plan = plan_tiles(p->M, p->N, p->K, bke, batch, p->ws ? p->ws_bytes : 0);
     const bool bf = p->in_dtype == COMAT_BF16;
-    const int tile = (plan.bm == 128 ? 2 : 0) | (plan.bn == 128 ? 1 : 0);  // 0: 64x64, 1: 64x128, 2: 128x64, 3: 128x128
-    (void)tile;
-    const int bm = bf ? plan.bm : 64, bn = bf ? plan.bn : 64;  // the larger tiles exist for bf16 only
-    g.tiles_m = (int)cdiv64(p->M, bm);
-    g.tiles_n = (int)cdiv64(p->N, bn);
-    int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
-    if (!bf && ks > 2) ks = 2;  // fp32 (parity mode): two wave groups at most
-    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;  // nearest: prefer no global reduce pass
-    if (g.splits < 1) g.splits = 1;
-    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
-    COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm: too many tiles");
+    const int bke = bf ? KTB / 2 : KTB / 4;
+    g.tiles_m = (int)cdiv64(p->M, 64);
+    g.tiles_n = (int)cdiv64(p->N, 64);
+    g.ntiles = (int64_t)g.tiles_m * g.tiles_n * batch;
+    g.splits = plan_splits(p->M, p->N, p->K, bke, batch, p->ws ? p->ws_bytes : 0);
+    const int64_t blocks = g.ntiles * g.splits;
+    COMAT_REQUIRE(blocks < (1ll << 31), "comat_gemm: too many tiles");
     g.ws = (float*)p->ws;
-    dim3 grid((unsigned)tiles, 1, 1);
+    dim3 grid((unsigned)blocks, 1, 1);
     hipStream_t st = (hipStream_t)stream;
     const int trans = (p->transA ? 1 : 0) | (p->transB ? 2 : 0);
-    const bool variant = ks > 1 || bm != 64 || bn != 64;
-    if (variant) {
-        COMAT_REQUIRE(comat_gemm_launch_variant(&g, bf ? 1 : 0, trans, bm, bn, plan.nth, ks, (unsigned)tiles, stream),
-                      "comat_gemm: unsupported kernel variant");
-    } else if (bf) {
-        launch_gemm_t<bf16_t, 64, 64>(g, trans, grid, st);
-    } else {
-        launch_gemm_t<float, 64, 64>(g, trans, grid, st);
-    }
-    if (g.splits > 1)
-        launch_reduce(g.ws, p->M, p->N, batch, p->batch2, p->sC1, p->sC2, p->sR1, p->sR2, g.splits, g.ep, st);
+    if (bf) launch_gemm_t<bf16_t>(g, trans, grid, st);
+    else launch_gemm_t<float>(g, trans, grid, st);
     return comat_check_launch("comat_gemm");
 }
 
@@ -1124,15 +756,19 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     COMAT_REQUIRE(batch == 1 || !p->bias2, "comat_gemm_segments: bias2 is not supported with a batch");
     COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm_segments: bias2 needs rows_per_bias2");
     COMAT_REQUIRE(p->ldc >= p->N, "comat_gemm_segments: ldc too small");
+    for (int s = 0; s < nseg; ++s) {
+        COMAT_REQUIRE(segs[s].A && segs[s].B && segs[s].K > 0 && segs[s].K < (1ll << 30),
+                      "comat_gemm_segments: bad segment %d", s);
+        COMAT_REQUIRE(segs[s].lda >= segs[s].K && segs[s].ldb >= segs[s].K,
+                      "comat_gemm_segments: leading dimension of segment %d too small", s);
+    }
+    if (const int rc = comat_gemm2_try_segments(p, segs, nseg, stream))
+        return rc < 0 ? rc : comat_check_launch("comat_gemm_segments");
     GemmSegArgs g;
     const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
     g.nk = 0;
     for (int s = 0; s < MAXSEG; ++s) {
         if (s < nseg) {
-            COMAT_REQUIRE(segs[s].A && segs[s].B && segs[s].K > 0 && segs[s].K < (1ll << 30),
-                          "comat_gemm_segments: bad segment %d", s);
-            COMAT_REQUIRE(segs[s].lda >= segs[s].K && segs[s].ldb >= segs[s].K,
-                          "comat_gemm_segments: leading dimension of segment %d too small", s);
             g.t.A[s] = segs[s].A; g.t.B[s] = segs[s].B;
             g.t.lda[s] = segs[s].lda; g.t.ldb[s] = segs[s].ldb; g.t.K[s] = (int)segs[s].K;
             g.t.sA[s] = segs[s].sA; g.t.sB[s] = segs[s].sB;
@@ -1150,29 +786,16 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
     g.sC = p->sC1; g.sR = p->sR1; g.sBias = p->bias ? p->N : 0;  // bias: [batch, N] when batched
-    TilePlan plan = plan_tiles(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0, false);
     g.tiles_m = (int)cdiv64(p->M, 64);
     g.tiles_n = (int)cdiv64(p->N, 64);
-    int ks = inblock_ksplit(plan.splits);
-    if (p->in_dtype != COMAT_BF16 && ks > 2) ks = 2;
-    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;
-    if (g.splits < 1) g.splits = 1;
-    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits * batch;
-    COMAT_REQUIRE(tiles < (1ll << 31), "comat_gemm_segments: too many tiles");
+    g.ntiles = (int64_t)g.tiles_m * g.tiles_n * batch;
+    g.splits = plan_splits(p->M, p->N, g.nk * bke, bke, batch, p->ws ? p->ws_bytes : 0);
+    const int64_t blocks = g.ntiles * g.splits;
+    COMAT_REQUIRE(blocks < (1ll << 31), "comat_gemm_segments: too many tiles");
     g.ws = (float*)p->ws;
     hipStream_t st = (hipStream_t)stream;
-    if (ks > 1) {
-        COMAT_REQUIRE(comat_gemm_seg_launch_variant(&g, p->in_dtype == COMAT_BF16 ? 1 : 0, ks, (unsigned)tiles, stream),
-                      "comat_gemm_segments: unsupported kernel variant");
-    } else if (p->in_dtype == COMAT_BF16) {
-        hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
-    } else {
-        hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)tiles), dim3(NT), 0, st, g);
-    }
-    if (g.splits > 1) {
-        COMAT_REQUIRE(batch == 1 || !p->bias, "comat_gemm_segments: batched split-K with bias is not supported");
-        launch_reduce(g.ws, p->M, p->N, batch, 1, p->sC1, 0, p->sR1, 0, g.splits, g.ep, st);
-    }
+    if (p->in_dtype == COMAT_BF16) hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)blocks), dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)blocks), dim3(NT), 0, st, g);
     return comat_check_launch("comat_gemm_segments");
 }
 
@@ -1189,6 +812,7 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     COMAT_REQUIRE(p->ups == 1 || (p->ups == 2 && p->mode == 0), "comat_conv2d: ups must be 1, or 2 with mode 0");
     COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_conv2d: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_conv2d: bad residual dtype");
+    if (const int rc = comat_gemm2_try_conv(p, stream)) return rc < 0 ? rc : comat_check_launch("comat_conv2d");
     ConvArgs g;
     g.X = p->X; g.W = p->W;
     g.geo.B = p->B; g.geo.Hin = p->Hin; g.geo.Win = p->Win; g.geo.Cin = p->Cin;
@@ -1201,32 +825,18 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     g.ep.ldc = p->Cout; g.ep.ldr = p->Cout; g.ep.rows_per_b2 = (int64_t)p->Hout * p->Wout;
     g.ep.alpha = p->alpha; g.ep.beta = p->beta; g.ep.act = p->act;
     g.ep.out_dt = p->out_dtype; g.ep.r_dt = p->r_dtype;
-    const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
-    const TilePlan plan = plan_tiles(g.M, g.N, g.K, bke, 1, p->ws ? p->ws_bytes : 0);
     const bool bf = p->in_dtype == COMAT_BF16;
-    const int bm = bf ? plan.bm : 64, bn = bf ? plan.bn : 64;  // the larger tiles exist for bf16 only
-    g.tiles_m = (int)cdiv64(g.M, bm);
-    g.tiles_n = (int)cdiv64(g.N, bn);
-    int ks = (bm == 64 && bn == 64) ? inblock_ksplit(plan.splits) : 1;
-    if (!bf && ks > 2) ks = 2;
-    g.splits = ks > 1 ? (plan.splits + ks / 2) / ks : plan.splits;  // nearest: prefer no global reduce pass
-    if (g.splits < 1) g.splits = 1;
-    const int64_t tiles = (int64_t)g.tiles_m * g.tiles_n * g.splits;
-    COMAT_REQUIRE(tiles < (1ll << 31), "comat_conv2d: too many tiles");
+    const int bke = bf ? KTB / 2 : KTB / 4;
+    g.tiles_m = (int)cdiv64(g.M, 64);
+    g.tiles_n = (int)cdiv64(g.N, 64);
+    g.ntiles = (int64_t)g.tiles_m * g.tiles_n;
+    g.splits = plan_splits(g.M, g.N, g.K, bke, 1, p->ws ? p->ws_bytes : 0);
+    const int64_t blocks = g.ntiles * g.splits;
+    COMAT_REQUIRE(blocks < (1ll << 31), "comat_conv2d: too many tiles");
     g.ws = (float*)p->ws;
-    dim3 grid((unsigned)tiles, 1, 1);
+    dim3 grid((unsigned)blocks, 1, 1);
     hipStream_t st = (hipStream_t)stream;
-    const bool variant = ks > 1 || bm != 64 || bn != 64;
-    if (variant) {
-        COMAT_REQUIRE(comat_conv_launch_variant(&g, bf ? 1 : 0, bm, bn, plan.nth, ks, (unsigned)tiles, stream),
-                      "comat_conv2d: unsupported kernel variant");
-    } else if (bf) {
-        hipLaunchKernelGGL((conv_kernel<bf16_t, 64, 64>), grid, dim3(NT), 0, st, g);
-    } else {
-        hipLaunchKernelGGL((conv_kernel<float, 64, 64>), grid, dim3(NT), 0, st, g);
-    }
-    if (g.splits > 1) launch_reduce(g.ws, g.M, g.N, 1, 1, 0, 0, 0, 0, g.splits, g.ep, st);
+    if (bf) hipLaunchKernelGGL((conv_kernel<bf16_t>), grid, dim3(NT), 0, st, g);
+    else hipLaunchKernelGGL((conv_kernel<float>), grid, dim3(NT), 0, st, g);
     return comat_check_launch("comat_conv2d");
 }
-
-#endif  // COMAT_GEMM_EXP_TU

@@ -1,0 +1,580 @@
+// gemm2.hip — LDS-DMA pipelined bf16 MFMA GEMM / K-segmented GEMM / implicit-GEMM conv2d for gfx950 (CDNA4).
+//
+// The k-contiguous bf16 contractions carry ~all FLOPs of the CoMat step (every frozen Linear / 1x1 conv, the LoRA
+// "frozen + low-rank" K-segmented products, every 3x3 conv of the UNets and the VAE).  The general kernel of gemm.hip
+// stages operands global -> VGPR -> ds_write -> LDS with ONE 32x32 MFMA tile per wave: two 16-byte LDS fragment reads
+// per MFMA (= the whole 256 B/clk LDS read port at full MFMA rate) plus ~80 B/clk of ds_write traffic make it
+// LDS-bound at ~10 % of the matrix peak (profiles/r01_pmc_conv_gemm_attnmap.txt).  This kernel is built around what
+// bounds it instead:
+//   * operands go global -> LDS by DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
+//     ds_write), 4-deep LDS ring, ONE s_barrier per k-tile, counted s_waitcnt vmcnt(N) so that two k-tiles stay in
+//     flight across every barrier (cdna_hip_programming.md section 5: "pipelining across barriers");
+//   * each wave owns 2x2 (or 2x1) MFMA tiles of 32x32: 4 fragment reads feed 4 MFMAs (half the LDS read traffic per
+//     FLOP), accumulators stay in registers for the whole k-loop;
+//   * LDS image = rows of 64 bytes (32 bf16 of k), 16-byte chunk c of row r stored at slot c ^ ((r >> 2) & 3): the four
+//     16-lane groups of a ds_read_b128 then touch all 64 banks exactly once (conflict-free without padding, which the
+//     lane-linear DMA destination would not allow).  The swizzle is applied on the SOURCE address of the DMA and on the
+//     fragment read (both sides, rule 21 of the guide);
+//   * conv: the im2col gather is the per-lane DMA source address (tap-uniform per k-tile because Cin % 32 == 0),
+//     padding taps read a 256-byte zero page;
+//   * accumulators are kept TRANSPOSED (MFMA(A = weight fragment, B = activation fragment): lane <-> output row,
+//     registers <-> 4 consecutive output columns), one v_permlane32_swap pass makes every lane own 8 consecutive
+//     columns: residual / bias loads and the output store are 16-byte accesses (8x fewer store instructions than the
+//     2-byte-per-lane stores of the natural layout);
+//   * split-K combines inside the launch (gemm_shared.h), no reduce kernel.
+// Fragment rule (as gemm.hip): lane (r = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h .. + 8 of row r for
+// both operands, so the k-permutation inside the MFMA cancels.
+#include "gemm_shared.h"
+
+namespace {
+
+constexpr int BK = 32;       // k elements per k-tile
+constexpr int RB = 64;       // bytes per LDS row
+constexpr int NST = 4;       // LDS ring depth (k-tiles)
+constexpr int MAXSEG2 = 8;
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised: source of padding taps
+
+struct Seg2 {
+    const bf16_t* A;
+    const bf16_t* B;
+    int64_t lda, ldb, sA, sB;
+    int nkt;  // k-tiles of this segment
+};
+
+struct Args2 {
+    Seg2 seg[MAXSEG2];
+    int nseg;
+    int Hin, Win, Cin, Hout, Wout, KW, stride, pad, ups;  // conv only (seg[0].A = X, seg[0].B = W, ldb = K)
+    int64_t M, N;
+    int nkt;  // k-tiles in total
+    int tiles_m, tiles_n, splits;
+    int64_t ntiles;
+    int64_t sC, sR, sBias;  // batch strides (elements)
+    float* ws;
+    Epi ep;
+    int vec;  // 16-byte epilogue accesses are legal (alignment / divisibility checked by the host)
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void mma_t(f32x16_t& acc, const short8_t& wfrag, const short8_t& xfrag) {
+    // D[n][m] += W[n][k] X[m][k]: A operand = weight fragment (lane&31 = n), B operand = activation fragment (lane&31 = m)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfrag), __builtin_bit_cast(bf16x8_t, xfrag),
+                                                  acc, 0, 0, 0);
+}
+
+// lanes 32..63 of `lo` <-> lanes 0..31 of `hi`
+__device__ __forceinline__ void half_swap(float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
+union Pack16 {
+    uint4 u;
+    bf16_t h[8];
+    float f[4];
+};
+
+// 8 consecutive output columns n .. n+7 of output row m
+__device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m, int64_t n, int64_t N, bool vec) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+    if (vec) {
+        if (ep.bias) {
+            const float4 b0 = *(const float4*)(ep.bias + n), b1 = *(const float4*)(ep.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (ep.bias2) {
+            const float* p2 = ep.bias2 + (int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + n;
+            const float4 b0 = *(const float4*)p2, b1 = *(const float4*)(p2 + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (ep.act == COMAT_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (ep.act == COMAT_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (ep.R) {
+            if (ep.r_dt == COMAT_F32) {
+                const float* pr = (const float*)ep.R + m * ep.ldr + n;
+                const float4 r0 = *(const float4*)pr, r1 = *(const float4*)(pr + 4);
+                v[0] += ep.beta * r0.x; v[1] += ep.beta * r0.y; v[2] += ep.beta * r0.z; v[3] += ep.beta * r0.w;
+                v[4] += ep.beta * r1.x; v[5] += ep.beta * r1.y; v[6] += ep.beta * r1.z; v[7] += ep.beta * r1.w;
+            } else {
+                Pack16 pk;
+                pk.u = *(const uint4*)((const bf16_t*)ep.R + m * ep.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ep.beta * bf16_to_f32(pk.h[e]);
+            }
+        }
+        if (ep.out_dt == COMAT_F32) {
+            float* pc = (float*)ep.C + m * ep.ldc + n;
+            *(float4*)pc = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(pc + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            Pack16 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.h[e] = f32_to_bf16(v[e]);
+            *(uint4*)((bf16_t*)ep.C + m * ep.ldc + n) = pk.u;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t col = n + e;
+            if (col < N) {
+                float x = v[e];
+                if (ep.bias) x += ep.bias[col];
+                if (ep.bias2) x += ep.bias2[(int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + col];
+                if (ep.act == COMAT_ACT_SILU) x = silu_f(x);
+                else if (ep.act == COMAT_ACT_GELU) x = gelu_f(x);
+                if (ep.R) x += ep.beta * ld_dt(ep.R, m * ep.ldr + col, ep.r_dt);
+                st_dt(ep.C, m * ep.ldc + col, x, ep.out_dt);
+            }
+        }
+    }
+}
+
+// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  CONV: implicit-GEMM gather.
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
+    constexpr int NW = WM * WN, NTH = NW * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int IA = BM / (16 * NW), IB = BN / (16 * NW);  // DMA instructions per wave per k-tile, per operand
+    static_assert(IA >= 1 && IB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile too small for the block");
+    static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be whole MFMA tiles");
+    constexpr int L = IA + IB;          // DMA instructions per wave per k-tile
+    constexpr int SS = (BM + BN) * RB;  // bytes per ring stage: [A: BM rows][B: BN rows]
+    static_assert(2 * L <= 63, "vmcnt range");
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SS];  // the ONLY LDS object of the kernel
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave / WN, wc = wave % WN;
+
+    // ---- work item: ((z * tiles_m + tm) * tiles_n + tn) * splits + sp  (all wave-uniform: kept in SGPRs) ----
+    unsigned lin = (unsigned)xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.splits));
+    lin /= (unsigned)g.splits;
+    const int64_t tile = __builtin_amdgcn_readfirstlane((int)lin);
+    const int tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
+    lin /= (unsigned)g.tiles_n;
+    const int tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
+    const int64_t z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int per = (g.nkt + g.splits - 1) / g.splits;
+    int kt0 = sp * per;
+    if (kt0 > g.nkt) kt0 = g.nkt;
+    const int kt1 = kt0 + per < g.nkt ? kt0 + per : g.nkt;
+    const int nt = __builtin_amdgcn_readfirstlane(kt1 - kt0);
+
+    // ---- DMA source state.  Wave-instruction i of an operand covers rows (i * NW + wave) * 16 .. + 16 of its tile,
+    // lane -> (row = lane / 4, slot = lane % 4) of the lane-linear 1 KiB it writes; the lane fetches chunk
+    // slot ^ ((row >> 2) & 3) of that row (the LDS swizzle, applied on the source side) ----
+    const int drow = lane >> 2;
+    const int csrc = (lane & 3) ^ ((drow >> 2) & 3);
+    const bf16_t* pb[IB];   // running source pointers, B operand
+    int64_t brow_[IB];      // clamped global row of the lane's B chunk
+    const bf16_t* pa[IA];   // GEMM: running source pointers, A operand
+    int64_t arow_[IA];      // GEMM: clamped global row
+    int by[IA], bx[IA], bb[IA];  // CONV: oy*stride - pad, ox*stride - pad (upsampled coordinates), b * Hin
+    bool rv[IA];
+    int seg = 0, seg_left = 0;   // issue-side segment cursor
+    int ky = 0, kx = 0, ci0 = 0;  // CONV: issue-side tap cursor
+
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        int64_t gr = n0 + (i * NW + wave) * 16 + drow;
+        brow_[i] = gr < g.N ? gr : g.N - 1;  // columns >= N are never stored: any valid row will do
+    }
+    if (CONV) {
+        const int hw = g.Hout * g.Wout;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int64_t gm = m0 + (i * NW + wave) * 16 + drow;
+            rv[i] = gm < g.M;
+            const int64_t gmc = rv[i] ? gm : 0;
+            const int b = (int)(gmc / hw), rem = (int)(gmc - (int64_t)b * hw);
+            const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
+            bb[i] = b * g.Hin;
+            by[i] = oy * g.stride - g.pad;
+            bx[i] = ox * g.stride - g.pad;
+        }
+        const int k0 = kt0 * BK;
+        const int tap = k0 / g.Cin;
+        ci0 = k0 - tap * g.Cin;
+        ky = tap / g.KW;
+        kx = tap - ky * g.KW;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) pb[i] = g.seg[0].B + brow_[i] * g.seg[0].ldb + k0 + csrc * 8;
+    } else {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int64_t gr = m0 + (i * NW + wave) * 16 + drow;
+            arow_[i] = gr < g.M ? gr : g.M - 1;
+        }
+        // locate k-tile kt0 in the segment list
+        int t0 = kt0;
+        seg = 0;
+        while (seg + 1 < g.nseg && t0 >= g.seg[seg].nkt) {
+            t0 -= g.seg[seg].nkt;
+            ++seg;
+        }
+        seg_left = g.seg[seg].nkt - t0;
+        const Seg2 sg = g.seg[seg];
+#pragma unroll
+        for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + t0 * BK + csrc * 8;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + t0 * BK + csrc * 8;
+    }
+
+    // issue the DMA of the next k-tile of this block's range into ring stage `st`
+    auto issue = [&](int st) {
+        char* sbase = smem + st * SS + wave * 1024;
+        if (CONV) {
+            const int lim_y = g.Hin * g.ups, lim_x = g.Win * g.ups;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                int sy = by[i] + ky, sx = bx[i] + kx;
+                const bool ok = rv[i] && (unsigned)sy < (unsigned)lim_y && (unsigned)sx < (unsigned)lim_x;
+                if (g.ups == 2) {
+                    sy >>= 1;
+                    sx >>= 1;
+                }
+                const int off = ((bb[i] + sy) * g.Win + sx) * g.Cin + ci0 + csrc * 8;
+                const void* src = ok ? (const void*)(g.seg[0].A + off) : (const void*)(g_zero_page + (lane & 15) * 16);
+                dma16(src, sbase + i * NW * 1024);
+            }
+            ci0 += BK;
+            if (ci0 >= g.Cin) {
+                ci0 = 0;
+                if (++kx == g.KW) {
+                    kx = 0;
+                    ++ky;
+                }
+            }
+        } else {
+            if (seg_left == 0) {  // next segment (uniform branch)
+                ++seg;
+                const Seg2 sg = g.seg[seg];
+                seg_left = sg.nkt;
+#pragma unroll
+                for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + csrc * 8;
+#pragma unroll
+                for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + csrc * 8;
+            }
+            --seg_left;
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                dma16(pa[i], sbase + i * NW * 1024);
+                pa[i] += BK;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            dma16(pb[i], sbase + BM * RB + i * NW * 1024);
+            pb[i] += BK;
+        }
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    // fragment addressing: lane (r, h), k-step s reads 16 bytes at row r, slot (2 s + h) ^ ((r >> 2) & 3)
+    const int sw = (r >> 2) & 3;
+    const int fo0 = r * RB + ((0 + h) ^ sw) * 16, fo1 = r * RB + ((2 + h) ^ sw) * 16;
+    const int a_base = wr * WTM * RB, b_base = BM * RB + wc * WTN * RB;
+
+    // ---- pipeline: tiles t+1, t+2 in flight while tile t is consumed; ONE barrier per k-tile ----
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u)
+        if (u < nt) issue(u);
+    for (int t = 0; t < nt; ++t) {
+        const int rem = nt - t;
+        if (rem >= 3) wait_vmcnt<2 * L>();
+        else if (rem == 2) wait_vmcnt<L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // every wave's part of tile t has landed; every wave is done reading tile t-1
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) issue((t + NST - 1) & (NST - 1));  // overwrites the stage of tile t-1
+        const char* st = smem + (t & (NST - 1)) * SS;
+        short8_t xf[2][TM], wf[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            xf[0][a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo0);
+            xf[1][a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo1);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            wf[0][b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo0);
+            wf[1][b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf[s][b], xf[s][a]);
+    }
+
+    // ---- split-K: combine inside the launch ----
+    if (g.splits > 1) {
+        constexpr int QPT = TM * TN * 4;  // float4 per thread
+        f32x4_t* mine = (f32x4_t*)(g.ws + WS_COUNTERS) + ((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    mine[((a * TN + b) * 4 + q) * NTH] = v;
+                }
+        if (!splitk_arrive_is_last((unsigned*)g.ws + tile, g.splits, (unsigned*)smem)) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        for (int s2 = 0; s2 < g.splits; ++s2) {
+            const f32x4_t* src = (const f32x4_t*)(g.ws + WS_COUNTERS) + ((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t v = src[((a * TN + b) * 4 + q) * NTH];
+                        acc[a][b][4 * q] += v[0];
+                        acc[a][b][4 * q + 1] += v[1];
+                        acc[a][b][4 * q + 2] += v[2];
+                        acc[a][b][4 * q + 3] += v[3];
+                    }
+        }
+    }
+
+    // ---- epilogue.  acc[a][b][i]: output row m = lane & 31 of the (a)-th 32-row tile, column (i & 3) + 8 (i >> 2) + 4 h
+    // of the (b)-th 32-column tile.  Half-swapping quad 0 <-> 1 and 2 <-> 3 gives lane h = 0 columns 0..7 and 16..23,
+    // lane h = 1 columns 8..15 and 24..31 ----
+    Epi ep = g.ep;
+    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
+    if (ep.bias) ep.bias += z * g.sBias;
+    const bool vec = g.vec != 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int64_t m = m0 + wr * WTM + a * 32 + r;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half_swap(v[j], v[4 + j]);
+                half_swap(v[8 + j], v[12 + j]);
+            }
+            const int64_t nb = n0 + wc * WTN + b * 32 + 8 * h;
+            if (m < g.M) {
+                if (nb < g.N) epilogue_run(ep, v, m, nb, g.N, vec);
+                if (nb + 16 < g.N) epilogue_run(ep, v + 8, m, nb + 16, g.N, vec);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4 };
+
+struct Cfg2 {
+    int bm, bn, nth;
+};
+static Cfg2 cfg_dims(int c) {
+    switch (c) {
+        case CFG_128x64: return {128, 64, 256};
+        case CFG_256x128: return {256, 128, 512};
+        case CFG_64x128: return {64, 128, 256};
+        default: return {128, 128, 256};
+    }
+}
+
+template <bool CONV> static void launch_cfg(int c, const Args2& a, unsigned blocks, hipStream_t st) {
+    switch (c) {
+        case CFG_128x64: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_256x128: hipLaunchKernelGGL((gemm2_kernel<256, 128, 4, 2, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+    }
+}
+
+// switches: COMAT_GEMM2=0 disables this kernel (everything runs on gemm.hip's general kernel); COMAT_G2_TUNE=1 makes
+// COMAT_G2_CFG / COMAT_G2_SPLITS be re-read on every call (tools/mb_gemm2.py sweeps them inside one process)
+static bool g2_enabled() {
+    static int v = 1;
+    static bool have = false;
+    return env_int_once("COMAT_GEMM2", 1, &v, &have) != 0;
+}
+static void g2_overrides(int* cfg, int* splits) {
+    static int tune = 0, c = 0, s = 0;
+    static bool h0 = false, h1 = false, h2 = false;
+    if (env_int_once("COMAT_G2_TUNE", 0, &tune, &h0)) {
+        const char* e = getenv("COMAT_G2_CFG");
+        const char* f = getenv("COMAT_G2_SPLITS");
+        *cfg = e ? atoi(e) : 0;
+        *splits = f ? atoi(f) : 0;
+        return;
+    }
+    *cfg = env_int_once("COMAT_G2_CFG", 0, &c, &h1);
+    *splits = env_int_once("COMAT_G2_SPLITS", 0, &s, &h2);
+}
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// tile shape and split count for a problem of M x N with nkt k-tiles, `batch` independent problems
+static void plan2(int64_t M, int64_t N, int nkt, int64_t batch, int64_t ws_bytes, int* cfg_out, int* splits_out) {
+    int fc = 0, fs = 0;
+    g2_overrides(&fc, &fs);
+    int c = fc;
+    if (c == CFG_AUTO) {
+        if (M >= 32768 && N >= 128) c = CFG_256x128;          // VAE-sized: plenty of tiles, take the biggest
+        else if (N % 128 != 0 && N % 128 <= 64) c = CFG_128x64;  // N = 64, 320, 960 ...: no half-empty column tiles
+        else c = CFG_128x128;
+    }
+    const Cfg2 d = cfg_dims(c);
+    const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
+    int64_t s = 1;
+    const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
+    if (slab_bytes > 0 && ntiles <= WS_COUNTERS) {
+        if (fs > 0) s = fs;
+        else if (ntiles < 192 && nkt >= 16) {  // fewer tiles than 3/4 of the CUs and a long contraction
+            s = cdiv64(256, ntiles);
+            if (s > nkt / 8) s = nkt / 8;
+        }
+        const int64_t cap = slab_bytes / (ntiles * d.bm * d.bn * 4);
+        if (s > cap) s = cap;
+        if (s > nkt) s = nkt;
+        if (s > 32) s = 32;
+        if (s < 1) s = 1;
+        const int per = (int)cdiv64(nkt, s);
+        s = cdiv64(nkt, per);  // no empty slices
+    }
+    *cfg_out = c;
+    *splits_out = (int)s;
+}
+
+static void fill_epi(Args2& a, const comat_gemm_params* p) {
+    a.ep.C = p->C; a.ep.bias = p->bias; a.ep.bias2 = p->bias2; a.ep.R = p->R;
+    a.ep.ldc = p->ldc; a.ep.ldr = p->ldr; a.ep.rows_per_b2 = p->rows_per_bias2 > 0 ? p->rows_per_bias2 : 1;
+    a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
+    a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
+}
+
+// 16-byte epilogue accesses: 8 columns per lane must stay inside a row and every row start must be 16-byte aligned
+static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t sBias, int64_t M) {
+    if (N % 8 || ep.ldc % 8 || !al16(ep.C) || sC % 8) return 0;
+    if (ep.R && (ep.ldr % 8 || !al16(ep.R) || sR % 8)) return 0;
+    if (ep.bias && (!al16(ep.bias) || sBias % 4)) return 0;
+    if (ep.bias2 && !al16(ep.bias2)) return 0;
+    if (M >= (1ll << 31)) return 0;
+    return 1;
+}
+
+static int finish_launch(Args2& a, bool conv, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
+    int c, s;
+    plan2(a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
+    const Cfg2 d = cfg_dims(c);
+    a.tiles_m = (int)cdiv64(a.M, d.bm);
+    a.tiles_n = (int)cdiv64(a.N, d.bn);
+    a.ntiles = (int64_t)a.tiles_m * a.tiles_n * batch;
+    a.splits = s;
+    a.ws = (float*)ws;
+    const int64_t blocks = a.ntiles * s;
+    if (blocks >= (1ll << 31)) return 0;
+    a.vec = epi_vec_ok(a.ep, a.N, a.sC, a.sR, a.sBias, a.M);
+    if (conv) launch_cfg<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
+    else launch_cfg<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
+    return 1;
+}
+
+}  // namespace
+
+int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
+    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->transA || p->transB || p->batch2 != 1) return 0;
+    if (p->K % BK || p->lda % 8 || p->ldb % 8 || !al16(p->A) || !al16(p->B)) return 0;
+    if (p->batch1 > 1 && (p->sA1 % 8 || p->sB1 % 8)) return 0;
+    if (p->M < 48 || p->M >= (1ll << 31) || p->N >= (1ll << 31)) return 0;  // skinny problems: the 64x64 kernel + split-K
+    Args2 a = {};
+    a.seg[0].A = (const bf16_t*)p->A; a.seg[0].B = (const bf16_t*)p->B;
+    a.seg[0].lda = p->lda; a.seg[0].ldb = p->ldb; a.seg[0].sA = p->sA1; a.seg[0].sB = p->sB1;
+    a.seg[0].nkt = (int)(p->K / BK);
+    a.nseg = 1;
+    a.nkt = a.seg[0].nkt;
+    a.M = p->M; a.N = p->N;
+    a.sC = p->sC1; a.sR = p->sR1; a.sBias = 0;
+    fill_epi(a, p);
+    return finish_launch(a, false, p->batch1, p->ws, p->ws_bytes, stream);
+}
+
+int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream) {
+    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || nseg > MAXSEG2) return 0;
+    if (p->M < 48 || p->M >= (1ll << 31) || p->N >= (1ll << 31)) return 0;
+    const int64_t batch = p->batch1 > 1 ? p->batch1 : 1;
+    Args2 a = {};
+    int64_t nkt = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (segs[s].K % BK || segs[s].lda % 8 || segs[s].ldb % 8 || !al16(segs[s].A) || !al16(segs[s].B)) return 0;
+        if (batch > 1 && (segs[s].sA % 8 || segs[s].sB % 8)) return 0;
+        a.seg[s].A = (const bf16_t*)segs[s].A; a.seg[s].B = (const bf16_t*)segs[s].B;
+        a.seg[s].lda = segs[s].lda; a.seg[s].ldb = segs[s].ldb; a.seg[s].sA = segs[s].sA; a.seg[s].sB = segs[s].sB;
+        a.seg[s].nkt = (int)(segs[s].K / BK);
+        nkt += a.seg[s].nkt;
+    }
+    if (nkt >= (1ll << 30)) return 0;
+    a.nseg = nseg;
+    a.nkt = (int)nkt;
+    a.M = p->M; a.N = p->N;
+    a.sC = p->sC1; a.sR = p->sR1; a.sBias = p->bias ? p->N : 0;
+    fill_epi(a, p);
+    return finish_launch(a, false, batch, p->ws, p->ws_bytes, stream);
+}
+
+int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
+    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->mode != 0 || p->Cin % BK) return 0;
+    if (!al16(p->X) || !al16(p->W)) return 0;
+    const int64_t M = (int64_t)p->B * p->Hout * p->Wout;
+    const int64_t K = (int64_t)p->KH * p->KW * p->Cin;
+    if (M < 48 || M >= (1ll << 31)) return 0;
+    Args2 a = {};
+    a.seg[0].A = (const bf16_t*)p->X; a.seg[0].B = (const bf16_t*)p->W;
+    a.seg[0].lda = 0; a.seg[0].ldb = K; a.seg[0].nkt = (int)(K / BK);
+    a.nseg = 1;
+    a.nkt = a.seg[0].nkt;
+    a.Hin = p->Hin; a.Win = p->Win; a.Cin = p->Cin; a.Hout = p->Hout; a.Wout = p->Wout;
+    a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.ups = p->ups;
+    a.M = M; a.N = p->Cout;
+    a.sC = a.sR = a.sBias = 0;
+    a.ep.C = p->Y; a.ep.bias = p->bias; a.ep.bias2 = p->bias2; a.ep.R = p->R;
+    a.ep.ldc = p->Cout; a.ep.ldr = p->Cout; a.ep.rows_per_b2 = (int64_t)p->Hout * p->Wout;
+    a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
+    a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
+    return finish_launch(a, true, 1, p->ws, p->ws_bytes, stream);
+}

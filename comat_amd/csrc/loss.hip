@@ -147,8 +147,6 @@ __global__ __launch_bounds__(NT) void disc_head_bwd_kernel(const void* __restric
 }
 
 // ---- attribute-concentration gather over one captured map [heads, npix, L] ----------------------------------------
-constexpr int MAX_TOK = 32;
-
 // Grid (256-pixel chunk, head).  No atomics: per-(block, head, token) spatial sums and per-head token maps go to the
 // workspace and are combined in a fixed order by attnmap_final_kernel (bit-reproducible, still fully parallel).
 //   ws  = [nblk, heads, n_tok, 2] partial (masked sum, sum)   followed by   [heads, n_tok, npix] per-head values
@@ -285,7 +283,7 @@ extern "C" int comat_attnmap_gather_fwd(const void* amap, const float* mask, con
                                         void* stream) {
     COMAT_REQUIRE(amap && mask && tok_idx && tok_obj && num && den && avg && ws,
                   "comat_attnmap_gather_fwd: null pointer");
-    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
+    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && dtype_ok(dtype),
                   "comat_attnmap_gather_fwd: bad args");
     const int nblk = (npix + NT - 1) / NT;
     hipLaunchKernelGGL(attnmap_fwd_kernel, dim3(nblk, heads), dim3(NT), 0, ST, amap, mask, tok_idx, tok_obj, ws, heads,
@@ -300,7 +298,7 @@ extern "C" int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, 
                                         const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,
                                         int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream) {
     COMAT_REQUIRE(g_num && g_den && mask && tok_idx && tok_obj && damap, "comat_attnmap_gather_bwd: null pointer");
-    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && n_tok <= MAX_TOK && dtype_ok(dtype),
+    COMAT_REQUIRE(heads > 0 && heads <= 65535 && npix > 0 && L > 0 && n_tok > 0 && dtype_ok(dtype),
                   "comat_attnmap_gather_bwd: bad args");
     hipLaunchKernelGGL(attnmap_bwd_kernel, dim3((npix + NT - 1) / NT, heads), dim3(NT), 0, ST, g_num, g_den, g_avg, mask,
                        tok_idx, tok_obj, damap, heads, npix, L, n_tok, dtype);

@@ -28,8 +28,14 @@ __global__ __launch_bounds__(NT) void sumsq_final_kernel(const float* __restrict
 __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s,
+                                                   const int32_t* __restrict__ step_dev,
                                                    const float* __restrict__ gnorm_sq, float max_norm) {
     float clip = 1.0f;
+    if (step_dev) {  // step count of applied updates lives on the device (see comat_adamw_tick)
+        const float t = (float)(*step_dev + 1);
+        bc1 = 1.0f - powf(b1, t);
+        bc2s = sqrtf(1.0f - powf(b2, t));
+    }
     // a non-finite gradient norm (overflow / NaN somewhere in backward) skips the update, like the GradScaler step
     // of the reference's mixed-precision run (accelerate, training_script.py:661-664): parameters and moments stay
     if (gnorm_sq && !isfinite(*gnorm_sq)) return;
@@ -49,6 +55,10 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
     }
 }
 
+__global__ void adamw_tick_kernel(int32_t* __restrict__ counters, const float* __restrict__ gnorm_sq) {
+    if (threadIdx.x == 0) counters[isfinite(*gnorm_sq) ? 0 : 1] += 1;
+}
+
 }  // namespace
 
 extern "C" int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
@@ -60,12 +70,18 @@ extern "C" int comat_sumsq(const float* x, int64_t n, float* out, float* ws, voi
 }
 
 extern "C" int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                           float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm,
-                           void* stream) {
-    COMAT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "comat_adamw: bad args");
+                           float eps, float weight_decay, int32_t step, const int32_t* step_dev,
+                           const float* gnorm_sq, float max_norm, void* stream) {
+    COMAT_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "comat_adamw: bad args");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_1d(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2s, gnorm_sq, max_norm);
+                       beta2, eps, weight_decay, bc1, bc2s, step_dev, gnorm_sq, max_norm);
     return comat_check_launch("comat_adamw");
+}
+
+extern "C" int comat_adamw_tick(int32_t* counters, const float* gnorm_sq, void* stream) {
+    COMAT_REQUIRE(counters && gnorm_sq, "comat_adamw_tick: null pointer");
+    hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, gnorm_sq);
+    return comat_check_launch("comat_adamw_tick");
 }

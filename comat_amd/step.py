@@ -44,7 +44,7 @@ class StepConfig:
     mask_token_loss_weight: float = 1e-3
     mask_pixel_loss_weight: float = 5e-5
     lr: float = 5e-5
-    lr_D: float = 5e-5
+    lr_D: float = 2e-5          # --learning_rate_D 2e-5 (scripts/sd15.sh)
     adam_beta1: float = 0.9
     adam_beta2: float = 0.999
     adam_beta1_D: float = 0.0
@@ -64,25 +64,37 @@ def _dbg(tag):
 
 
 class FlatAdamW:
-    """clip_grad_norm_ + AdamW over flat fp32 buffers (one or more segments sharing the global norm)."""
+    """clip_grad_norm_ + AdamW over flat fp32 buffers (one or more segments sharing the global norm).
+
+    The step count of the bias correction lives in device memory (`counters` int32 [2] = applied, skipped) and advances
+    only when an update is applied: a non-finite gradient norm skips the update (the inf/NaN check of the reference's
+    mixed-precision optimizer step, training_script.py:661-664) WITHOUT moving the bias correction ahead of the
+    moments, the skip is visible to the caller (`counters[1]`, `gnorm_sq`), and a captured hipGraph of the whole step
+    replays with the right count.  Deliberate deviation: plain torch AdamW would apply a NaN update."""
 
     def __init__(self, segments, lr, betas, eps, weight_decay, max_norm):
         self.segments = segments  # list of (param_flat, grad_flat)
         self.m = [torch.zeros_like(p) for p, _ in segments]
         self.v = [torch.zeros_like(p) for p, _ in segments]
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_norm
-        self.t = 0
-        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=segments[0][0].device)
+        dev = segments[0][0].device
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=dev)
+
+    @property
+    def t(self):
+        """number of applied updates (host read: synchronises; for logs and tests)"""
+        return int(self.counters[0])
 
     def step(self):
         k = ops.kernels()
-        self.t += 1
         self.gnorm_sq.zero_()
         for _, g in self.segments:
             k.sumsq(g, g.numel(), self.gnorm_sq)
         for (p, g), m, v in zip(self.segments, self.m, self.v):
-            k.adamw(p, g, m, v, p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                    self.gnorm_sq, self.max_norm)
+            k.adamw(p, g, m, v, p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 0,
+                    self.gnorm_sq, self.max_norm, step_dev=self.counters)
+        k.adamw_tick(self.counters, self.gnorm_sq)
 
 
 def sample_training_steps(total_step, K, rng: random.Random):

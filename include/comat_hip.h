@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 1
+#define COMAT_ABI_VERSION 2
 
 enum { COMAT_F32 = 0, COMAT_BF16 = 1 };
 enum { COMAT_OK = 0, COMAT_EINVAL = -1, COMAT_ELAUNCH = -2, COMAT_EUNSUPPORTED = -3 };
@@ -59,10 +59,22 @@ typedef struct {
     int32_t in_dtype;   /* dtype of A and B */
     int32_t out_dtype;  /* dtype of C */
     int32_t r_dtype;    /* dtype of R */
-    void* ws;           /* optional caller-owned fp32 workspace for split-K partial slabs (NULL: never split) */
+    void* ws;           /* optional caller-owned split-K workspace (NULL: never split), see below */
     int64_t ws_bytes;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
+
+/* Split-K workspace (comat_gemm, comat_gemm_segments, comat_conv2d).  Problems with few output tiles and a long
+ * contraction are cut along k; the partial tiles are combined INSIDE the launch by the last-arriving workgroup of
+ * each tile, in slice order (bit-reproducible; no reduce launch).  Layout of `ws`:
+ *   [0, COMAT_WS_COUNTER_BYTES)  uint32 ticket counters, one per output tile.  The caller zeroes this region ONCE
+ *                                 (before the first call that receives the buffer); every launch restores the zeros.
+ *   [COMAT_WS_COUNTER_BYTES, ws_bytes)  fp32 partial tiles.
+ * One workspace serves any number of calls on ONE stream; calls that may overlap (different streams) need a
+ * workspace each.  comat_gemm_workspace_bytes() returns the size that lets a problem use its full planned split (a
+ * smaller buffer only lowers the split count). */
+#define COMAT_WS_COUNTER_BYTES (256 * 1024)
+int64_t comat_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int32_t in_dtype);
 
 /* K-segmented GEMM:  C = act(alpha * sum_s A_s[M, K_s] B_s[N, K_s]^T + bias + bias2) + beta * R   (1 <= nseg <= 8).
  * Every A_s / B_s is k-contiguous (row-major [rows, K_s] with leading dimension lda / ldb); M, N, the dtypes, the
@@ -98,7 +110,7 @@ typedef struct {
     float alpha, beta;
     int32_t act;
     int32_t in_dtype, out_dtype, r_dtype;
-    void* ws;           /* optional caller-owned fp32 split-K workspace */
+    void* ws;           /* optional caller-owned split-K workspace (layout: see comat_gemm) */
     int64_t ws_bytes;
 } comat_conv_params;
 int comat_conv2d(const comat_conv_params* p, void* stream);
@@ -265,9 +277,16 @@ int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float
  * the bit-identical norm (and clip factor) from the all-reduced gradient. */
 int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 /* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)).  A non-finite
- * *gnorm_sq skips the update entirely (p, m, v untouched): the inf/NaN check of a mixed-precision optimizer step. */
+ * *gnorm_sq skips the update entirely (p, m, v untouched): the inf/NaN check of a mixed-precision optimizer step.
+ * Step count t of the bias correction: `step` (host value, >= 1) when step_dev is NULL; otherwise *step_dev + 1 with
+ * the count of APPLIED updates kept in device memory — advanced by comat_adamw_tick after the adamw launches of one
+ * optimizer step, and only when the update was applied (so a skipped step does not run the bias correction ahead of
+ * the moments, and a captured hipGraph of the whole step replays with the right count). */
 int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, void* stream);
+                float eps, float weight_decay, int32_t step, const int32_t* step_dev, const float* gnorm_sq,
+                float max_norm, void* stream);
+/* counters[0] += 1 if *gnorm_sq is finite (update applied), else counters[1] += 1 (update skipped). */
+int comat_adamw_tick(int32_t* counters, const float* gnorm_sq, void* stream);
 
 #ifdef __cplusplus
 }

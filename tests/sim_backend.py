@@ -347,7 +347,12 @@ class SimKernels:
     def sumsq(self, x, n, out):
         out[0] += (x.reshape(-1)[:n].double() ** 2).sum().float()
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm):
+    def adamw_tick(self, counters, gnorm_sq):
+        counters[0 if math.isfinite(float(gnorm_sq[0])) else 1] += 1
+
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None):
+        if step_dev is not None:
+            step = int(step_dev[0]) + 1
         clip = 1.0
         if gnorm_sq is not None and not math.isfinite(float(gnorm_sq[0])):
             return  # non-finite gradient norm: the update is skipped

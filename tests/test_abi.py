@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "comat_hip.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\s*\*)\s+(comat_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+(comat_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/comat_hip.h but not exported"
     bound = set(_hip.SIGNATURES) | {"comat_abi_version", "comat_last_error"}
     assert bound == set(names), (bound ^ set(names))
-    assert lib.comat_abi_version() == 1
+    assert lib.comat_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
