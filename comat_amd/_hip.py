@@ -96,6 +96,7 @@ SIGNATURES = {
     "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _vp, _f, _vp],
     "comat_adamw_tick": [_vp, _vp, _vp],
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
+    "comat_set_option": [C.c_char_p, _i32],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
@@ -124,6 +125,12 @@ def load_library(path: str | None = None):
         raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def set_option(name: str, value: int):
+    """kernel-selection option of the library (include/comat_hip.h: comat_set_option); tests and microbenchmarks only"""
+    load_library()
+    _check(_lib.comat_set_option(name.encode(), int(value)), "comat_set_option")
 
 
 def _check(rc: int, name: str):

@@ -51,10 +51,10 @@ class Blip:
     def __init__(self, cfg: BlipConfig, sd: dict, dtype=torch.bfloat16, device="cuda", fused_qkv=None):
         self.cfg, self.dtype, self.device = cfg, dtype, device
         T = dtype
-        # ViT q/k/v as one GEMM + strided fused attention (ops.fused_qkv_attention): implemented, not yet validated
-        # on a GPU -> opt-in (COMAT_BLIP_FUSED_QKV=1 or fused_qkv=True)
+        # ViT q/k/v as one GEMM + strided fused attention (ops.fused_qkv_attention), as the checkpoint stores the
+        # projection; validated on MI355X in round 2 (COMAT_BLIP_FUSED_QKV=0 restores three separate projections)
         if fused_qkv is None:
-            fused_qkv = os.environ.get("COMAT_BLIP_FUSED_QKV") == "1"
+            fused_qkv = os.environ.get("COMAT_BLIP_FUSED_QKV", "1") != "0"
         hd = cfg.v_hidden // cfg.v_heads
         self.fused_qkv = bool(fused_qkv) and ops.flash_ok(hd, dtype)
 

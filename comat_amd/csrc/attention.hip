@@ -570,16 +570,14 @@ template <typename T, bool TR> int dispatch_tr(const FlashArgs& a, bool bwd, boo
 }
 
 template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st) {
-    // experimental switches, both bit-identical to the default by construction:
-    // COMAT_FLASH_TRIM=1 skips the MFMA k-steps whose head-dim chunk is pure zero padding (head dim 40 in a 64-wide
-    //   tile: 3 of 4 steps; 80 in 96: 5 of 6) — the skipped products are exactly zero;
-    // COMAT_FLASH_TR=1 stages the k-major operand tiles (V; K in dQ; Q and dO in dK/dV) as transposed LDS images, so
-    //   their MFMA fragments are two 8-byte reads instead of eight 2-byte reads.
-    const char* e = getenv("COMAT_FLASH_TRIM");
-    const bool trim = e && atoi(e) == 1;
-    const char* e2 = getenv("COMAT_FLASH_TR");
-    if (e2 && atoi(e2) == 1) return dispatch_tr<T, true>(a, bwd, trim, st);
-    return dispatch_tr<T, false>(a, bwd, trim, st);
+    // Two refinements, both bit-identical to the plain kernels by construction and validated so on MI355X (round 2,
+    // profiles/r02_a_*): TRIM skips the MFMA k-steps whose head-dim chunk is pure zero padding (head dim 40 in a 64-wide
+    // tile: 3 of 4 steps; 80 in 96: 5 of 6) - the skipped products are exactly zero; TR stages the k-major operand tiles
+    // (V; K in dQ; Q and dO in dK/dV) as transposed LDS images, so their MFMA fragments are two 8-byte reads instead of
+    // eight 2-byte reads.  Options flash_trim / flash_tr = 0 (COMAT_FLASH_TRIM / COMAT_FLASH_TR) select the plain kernels.
+    const int trim_v = comat_option(COMAT_OPT_FLASH_TRIM), tr_v = comat_option(COMAT_OPT_FLASH_TR);
+    if (tr_v == 1) return dispatch_tr<T, true>(a, bwd, trim_v == 1, st);
+    return dispatch_tr<T, false>(a, bwd, trim_v == 1, st);
 }
 
 int check_args(const char* what, const void* Q, const void* K, const void* V, int B, int H, int Nq, int Nk, int d,

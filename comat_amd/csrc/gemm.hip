@@ -662,9 +662,7 @@ template <typename T> void launch_gemm_t(const GemmArgs& g, int trans, dim3 grid
 // workgroups to put several on every CU (the k-loop is latency-bound otherwise), >= 8 k-tiles per split so that the
 // slab traffic stays small; bounded by the caller's workspace (slabs) and by the ticket counters (one per tile).
 int plan_splits(int64_t M, int64_t N, int64_t K, int bke, int64_t batch, int64_t ws_bytes) {
-    static int force = 0;
-    static bool have = false;
-    env_int_once("COMAT_FORCE_SPLITS", 0, &force, &have);  // tuning knob (tools/microbench_gemm.py)
+    const int force = comat_option(COMAT_OPT_FORCE_SPLITS);  // tuning knob (tools/mb_gemm2.py)
     const int64_t ntiles = cdiv64(M, 64) * cdiv64(N, 64) * batch;
     const int64_t nk = cdiv64(K, bke);
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;

@@ -426,25 +426,12 @@ template <bool CONV> static void launch_cfg(int c, const Args2& a, unsigned bloc
     }
 }
 
-// switches: COMAT_GEMM2=0 disables this kernel (everything runs on gemm.hip's general kernel); COMAT_G2_TUNE=1 makes
-// COMAT_G2_CFG / COMAT_G2_SPLITS be re-read on every call (tools/mb_gemm2.py sweeps them inside one process)
-static bool g2_enabled() {
-    static int v = 1;
-    static bool have = false;
-    return env_int_once("COMAT_GEMM2", 1, &v, &have) != 0;
-}
+// options (runtime.hip): gemm2 = 0 routes everything to gemm.hip's general kernel; g2_cfg / g2_splits force the block
+// tile and the split count (tools/mb_gemm2.py sweeps them)
+static bool g2_enabled() { return comat_option(COMAT_OPT_GEMM2) != 0; }
 static void g2_overrides(int* cfg, int* splits) {
-    static int tune = 0, c = 0, s = 0;
-    static bool h0 = false, h1 = false, h2 = false;
-    if (env_int_once("COMAT_G2_TUNE", 0, &tune, &h0)) {
-        const char* e = getenv("COMAT_G2_CFG");
-        const char* f = getenv("COMAT_G2_SPLITS");
-        *cfg = e ? atoi(e) : 0;
-        *splits = f ? atoi(f) : 0;
-        return;
-    }
-    *cfg = env_int_once("COMAT_G2_CFG", 0, &c, &h1);
-    *splits = env_int_once("COMAT_G2_SPLITS", 0, &s, &h2);
+    *cfg = comat_option(COMAT_OPT_G2_CFG);
+    *splits = comat_option(COMAT_OPT_G2_SPLITS);
 }
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

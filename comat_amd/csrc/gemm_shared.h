@@ -58,16 +58,6 @@ __device__ __forceinline__ bool splitk_arrive_is_last(unsigned* counter, int spl
 // ---- host side ------------------------------------------------------------------------------------------------
 constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters at the head of the workspace
 
-// environment switches are read ONCE per process (a launch has a budget of a few microseconds)
-static inline int env_int_once(const char* name, int dflt, int* cache, bool* have) {
-    if (!*have) {
-        const char* e = getenv(name);
-        *cache = e ? atoi(e) : dflt;
-        *have = true;
-    }
-    return *cache;
-}
-
 // gemm2.hip: the pipelined bf16 kernel.  Each returns 1 when it took the problem (launched), 0 when the shape is not
 // eligible (the caller falls through to the general kernel), <0 on error.
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream);

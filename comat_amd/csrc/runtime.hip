@@ -1,5 +1,6 @@
-// runtime.hip — error reporting and ABI version for libcomat_hip.
+// runtime.hip — error reporting, ABI version and the tuning-option table of libcomat_hip.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -22,3 +23,48 @@ int comat_check_launch(const char* what) {
 
 extern "C" int comat_abi_version(void) { return COMAT_ABI_VERSION; }
 extern "C" const char* comat_last_error(void) { return g_err; }
+
+// ---- tuning options -------------------------------------------------------------------------------------------
+// Kernel-selection switches (A/B runs, microbenchmarks, parity tests of every variant).  Each option takes its value
+// from the environment variable COMAT_<NAME> the first time it is read (a launch has a budget of a few microseconds:
+// no getenv per call) and can be overridden at run time with comat_set_option().  Results never depend on them
+// beyond floating-point summation order (split counts, tile shapes).
+namespace {
+struct Opt {
+    const char* name;
+    const char* env;
+    int dflt, value;
+    bool have;
+};
+Opt g_opts[COMAT_N_OPTIONS] = {
+    {"flash_trim", "COMAT_FLASH_TRIM", 1, 0, false},      // skip all-zero head-dim MFMA steps of the fused attention
+    {"flash_tr", "COMAT_FLASH_TR", 1, 0, false},          // transposed LDS images for its k-major operand tiles
+    {"gemm2", "COMAT_GEMM2", 1, 0, false},                // LDS-DMA pipelined GEMM / conv kernel (gemm2.hip)
+    {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
+    {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
+    {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
+    {"norm_fused", "COMAT_NORM_FUSED", 1, 0, false},      // GroupNorm statistics finalised by the last-arriving block
+};
+}  // namespace
+
+int comat_option(int id) {
+    Opt& o = g_opts[id];
+    if (!o.have) {
+        const char* e = getenv(o.env);
+        o.value = e ? atoi(e) : o.dflt;
+        o.have = true;
+    }
+    return o.value;
+}
+
+extern "C" int comat_set_option(const char* name, int32_t value) {
+    COMAT_REQUIRE(name != nullptr, "comat_set_option: null name");
+    for (int i = 0; i < COMAT_N_OPTIONS; ++i)
+        if (strcmp(name, g_opts[i].name) == 0) {
+            g_opts[i].value = value;
+            g_opts[i].have = true;
+            return COMAT_OK;
+        }
+    comat_set_error("comat_set_option: unknown option '%s'", name);
+    return COMAT_EINVAL;
+}

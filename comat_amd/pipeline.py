@@ -72,10 +72,11 @@ class TrainableSDPipeline:
         # only for forwards that also capture attention maps).  History: an early build raised a hardware exception
         # in the second optimisation step when graphs and attribute-concentration steps were combined; it has not
         # reproduced since the attention-map gather kernel was rewritten (fixed-order, no atomics) — see DESIGN.md.
-        # SDXL (prompt-dependent time embedding = an extra graph input): implemented, not yet validated on a GPU ->
-        # opt-in through COMAT_SDXL_GRAPHS=1
+        # SDXL: the prompt-dependent half of the time embedding is an extra graph input (validated on MI355X in round 2;
+        # COMAT_SDXL_GRAPHS=0 disables).  One graph per timestep: capture them up front with prepare_graphs() — a
+        # capture costs ~3 eager forwards, and lazily captured graphs only pay off after every timestep has been seen
         use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
-                      and (not unet.cfg.addition_embed or os.environ.get("COMAT_SDXL_GRAPHS") == "1"))
+                      and (not unet.cfg.addition_embed or os.environ.get("COMAT_SDXL_GRAPHS", "1") != "0"))
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
 
     def prepare_graphs(self, batch_size, height, width, L, num_inference_steps):

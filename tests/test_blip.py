@@ -68,8 +68,6 @@ def test_score_with_crop_matches_oracle(dev, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_fused_qkv_vit_matches_split_projections(dev, dtype):
-    if dev.type == "cuda" and __import__("os").environ.get("COMAT_TEST_EXPERIMENTAL") != "1":
-        pytest.skip("fused-qkv ViT is opt-in until validated on a GPU: run with COMAT_TEST_EXPERIMENTAL=1")
     """BLIP ViT with q/k/v as ONE GEMM + strided fused attention (opt-in) == the three-projection path: reward,
     token log-probs and the gradient that flows back into the image."""
     from comat_amd import config, weights

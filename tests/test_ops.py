@@ -595,108 +595,229 @@ def test_adamw_with_clip(dev):
         assert all(torch.equal(a, b) for a, b in zip(before, (p, m, v)))
 
 
+def _set_opts(**kw):
+    from comat_amd import _hip
+    for k_, v_ in kw.items():
+        _hip.set_option(k_, v_)
+
+
+@pytest.fixture
+def default_opts():
+    """restore the library's kernel-selection options after a test that forces variants"""
+    yield
+    _set_opts(gemm2=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=1)
+
+
+G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
+    (300, 200, 320, 1), (8192, 320, 320, 1), (577, 1024, 4096, 1), (128, 1280, 1280, 1), (257, 136, 64, 1),
+    (2048, 384, 640, 3), (64, 64, 32, 1), (1000, 4, 96, 1), (512, 1280, 10240, 1)]
+
+
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental block tiles (not selected by default): run with COMAT_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("tile", ["64", "128", "12864", "64128", "1288", "128648"])
-def test_block_tile_variants_match_default(hip, tile, monkeypatch):
-    """Every COMAT_FORCE_TILE block-tile variant of the GEMM / conv kernels (4 or 8 waves per block) reproduces the
-    default 64x64 tile on ragged shapes: same operands, same k order per output element -> same fp32 sums up to the
-    split-K grouping, compared with bf16 tolerance against an fp32 matmul / conv reference."""
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_gemm2_matches_reference(hip, cfg, splits, default_opts):
+    """gemm2.hip (LDS-DMA pipelined kernel) under every block tile (g2_cfg) and split count against an fp32 reference
+    and against the general 64x64 kernel on the same bf16 operands (they differ only in fp32 summation order): ragged
+    M / N, bias, per-row-group bias, residual in bf16 and fp32, activation, fp32 and bf16 outputs, a batched launch,
+    in-place accumulation (R == C)."""
     dtype = torch.bfloat16
     k = ops.kernels()
-    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
-    monkeypatch.setenv("COMAT_FORCE_TILE", tile)
-    for (M, N, K_, tA, tB) in ((300, 200, 328, False, False), (257, 129, 100, True, False), (130, 260, 72, False, True),
-                               (515, 140, 1030, True, True), (2048, 384, 640, False, False)):
-        A = rnd(*((K_, M) if tA else (M, K_)), dtype=dtype, seed=1, scale=0.5)
-        B = rnd(*((K_, N) if tB else (N, K_)), dtype=dtype, seed=2, scale=0.5)
-        bias, R = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
-        out = torch.empty((M, N), dtype=dtype, device=hip)
-        k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M if tA else K_, N if tB else K_, N, transA=tA,
-               transB=tB, bias=dv(bias, hip), R=dv(R, hip, dtype), ldr=N, beta=1.0)
-        ref = (A.t() if tA else A) @ (B if tB else B.t()) + bias + R
-        check(out, ref, dtype, f"gemm tile={tile} M={M} N={N} K={K_} tA={tA} tB={tB}")
-    for (Bn, H, W, Cin, Cout, stride, ups) in ((2, 13, 9, 40, 72, 1, 1), (1, 16, 16, 64, 136, 2, 1), (1, 8, 8, 48, 64, 1, 2),
-                                               (1, 64, 64, 64, 128, 1, 1)):
-        x = rnd(Bn, Cin, H, W, dtype=dtype, seed=5)
-        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=6, scale=(9 * Cin) ** -0.5)
-        b = rnd(Cout, seed=7)
-        conv = ops.FrozenConv(w, b, dtype, hip, stride=stride, pad=1)
-        xd = dv(tok(x), hip, dtype, grad=True)
-        y = ops.conv2d(xd, conv, Bn, H, W, ups=ups)
-        xr = x.clone().requires_grad_(True)
-        xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups == 2 else xr
-        yr = F.conv2d(xin, w, b, stride=stride, padding=1)
-        g = rnd(*yr.shape, dtype=dtype, seed=8)
-        yr.backward(g)
-        y.backward(dv(tok(g), hip, dtype))
-        check(y, tok(yr), dtype, f"conv tile={tile} {Bn}x{H}x{W} {Cin}->{Cout} s={stride} ups={ups}")
-        check(xd.grad, tok(xr.grad), dtype, f"conv dgrad tile={tile}", factor=2)
+    for (M, N, K_, nb) in G2_GEMMS:
+        A = rnd(nb, M, K_, dtype=dtype, seed=1, scale=0.5)
+        B = rnd(nb, N, K_, dtype=dtype, seed=2, scale=0.5)
+        bias = rnd(N, seed=3)
+        rows_b2 = 64 if M % 64 == 0 else M
+        bias2 = rnd(M // rows_b2, N, seed=5)
+        for out_dt, r_dt, act in ((torch.bfloat16, torch.bfloat16, ops.ACT_NONE), (torch.float32, torch.float32, ops.ACT_SILU),
+                                  (torch.bfloat16, None, ops.ACT_GELU)):
+            R = rnd(nb, M, N, dtype=r_dt, seed=4) if r_dt is not None else None
+            Ad, Bd = dv(A, hip, dtype), dv(B, hip, dtype)
+            Rd = dv(R, hip, r_dt) if R is not None else None
+            use_b = nb == 1
+            outs = []
+            for g2 in (1, 0):
+                _set_opts(gemm2=g2, g2_cfg=cfg, g2_splits=splits)
+                out = torch.full((nb, M, N), float("nan"), dtype=out_dt, device=hip)
+                k.gemm(Ad, Bd, out, M, N, K_, K_, K_, N, bias=dv(bias, hip) if use_b else None,
+                       bias2=dv(bias2, hip) if use_b else None, rows_per_bias2=rows_b2 if use_b else 0, R=Rd, ldr=N,
+                       beta=0.5 if R is not None else 0.0, alpha=0.25, act=act, batch=(nb, 1), sA=(M * K_, 0),
+                       sB=(N * K_, 0), sC=(M * N, 0), sR=(M * N, 0))
+                outs.append(out)
+            pre = 0.25 * torch.einsum("bmk,bnk->bmn", A, B)
+            if use_b:
+                pre = pre + bias + bias2.repeat_interleave(rows_b2, dim=0)
+            ref = {ops.ACT_NONE: lambda t: t, ops.ACT_SILU: F.silu, ops.ACT_GELU: F.gelu}[act](pre)
+            if R is not None:
+                ref = ref + 0.5 * R
+            what = f"gemm2 cfg={cfg} splits={splits} M={M} N={N} K={K_} b={nb} out={out_dt} act={act}"
+            check(outs[0], ref, dtype, what)
+            check(outs[0], outs[1], dtype, what + " vs general kernel", factor=0.5 if out_dt == torch.bfloat16 else 0.02)
+    # in-place accumulation into an fp32 buffer (the LoRA weight-gradient pattern), twice: R aliases C
+    _set_opts(gemm2=1, g2_cfg=cfg, g2_splits=splits)
+    A, B = rnd(320, 4096, dtype=dtype, seed=7, scale=0.3), rnd(128, 4096, dtype=dtype, seed=8, scale=0.3)
+    acc = torch.zeros((320, 128), dtype=torch.float32, device=hip)
+    for _ in range(2):
+        k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), acc, 320, 128, 4096, 4096, 4096, 128, R=acc, ldr=128, beta=1.0)
+    check(acc, 2 * (A @ B.t()), dtype, f"gemm2 accumulate cfg={cfg} splits={splits}")
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental in-block split-K (not selected by default): run with COMAT_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("ks", ["2", "4"])
-def test_inblock_split_k_matches_reference(hip, ks, dtype, monkeypatch):
-    """COMAT_KSPLIT: wave groups of one block split the k-range of a 64x64 tile and combine in LDS.  Shapes are the
-    short-on-tiles / long-in-K kind that the planner splits (LoRA weight gradients, low-resolution projections and
-    convs), with ragged M / N / K and every operand layout."""
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("splits", [0, 2])
+def test_gemm2_segments_and_conv(hip, cfg, splits, default_opts):
+    """K-segmented products (frozen + low-rank, batched q/k/v launch) and implicit-GEMM convs (stride 1 / 2, fused 2x
+    upsample, padding taps, ragged M and Cout, time-embedding bias, residual) of the pipelined kernel, forward and the
+    data-gradient through ops.conv2d, against fp32 references."""
+    dtype = torch.bfloat16
     k = ops.kernels()
-    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
-    monkeypatch.setenv("COMAT_KSPLIT", ks)
+    _set_opts(gemm2=1, g2_cfg=cfg, g2_splits=splits)
+    tokf = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    for (M, N, K1, K2, G) in ((8192, 320, 320, 128, 1), (577, 200, 1280, 128, 1), (2048, 640, 640, 128, 3), (130, 96, 64, 32, 2)):
+        A1 = rnd(M, K1, dtype=dtype, seed=31, scale=0.3)
+        W = rnd(G, N, K1, dtype=dtype, seed=32, scale=0.3)
+        H_ = rnd(M, G * K2, dtype=dtype, seed=33, scale=0.3)
+        U = rnd(G, N, K2, dtype=dtype, seed=34, scale=0.3)
+        out = torch.full((G, M, N), float("nan"), dtype=dtype, device=hip)
+        Wd, Ud, Hd = dv(W, hip, dtype), dv(U, hip, dtype), dv(H_, hip, dtype)
+        k.gemm_segments([(dv(A1, hip, dtype), Wd, K1, K1, K1, 0, N * K1), (Hd, Ud, K2, G * K2, K2, K2, N * K2)], out, M, N, N,
+                        batch=G, sC=M * N)
+        ref = torch.stack([A1 @ W[i].t() + H_[:, i * K2:(i + 1) * K2] @ U[i].t() for i in range(G)])
+        check(out, ref, dtype, f"gemm2 segments cfg={cfg} splits={splits} M={M} N={N} G={G}")
+    for (Bn, H, W_, Cin, Cout, stride, ups, res) in ((2, 16, 16, 64, 96, 1, 1, True), (1, 64, 64, 320, 320, 1, 1, False),
+                                                    (2, 13, 9, 32, 72, 1, 1, False), (1, 16, 16, 64, 136, 2, 1, False),
+                                                    (1, 8, 8, 96, 64, 1, 2, True), (2, 8, 8, 1280, 128, 1, 1, False)):
+        x = rnd(Bn, Cin, H, W_, dtype=dtype, seed=5)
+        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=6, scale=(9 * Cin) ** -0.5)
+        b = rnd(Cout, seed=7)
+        b2 = rnd(Bn, Cout, seed=9)
+        conv = ops.FrozenConv(w, b, dtype, hip, stride=stride, pad=1)
+        xd = dv(tokf(x), hip, dtype, grad=True)
+        xr = x.clone().requires_grad_(True)
+        xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups == 2 else xr
+        yr = F.conv2d(xin, w, b, stride=stride, padding=1) + b2[:, :, None, None]
+        rr = rnd(*yr.shape, dtype=dtype, seed=10) if res else None
+        y = ops.conv2d(xd, conv, Bn, H, W_, ups=ups, bias2=dv(b2, hip),
+                       residual=dv(tokf(rr), hip, dtype) if res else None)
+        if res:
+            yr = yr + rr
+        g = rnd(*yr.shape, dtype=dtype, seed=8)
+        yr.backward(g)
+        y.backward(dv(tokf(g), hip, dtype))
+        what = f"gemm2 conv cfg={cfg} splits={splits} {Bn}x{H}x{W_} {Cin}->{Cout} s={stride} ups={ups}"
+        check(y, tokf(yr), dtype, what)
+        check(xd.grad, tokf(xr.grad), dtype, what + " dgrad", factor=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("splits", [2, 5, 16])
+def test_inlaunch_split_k_general_kernel(hip, dtype, splits, default_opts):
+    """Split-K of the general 64x64 kernel: the last-arriving block of every tile sums the slices in slice order inside
+    the launch (no reduce kernel).  Every operand layout, ragged shapes, repeated launches on the same workspace (the
+    ticket counters are re-armed by the kernel), bit-reproducible results, conv and K-segmented variants."""
+    k = ops.kernels()
+    tokf = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    _set_opts(gemm2=0, force_splits=splits)
     for (M, N, K_, tA, tB) in ((320, 128, 8192, True, True), (130, 70, 4100, False, False), (512, 1280, 1280, False, False),
-                               (64, 64, 1000, False, True), (200, 136, 2055, True, False), (2048, 640, 640, False, False)):
+                               (64, 64, 1000, False, True), (200, 136, 2055, True, False), (16, 768, 768, False, False)):
         A = rnd(*((K_, M) if tA else (M, K_)), dtype=dtype, seed=1, scale=0.5)
         B = rnd(*((K_, N) if tB else (N, K_)), dtype=dtype, seed=2, scale=0.5)
         bias, R = rnd(N, seed=3), rnd(M, N, dtype=dtype, seed=4)
-        out = torch.empty((M, N), dtype=torch.float32, device=hip)
-        k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M if tA else K_, N if tB else K_, N, transA=tA,
-               transB=tB, bias=dv(bias, hip), R=dv(R, hip, dtype), ldr=N, beta=1.0, alpha=0.25)
         ref = 0.25 * ((A.t() if tA else A) @ (B if tB else B.t())) + bias + R
-        check(out, ref, dtype, f"gemm ks={ks} M={M} N={N} K={K_} tA={tA} tB={tB}")
-    for (Bn, H, W, Cin, Cout, stride) in ((2, 8, 8, 320, 200, 1), (2, 16, 16, 256, 128, 1), (1, 16, 16, 128, 136, 2)):
-        x = rnd(Bn, Cin, H, W, dtype=dtype, seed=5)
+        outs = []
+        for rep in range(3):
+            out = torch.full((M, N), float("nan"), dtype=torch.float32, device=hip)
+            k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M if tA else K_, N if tB else K_, N, transA=tA,
+                   transB=tB, bias=dv(bias, hip), R=dv(R, hip, dtype), ldr=N, beta=1.0, alpha=0.25)
+            check(out, ref, dtype, f"split-K gemm splits={splits} M={M} N={N} K={K_} tA={tA} tB={tB} rep={rep}")
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "split-K result is not bit-reproducible"
+    for (Bn, H, W_, Cin, Cout, stride) in ((2, 8, 8, 320, 200, 1), (1, 16, 16, 128, 136, 2), (1, 8, 8, 20, 64, 1)):
+        x = rnd(Bn, Cin, H, W_, dtype=dtype, seed=5)
         w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=6, scale=(9 * Cin) ** -0.5)
         b = rnd(Cout, seed=7)
         conv = ops.FrozenConv(w, b, dtype, hip, stride=stride, pad=1)
-        xd = dv(tok(x), hip, dtype, grad=True)
-        y = ops.conv2d(xd, conv, Bn, H, W)
+        xd = dv(tokf(x), hip, dtype, grad=True)
+        y = ops.conv2d(xd, conv, Bn, H, W_)
         xr = x.clone().requires_grad_(True)
         yr = F.conv2d(xr, w, b, stride=stride, padding=1)
         g = rnd(*yr.shape, dtype=dtype, seed=8)
         yr.backward(g)
-        y.backward(dv(tok(g), hip, dtype))
-        check(y, tok(yr), dtype, f"conv ks={ks} {Bn}x{H}x{W} {Cin}->{Cout} s={stride}")
-        check(xd.grad, tok(xr.grad), dtype, f"conv dgrad ks={ks}", factor=2)
-    # K-segmented GEMM (long first segment + LoRA-sized second one, and a batched launch)
+        y.backward(dv(tokf(g), hip, dtype))
+        check(y, tokf(yr), dtype, f"split-K conv splits={splits} {Bn}x{H}x{W_} {Cin}->{Cout} s={stride}")
+        check(xd.grad, tokf(xr.grad), dtype, f"split-K conv dgrad splits={splits}", factor=2)
     A1, B1 = rnd(512, 1280, dtype=dtype, seed=31, scale=0.3), rnd(200, 1280, dtype=dtype, seed=32, scale=0.3)
     A2, B2 = rnd(512, 136, dtype=dtype, seed=33, scale=0.3), rnd(200, 136, dtype=dtype, seed=34, scale=0.3)
     out = torch.empty((512, 200), dtype=torch.float32, device=hip)
     k.gemm_segments([(dv(A1, hip, dtype), dv(B1, hip, dtype), 1280, 1280, 1280),
                      (dv(A2, hip, dtype), dv(B2, hip, dtype), 136, 136, 136)], out, 512, 200, 200)
-    check(out, A1 @ B1.t() + A2 @ B2.t(), dtype, f"gemm_segments ks={ks}")
+    check(out, A1 @ B1.t() + A2 @ B2.t(), dtype, f"split-K gemm_segments splits={splits}")
+
+
+def test_adamw_step_count_on_device(dev):
+    """FlatAdamW keeps the number of APPLIED updates in device memory: a skipped (non-finite) step does not advance the
+    bias correction, and the skip is visible in the counters."""
+    from comat_amd.step import FlatAdamW
+    n = 3000
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2)
+    pr = p0.clone().requires_grad_(True)
+    ref = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p, g = dv(p0, dev), torch.zeros(n, device=dev)
+    opt = FlatAdamW([(p, g)], 1e-2, (0.9, 0.999), 1e-8, 1e-2, 0.0)
+    for step in range(1, 5):
+        if step == 2:  # a non-finite gradient in between: skipped, counted, and NOT a bias-correction step
+            g.copy_(dv(g0, dev))
+            g[5] = float("nan")
+            opt.step()
+            assert opt.counters.tolist() == [1, 1]
+        g.copy_(dv(g0 * step, dev))
+        pr.grad = (g0 * step).clone()
+        ref.step()
+        opt.step()
+    assert opt.counters.tolist() == [4, 1] and opt.t == 4
+    check(p, pr, torch.float32, "adamw with a skipped step", factor=0.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attnmap_gather_many_tokens(dev, dtype):
+    """more than 32 attribute / noun tokens in one prompt (the reference's get_grounding_loss_by_layer takes any number
+    up to the 77 text positions, attn_utils/tc_loss_utils.py:104-167)"""
+    heads, res, L, n_tok, n_obj = 2, 8, 77, 45, 3
+    npix = res * res
+    amap = torch.softmax(rnd(heads, npix, L, seed=1), dim=-1).to(dtype)
+    mask = (rnd(n_obj, npix, seed=2) > 0).float()
+    g = torch.Generator().manual_seed(3)
+    tok_idx = torch.randint(1, L, (n_tok,), generator=g, dtype=torch.int32)
+    tok_obj = torch.randint(0, n_obj, (n_tok,), generator=g, dtype=torch.int32)
+    ad = dv(amap, dev, dtype, grad=True)
+    num, den, avg = ops.attnmap_gather(ad, dv(mask, dev), tok_idx.to(dev), tok_obj.to(dev))
+    af = amap.float()
+    sel = af[:, :, tok_idx.long()]                                  # [heads, npix, n_tok]
+    num_r = (sel * mask[tok_obj.long()].t()[None]).sum(1)
+    den_r = sel.sum(1)
+    avg_r = sel.mean(0).t()
+    check(num, num_r, torch.float32, "num", factor=5)
+    check(den, den_r, torch.float32, "den", factor=5)
+    check(avg, avg_r, torch.float32, "avg", factor=5)
+    (num.sum() + den.sum() + avg.sum()).backward()
+    assert torch.isfinite(ad.grad.float()).all()
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
-                    reason="experimental zero-chunk trimming of the fused attention (COMAT_FLASH_TRIM): COMAT_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 1024, 1024, 8, 40), (1, 300, 77, 8, 80), (2, 70, 70, 2, 40), (1, 130, 33, 1, 48),
                                  (1, 577, 577, 3, 64), (2, 64, 200, 2, 160), (2, 16, 37, 2, 16)])
-def test_flash_trim_is_bit_identical(hip, dtype, cfg, monkeypatch):
-    """COMAT_FLASH_TRIM=1 skips only MFMA steps whose operands are zero padding, COMAT_FLASH_TR=1 only changes how the
-    k-major operand tiles are staged in LDS (transposed image, wide reads): outputs and gradients of every combination
-    must be bit-identical to the default kernels."""
+def test_flash_trim_is_bit_identical(hip, dtype, cfg, default_opts):
+    """flash_trim skips only MFMA steps whose operands are zero padding, flash_tr only changes how the k-major operand
+    tiles are staged in LDS (transposed image, wide reads): outputs and gradients of every combination (the default is
+    both on) must be bit-identical to the plain kernels."""
     B, Nq, Nk, H, d = cfg
     q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
     g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
     res = []
-    for trim, tr in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
-        monkeypatch.setenv("COMAT_FLASH_TRIM", trim)
-        monkeypatch.setenv("COMAT_FLASH_TR", tr)
+    for trim, tr in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        _set_opts(flash_trim=trim, flash_tr=tr)
         qd, kd, vd = (dv(t, hip, dtype, grad=True) for t in (q, k_, v))
         o, _ = ops.attention(qd, kd, vd, B, Nq, Nk, H, d, need_probs=False)
         o.backward(dv(g, hip, dtype))
@@ -711,8 +832,6 @@ def test_flash_trim_is_bit_identical(hip, dtype, cfg, monkeypatch):
 def test_merged_nograd_weights(dev, dtype, G, monkeypatch):
     """COMAT_NOGRAD_MERGED=1: no-grad calls through W + s U D (merged once per optimizer step) give the unmerged result
     (fp32: to rounding; bf16: within bf16 tolerance), follow parameter updates, and leave grad-mode calls untouched."""
-    if dev.type == "cuda" and os.environ.get("COMAT_TEST_EXPERIMENTAL") != "1":
-        pytest.skip("merged no-grad weights are opt-in until validated on a GPU: COMAT_TEST_EXPERIMENTAL=1")
     M, K, r, N = 130, 64, 8, 96
     x = rnd(M, K, dtype=dtype, seed=1)
     ws = [rnd(N, K, dtype=dtype, seed=20 + i, scale=K ** -0.5) for i in range(G)]

@@ -102,8 +102,6 @@ def test_sdxl_attrcon_sampler(dev, dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(__import__("os").environ.get("COMAT_TEST_EXPERIMENTAL") != "1",
-                    reason="SDXL graph replay is opt-in (COMAT_SDXL_GRAPHS=1) until validated: COMAT_TEST_EXPERIMENTAL=1")
 def test_sdxl_graphed_nograd_unet_matches_eager(hip):
     """hipGraph replay of the SDXL no-grad UNet forward with the prompt embedding as a graph INPUT: replays with
     different latents / text / pooled embeddings match eager launches bit for bit, with one captured graph."""

@@ -212,3 +212,14 @@ def test_step_has_no_host_synchronisation(attrcon):
         trainer.train_step(batch)  # second step: random step / crop sampling, optimizer state, compute-copy refresh
     finally:
         ops.set_kernel_backend(None)
+
+
+def test_step_config_defaults_follow_the_reference_recipe():
+    """StepConfig() carries the values of the reference's scripts/sd15.sh (lines 5-17): --learning_rate 5e-5
+    --max_grad_norm 0.1 --K 5 --total_step 50 --gan_loss_weight 1 --learning_rate_D 2e-5 --adam_beta1_D 0
+    --max_grad_norm_D 1 --mask_token_loss_weight 1e-3 --mask_pixel_loss_weight 5e-5 --attrcon_train_steps 2."""
+    from comat_amd.step import StepConfig
+    c = StepConfig()
+    assert (c.lr, c.max_grad_norm, c.K, c.total_step, c.resolution) == (5e-5, 0.1, 5, 50, 512)
+    assert (c.gan_loss, c.gan_loss_weight, c.lr_D, c.adam_beta1_D, c.max_grad_norm_D) == (True, 1.0, 2e-5, 0.0, 1.0)
+    assert (c.mask_token_loss_weight, c.mask_pixel_loss_weight, c.attrcon_train_steps) == (1e-3, 5e-5, 2)
