@@ -105,9 +105,12 @@ class Blip:
         self.norm_scale = (1.0 / std).to(device)
         self.norm_shift = (-torch.tensor(CLIP_MEAN) / std).to(device)
         self._tables = {}
+        self.static_tables = None
 
     # ---- image preprocessing -----------------------------------------------------------------------------------
     def tables(self, H, W, crop):
+        if self.static_tables is not None:  # a captured step graph reads fixed-address tables (step.GraphedStep)
+            return self.static_tables
         key = (H, W, crop)
         if key not in self._tables:
             fwd, bwd = resize_tables(H, W, crop, (self.cfg.image_size, self.cfg.image_size), "bicubic")

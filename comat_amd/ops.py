@@ -66,15 +66,19 @@ def _side_stream(dev):
 
 
 _join_queued = False
+_side_dirty = []  # side streams that received work since the last join
 
 
 def join_side_streams():
-    """Make the current stream wait for everything queued on the side streams.  Queued automatically as an autograd
-    end-of-backward callback, so LoRA gradients are complete (in stream order) when `.backward()` returns."""
+    """Make the current stream wait for everything queued on the side streams since the last join.  Queued
+    automatically as an autograd end-of-backward callback, so LoRA gradients are complete (in stream order) when
+    `.backward()` returns.  Only streams that were actually forked are waited for: inside a hipGraph capture a wait on
+    a stream that is not part of the capture would be an illegal cross-capture dependency."""
     global _join_queued
     _join_queued = False
-    for (dev, _), st in _side.items():
+    for dev, st in _side_dirty:
         torch.cuda.current_stream(dev).wait_stream(st)
+    _side_dirty.clear()
     _side_keep.clear()
 
 
@@ -83,6 +87,17 @@ def _queue_join():
     if not _join_queued:
         _join_queued = True
         torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+
+
+def reset_side_stream_state():
+    """Start of a top-level forward/backward: join what a previous backward may have left behind (an exception in the
+    middle of a backward skips its end-of-backward callback; the latch would stay set and no later backward would ever
+    join the side streams again) and drop the latch."""
+    global _join_queued
+    if _side_dirty:
+        join_side_streams()
+    _join_queued = False
+    _side_keep.clear()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -632,6 +647,8 @@ class _LoRAGroupLinear(Function):
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     weight_grads()
+                if not any(st is side for _, st in _side_dirty):
+                    _side_dirty.append((x.device, side))
                 _side_keep.append((gs, h, u, x))  # keep the operands alive until join_side_streams()
                 _queue_join()
         dx = None
@@ -997,6 +1014,35 @@ class ResampleTables:
                         KT=int(d["KT"]))
         self.fwd, self.bwd = put(fwd), put(bwd)
         self.Hin, self.Win, self.Hout, self.Wout = Hin, Win, Hout, Wout
+
+    def static_copy(self, extra_taps=2):
+        """A second table set with `extra_taps` spare (zero-weight) taps per row: the fixed-address tables that a
+        captured hipGraph of the training step reads.  `load()` refills it with another crop's operator before a
+        replay (the resampling kernel skips zero weights, so padded taps cost nothing)."""
+        new = ResampleTables.__new__(ResampleTables)
+        new.Hin, new.Win, new.Hout, new.Wout = self.Hin, self.Win, self.Hout, self.Wout
+
+        def grow(d):
+            KT = d["KT"] + extra_taps
+            out = dict(ystart=d["ystart"].clone(), xstart=d["xstart"].clone(), KT=KT)
+            for k in ("ywt", "xwt"):
+                w = torch.zeros((d[k].shape[0], KT), dtype=d[k].dtype, device=d[k].device)
+                w[:, : d["KT"]] = d[k]
+                out[k] = w
+            return out
+        new.fwd, new.bwd = grow(self.fwd), grow(self.bwd)
+        return new
+
+    def load(self, other):
+        """copy `other`'s operator into these (fixed-address) tables; raises if it needs more taps than there is room"""
+        for mine, theirs in ((self.fwd, other.fwd), (self.bwd, other.bwd)):
+            if theirs["KT"] > mine["KT"]:
+                raise ValueError("resampling operator needs more taps than the static tables hold")
+            mine["ystart"].copy_(theirs["ystart"])
+            mine["xstart"].copy_(theirs["xstart"])
+            for k in ("ywt", "xwt"):
+                mine[k].zero_()
+                mine[k][:, : theirs["KT"]] = theirs[k]
 
 
 class _Resample(Function):

@@ -201,6 +201,7 @@ class CoMatTrainer:
         with the G backward chain instead of after it (both are latency-bound at bs=1, neither fills the chip).  The
         results are bit-identical to the serial order (no atomics anywhere); COMAT_D_STREAM=0 restores it."""
         cfg = self.cfg
+        ops.reset_side_stream_state()
         self.bank.set_requires_grad(True)
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
@@ -228,6 +229,8 @@ class CoMatTrainer:
         """all-reduce(mean) of the flat gradient buffers (RCCL, async) + clip + AdamW for G and D.  The G all-reduce is
         launched as soon as the G backward is queued, i.e. before the concurrently running D step is joined: on
         several GPUs it overlaps the tail of the D step; the D buffers follow once that stream has been joined."""
+        if self.device.type == "cuda":
+            ops.join_side_streams()  # idempotent; does not rely on the end-of-backward callback alone
         self.reducer.start(self.bank.flat_grad)
         if self._d_pending:
             torch.cuda.current_stream(self.device).wait_stream(self._d_stream)
@@ -247,5 +250,108 @@ class CoMatTrainer:
         and data-parallel runs (the exchange is a no-op in a single-process run)."""
         logs = self._forward_backward(batch, fixed)
         self._apply_updates()
+        logs["grad_norm_sq"] = self.opt.gnorm_sq  # non-finite => the generator update of this step was skipped
         logs["training_steps"], logs["crop"] = self._last
         return logs
+
+
+class GraphedStep:
+    """The whole optimisation step as ONE hipGraph: G forward + backward, D forward + backward (on its own stream),
+    LoRA weight gradients (side streams), gradient norms, clip + AdamW for G and D — ~17 k kernel launches that cost
+    the host ~10 us each when issued one by one (the eager step is host-bound: bench `host_enqueue_ms_per_step` ~= the
+    step time) replayed by the GPU's own command processor.
+
+    What makes the step replayable:
+      * every host value that changes between steps is a graph INPUT at a fixed device address: the batch tensors, the
+        per-step noises, the crop (the crop + resize operator of the BLIP preprocessing is a pair of tap tables:
+        `ResampleTables.static_copy / load`), and the AdamW step count (device counter, `FlatAdamW.counters`);
+      * what does not change for a given list of trained denoise steps is baked in: timesteps (time-embedding
+        projections, DDPM coefficients), the launch topology, every workspace.  One graph per distinct
+        `training_steps` tuple (C2: N = K, a single tuple), captured lazily at its first use after one eager step;
+      * no host synchronisation and no host-side data dependence inside the step (asserted by
+        tests/test_step.py::test_step_is_enqueue_only).
+    Not captured (the eager path runs instead): attribute-concentration steps (their masks are resized on the host),
+    data-parallel runs (the RCCL all-reduce stays outside graphs until it can be tested on a multi-GPU node).
+    Results are bit-identical to eager steps (`tests/test_step.py::test_graphed_step_matches_eager`)."""
+
+    BATCH_KEYS = ("prompt_embeds", "negative_prompt_embeds", "gan_null_embeds", "latents", "real_latents",
+                  "blip_input_ids", "blip_attention_mask", "pooled_prompt_embeds", "negative_pooled_prompt_embeds")
+
+    def __init__(self, trainer: CoMatTrainer):
+        self.tr = trainer
+        self.graphs = {}
+        self.static = None      # fixed-address copies of the batch
+        self.static_key = None  # shapes / dtypes they were built for
+        self.pool = None
+
+    def supported(self, batch):
+        from .dist import world_size
+        return (self.tr.device.type == "cuda" and not self.tr.cfg.attrcon and world_size() == 1
+                and batch.get("noises") is not None and batch.get("latents") is not None)
+
+    def _stage(self, batch):
+        """copy the batch into the fixed-address buffers (allocating them at the first call / on a shape change)"""
+        dev = self.tr.device
+        key = tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self.BATCH_KEYS if k in batch) + \
+            (("noises", len(batch["noises"]), tuple(batch["noises"][0].shape)),)
+        if self.static is None or key != self.static_key:
+            self.static = {k: torch.empty_like(batch[k], device=dev) for k in self.BATCH_KEYS if k in batch}
+            self.static["noises"] = [torch.empty_like(n, device=dev) for n in batch["noises"]]
+            self.static_key = key
+            self.graphs = {}
+        for k, v in self.static.items():
+            if k == "noises":
+                for dst, src in zip(v, batch["noises"]):
+                    dst.copy_(src, non_blocking=True)
+            else:
+                v.copy_(batch[k], non_blocking=True)
+        for k in batch:  # host-side metadata passes through untouched
+            if k not in self.static:
+                self.static[k] = batch[k]
+        return self.static
+
+    def __call__(self, batch, training_steps=None, crop=None):
+        tr = self.tr
+        cfg = tr.cfg
+        if not self.supported(batch):
+            return tr.train_step(batch, **{k: v for k, v in (("training_steps", training_steps), ("crop", crop))
+                                            if v is not None})
+        if training_steps is None:
+            training_steps = sample_training_steps(cfg.total_step, cfg.K, tr.rng)
+        if crop is None:
+            crop = sample_crop(cfg.resolution, tr.rng)
+        sb = self._stage(batch)
+        res = cfg.resolution
+        real_tab = tr.blip.tables(res, res, crop) if tr.blip.static_tables is None else None
+        if real_tab is None:  # static tables are installed: look the crop's operator up in the cache behind them
+            st = tr.blip.static_tables
+            tr.blip.static_tables = None
+            real_tab = tr.blip.tables(res, res, crop)
+            tr.blip.static_tables = st
+        key = tuple(training_steps)
+        ent = self.graphs.get(key)
+        if ent is None:
+            # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
+            # tables, workspaces of the default stream) and is a real optimisation step of its own
+            logs = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+            if tr.blip.static_tables is None:
+                tr.blip.static_tables = real_tab.static_copy()
+            tr.blip.static_tables.load(real_tab)
+            tr.bank.mark_updated()
+            if tr.D is not None:
+                tr.D.bank.mark_updated()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+            if self.pool is None:
+                self.pool = g.pool()
+            self.graphs[key] = (g, out)
+            # the capture did not execute anything: the eager step above is this call's step
+            return logs
+        g, out = ent
+        tr.blip.static_tables.load(real_tab)
+        g.replay()
+        out = dict(out)
+        out["training_steps"], out["crop"] = list(training_steps), crop
+        return out

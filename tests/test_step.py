@@ -223,3 +223,49 @@ def test_step_config_defaults_follow_the_reference_recipe():
     assert (c.lr, c.max_grad_norm, c.K, c.total_step, c.resolution) == (5e-5, 0.1, 5, 50, 512)
     assert (c.gan_loss, c.gan_loss_weight, c.lr_D, c.adam_beta1_D, c.max_grad_norm_D) == (True, 1.0, 2e-5, 0.0, 1.0)
     assert (c.mask_token_loss_weight, c.mask_pixel_loss_weight, c.attrcon_train_steps) == (1e-3, 5e-5, 2)
+
+
+def test_graphed_step_wrapper_runs_eager_without_a_gpu(sim):
+    """GraphedStep falls through to the eager step where capture is not supported (no GPU / attribute concentration /
+    several ranks): same call convention, same results."""
+    from comat_amd.step import GraphedStep
+    cfg, batch, W, trainer = make_world(torch.float32, sim, False)
+    cfg2, batch2, W2, trainer2 = make_world(torch.float32, sim, False)
+    gs = GraphedStep(trainer)
+    assert not gs.supported(batch)
+    a = gs(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    b = trainer2.train_step(batch2, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    assert float(a["step_loss"]) == float(b["step_loss"])
+    assert torch.equal(trainer.bank.flat, trainer2.bank.flat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_graphed_step_matches_eager(hip, dtype):
+    """The whole optimisation step replayed from ONE hipGraph (G fwd/bwd, D fwd/bwd on its stream, side-stream weight
+    gradients, clip + AdamW with the device-side step count) against eager steps: different noises, latents, prompts and
+    crops per step (graph inputs), two different trained-step lists (two graphs sharing one memory pool) — parameters of
+    G and D, the optimizer moments and the logged losses stay bit-identical over 6 steps."""
+    from comat_amd.step import GraphedStep
+    cfg, batch, W, tr_e = make_world(dtype, hip, False)
+    cfg, _, _, tr_g = make_world(dtype, hip, False)
+    gs = GraphedStep(tr_g)
+    assert gs.supported(batch)
+    gen = torch.Generator().manual_seed(11)
+    plan = [([1, 2], (1, 0, 63, 63)), ([1, 2], (0, 1, 63, 63)), ([0, 1], (1, 1, 63, 63)), ([1, 2], (0, 0, 63, 63)),
+            ([0, 1], (0, 1, 63, 63)), ([1, 2], (1, 1, 63, 63))]
+    for it, (ts, crop) in enumerate(plan):
+        b = dict(batch)
+        b["latents"] = torch.randn(batch["latents"].shape, generator=gen)
+        b["noises"] = [torch.randn(n.shape, generator=gen) for n in batch["noises"]]
+        b["prompt_embeds"] = torch.randn(batch["prompt_embeds"].shape, generator=gen).to(dtype).float()
+        le = tr_e.train_step(b, training_steps=ts, crop=crop)
+        lg = gs(b, training_steps=ts, crop=crop)
+        torch.cuda.synchronize()
+        for k in ("step_loss", "Blip", "G_loss", "D_loss"):
+            assert float(le[k]) == float(lg[k]), f"step {it}: {k} {float(le[k])} (eager) vs {float(lg[k])} (graph)"
+        assert torch.equal(tr_e.bank.flat, tr_g.bank.flat), f"step {it}: generator LoRA parameters differ"
+        assert torch.equal(tr_e.D.bank.flat, tr_g.D.bank.flat), f"step {it}: discriminator LoRA parameters differ"
+        assert torch.equal(tr_e.D.head, tr_g.D.head)
+        assert torch.equal(tr_e.opt.m[0], tr_g.opt.m[0]) and torch.equal(tr_e.opt.v[0], tr_g.opt.v[0])
+    assert len(gs.graphs) == 2 and tr_g.opt.t == 6 and tr_g.opt_D.t == 6
