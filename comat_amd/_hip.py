@@ -62,9 +62,9 @@ SIGNATURES = {
     "comat_gemm_segments": [C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, _vp],
     "comat_conv2d": [C.POINTER(ConvParams), _vp],
     "comat_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp],
-    "comat_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _vp],
+    "comat_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _vp],
     "comat_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f, _i32, _vp],
-    "comat_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "comat_softmax_fwd": [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp],
     "comat_softmax_bwd": [_vp, _vp, _vp, _i64, _i32, _f, _i32, _i32, _i32, _vp],
     "comat_flash_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f, _i32, _vp],
@@ -268,20 +268,32 @@ class HipKernels:
         _check(_lib.comat_conv2d(C.byref(p), _stream()), "comat_conv2d")
 
     # ---- normalisation -------------------------------------------------------------------------------------
-    def groupnorm_fwd(self, x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu):
+    def _gn_workspace(self, dev, B, G):
+        """GroupNorm workspace of the current stream: ticket counters (zeroed here once, re-armed by the kernels) + the
+        per-block partial sums (include/comat_hip.h: COMAT_GN_WS_DOUBLES)"""
+        need = 512 + B * G * 2 * 1025
+        key = ("gn", dev, _stream())
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.zeros(max(need, 1 << 18), dtype=torch.float64, device=dev)
+        return ws
+
+    def groupnorm_fwd(self, x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu):
+        ws = self._gn_workspace(x.device, B, G)
         _check(_lib.comat_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), B, HW, Cc,
                                         G, eps, int(silu), dt(x), _stream()), "comat_groupnorm_fwd")
 
-    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu):
+    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, B, HW, Cc, G, silu, add=None):
+        ws = self._gn_workspace(x.device, B, G)
         _check(_lib.comat_groupnorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), _ptr(stats), _ptr(dx), _ptr(ws),
-                                        B, HW, Cc, G, int(silu), dt(x), _stream()), "comat_groupnorm_bwd")
+                                        B, HW, Cc, G, int(silu), _ptr(add), dt(x), _stream()), "comat_groupnorm_bwd")
 
     def layernorm_fwd(self, x, gamma, beta, y, stats, M, Cc, eps):
         _check(_lib.comat_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, Cc, eps, dt(x),
                                         _stream()), "comat_layernorm_fwd")
 
-    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc):
-        _check(_lib.comat_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(stats), _ptr(dx), M, Cc, dt(x),
+    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc, add=None):
+        _check(_lib.comat_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(gamma), _ptr(stats), _ptr(dx), M, Cc, _ptr(add), dt(x),
                                         _stream()), "comat_layernorm_bwd")
 
     # ---- softmax -------------------------------------------------------------------------------------------

@@ -135,14 +135,14 @@ class Blip:
         h = _PrependClassToken.apply(h, self.cls, B)
         h = ops.add_rowvec(h.reshape(B, N * d), self.pos[: N * d]).reshape(B * N, d)
         for Lr in self.vlayers:
-            x = ops.layer_norm(h, *Lr["ln1"], eps=cfg.v_eps)
+            x, h = ops.layer_norm_fork(h, *Lr["ln1"], eps=cfg.v_eps)
             if self.fused_qkv:
                 o = ops.fused_qkv_attention(x, Lr["qkv"], B, N, nh)
             else:
                 q, k, v = (ops.linear(x, w) for w in Lr["qkv"])
                 o, _ = ops.attention(q, k, v, B, N, N, nh, d // nh, need_probs=False)
             h = ops.linear(o, Lr["proj"], residual=h)
-            x = ops.layer_norm(h, *Lr["ln2"], eps=cfg.v_eps)
+            x, h = ops.layer_norm_fork(h, *Lr["ln2"], eps=cfg.v_eps)
             h = ops.linear(ops.gelu(ops.linear(x, Lr["fc1"])), Lr["fc2"], residual=h)
         return ops.layer_norm(h, *self.post_ln, eps=cfg.v_eps), N
 

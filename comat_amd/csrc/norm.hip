@@ -2,7 +2,7 @@
 // HBM-bound kernels: every pass reads whole rows (C contiguous elements) so that a wave's accesses coalesce.
 // Statistics are accumulated per block in fp32 and combined across blocks in fp64 (hardware double atomics),
 // which keeps E[x^2]-E[x]^2 stable enough for the fp32 parity mode.
-#include "common.h"
+#include "gemm_shared.h"  // splitk_arrive_is_last: the agent-scope ticket protocol, reused for the statistics
 
 namespace {
 
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
                                                           const float* __restrict__ beta,
                                                           const float* __restrict__ stats,
                                                           const double* __restrict__ ws, T* __restrict__ dx,
-                                                          int64_t HW, int C, int G, int silu, int64_t total) {
+                                                          int64_t HW, int C, int G, int silu, int64_t total,
+                                                          const T* __restrict__ add) {
     const int cpg = C / G;
     const float inv_n = 1.0f / (float)((double)HW * cpg);
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
@@ -150,7 +151,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ 
         float g = ldf<T>(dy + i);
         if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
         g *= gamma[c];
-        stf<T>(dx + i, rstd * (g - (s1 + xh * s2) * inv_n));
+        float d = rstd * (g - (s1 + xh * s2) * inv_n);
+        if (add) d += ldf<T>(add + i);
+        stf<T>(dx + i, d);
     }
 }
 
@@ -168,6 +171,12 @@ template <typename T> __device__ __forceinline__ void gv_set(GV16& v, int e, flo
     else v.f[e] = x;
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 constexpr int VSLOTS = 2;  // channel vectors per thread: C <= 256 * 2 * EPV
 
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): s1 = sum gy*gamma, s2 = sum gy*gamma*xhat
@@ -175,7 +184,9 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ stats, double* __restrict__ ws,
-                                                       int HW, int C, int G, int silu, int rows_per_block) {
+                                                       int HW, int C, int G, int silu, int rows_per_block,
+                                                       unsigned* __restrict__ tickets, float* __restrict__ stats_out,
+                                                       double count, float eps) {
     constexpr int EPV = 16 / sizeof(T);
     // per-(row lane, channel) partial sums: reduced in a FIXED order below, so the block result is deterministic
     // (LDS float atomics from many waves made run-to-run results differ in the last bf16 bit of a few outputs)
@@ -243,12 +254,36 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
         part[threadIdx.x * 2 + 0] = (double)f1;
         part[threadIdx.x * 2 + 1] = (double)f2;
     }
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    if (tickets == nullptr) return;  // three-launch form: gn_reduce(_finalize)_kernel combines the partials
+    // Two-launch form: the LAST block of this sample to arrive combines the per-block partials of its G groups, in the
+    // same fixed order as gn_reduce(_finalize)_kernel (lane l takes slabs l, l+64, ..., then a fixed butterfly), so the
+    // statistics stay bit-reproducible and identical to the three-launch form.
+    if (!splitk_arrive_is_last(tickets + b, (int)gridDim.x, (unsigned*)p_a)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = gridDim.x;
+    const int64_t n = (int64_t)gridDim.y * G * 2;
+    for (int g2 = wave; g2 < G; g2 += NT / 64) {
+        const int64_t i = (int64_t)b * G + g2;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = lane; k < nblk; k += 64) {
+            s1 += ws[(int64_t)(1 + k) * n + 2 * i];
+            s2 += ws[(int64_t)(1 + k) * n + 2 * i + 1];
+        }
+        s1 = wave_sum_f64(s1);
+        s2 = wave_sum_f64(s2);
+        if (lane == 0) {
+            if (MODE == 0) {
+                const double mean = s1 / count;
+                double var = s2 / count - mean * mean;
+                if (var < 0) var = 0;
+                stats_out[2 * i] = (float)mean;
+                stats_out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            } else {
+                ws[2 * i] = s1;
+                ws[2 * i + 1] = s2;
+            }
+        }
+    }
 }
 
 // ws[0 .. n) = sum over blocks of the partial slabs ws[(1+blk)*n + i]: one wave per output, lane l takes slabs
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(NT) void gn_vapply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ stats, const double* __restrict__ ws,
                                                        T* __restrict__ out, int HW, int C, int G, int silu,
-                                                       int64_t nvec) {
+                                                       int64_t nvec, const T* __restrict__ add) {
     constexpr int EPV = 16 / sizeof(T);
     const int VPR = C / EPV;
     const int cpg = C / G;
@@ -297,9 +332,10 @@ __global__ __launch_bounds__(NT) void gn_vapply_kernel(const T* __restrict__ x, 
         const int64_t row = i / VPR;
         const int c0 = (int)(i - row * VPR) * EPV;
         const int b = (int)(row / HW);
-        GV16 xv, gv, ov;
+        GV16 xv, gv, ov, av;
         xv.u = *(const uint4*)(x + i * EPV);
         if (MODE == 1) gv.u = *(const uint4*)(dy + i * EPV);
+        if (MODE == 1 && add) av.u = *(const uint4*)(add + i * EPV);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const int c = c0 + e;
@@ -315,7 +351,9 @@ __global__ __launch_bounds__(NT) void gn_vapply_kernel(const T* __restrict__ x, 
                 if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
                 g *= gamma[c];
                 const float s1 = (float)ws[2 * sg], s2 = (float)ws[2 * sg + 1];
-                gv_set<T>(ov, e, rstd * (g - (s1 + xh * s2) * inv_n));
+                float d = rstd * (g - (s1 + xh * s2) * inv_n);
+                if (add) d += gv_get<T>(av, e);  // gradient of the branch that bypasses the norm (residual / shortcut)
+                gv_set<T>(ov, e, d);
             }
         }
         *(uint4*)(out + i * EPV) = ov.u;
@@ -332,34 +370,47 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
     return (int)rpb;
 }
 
+// workspace: [GN_TICKETS uint32 ticket counters (zeroed once by the caller, re-armed by the kernels) | doubles]
+constexpr int GN_TICKETS = 1024;
+static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) != 0 && B <= GN_TICKETS; }
+
 template <typename T>
-static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int B,
+static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
                        int64_t HW, int C, int G, float eps, int silu, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
     const int rpb = gn_rows_per_block(B, HW, C, EPV);
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
+    unsigned* tickets = (unsigned*)ws_all;
+    double* ws = ws_all + GN_TICKETS / 2;
+    const bool fused = gn_two_launch(B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
-                       (const float*)nullptr, ws, (int)HW, C, G, silu, rpb);
-    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(B * G), dim3(64), 0, st, (const double*)ws, (int)sg.x, B * G, stats,
+                       (const float*)nullptr, ws, (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, stats,
                        (double)HW * (C / G), eps);
+    if (!fused)
+        hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(B * G), dim3(64), 0, st, (const double*)ws, (int)sg.x, B * G,
+                           stats, (double)HW * (C / G), eps);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 0>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
                        (const T*)nullptr, gamma, beta, (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G,
-                       silu, nvec);
+                       silu, nvec, (const T*)nullptr);
 }
 
 template <typename T>
 static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
-                       double* ws, int B, int64_t HW, int C, int G, int silu, hipStream_t st) {
+                       double* ws_all, int B, int64_t HW, int C, int G, int silu, const void* add, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
     const int rpb = gn_rows_per_block(B, HW, C, EPV);
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
+    unsigned* tickets = (unsigned*)ws_all;
+    double* ws = ws_all + GN_TICKETS / 2;
+    const bool fused = gn_two_launch(B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
-                       (int)HW, C, G, silu, rpb);
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
+                       (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, (float*)nullptr, 0.0, 0.0f);
+    if (!fused) hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
     const int64_t nvec = (int64_t)B * HW * C / EPV;
     hipLaunchKernelGGL((gn_vapply_kernel<T, 1>), dim3(grid_1d(nvec, NT, 4096)), dim3(NT), 0, st, (const T*)x,
-                       (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, nvec);
+                       (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, nvec,
+                       (const T*)add);
 }
 
 static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int64_t HW) {
@@ -399,7 +450,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const T* __restrict__ x, con
 template <typename T>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                     const float* __restrict__ gamma, const float* __restrict__ stats,
-                                                    T* __restrict__ dx, int64_t M, int C) {
+                                                    T* __restrict__ dx, int64_t M, int C, const T* __restrict__ add) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -419,7 +470,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
     for (int c = lane; c < C; c += 64) {
         const float g = ldf<T>(gr + c) * gamma[c];
         const float xh = (ldf<T>(xr + c) - mean) * rstd;
-        stf<T>(dr + c, rstd * (g - s1 - xh * s2));
+        float d = rstd * (g - s1 - xh * s2);
+        if (add) d += ldf<T>(add + row * C + c);  // gradient of the branch that bypasses the norm (residual)
+        stf<T>(dr + c, d);
     }
 }
 
@@ -438,6 +491,7 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
         else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
         return comat_check_launch("comat_groupnorm_fwd");
     }
+    ws += GN_TICKETS / 2;  // the ticket counters at the head of the workspace stay untouched (zero)
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {  // scalar fallback: fp64 atomics
         comat_set_error("comat_groupnorm_fwd: memset failed");
         return COMAT_ELAUNCH;
@@ -462,17 +516,19 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                    const float* stats, void* dx, double* ws, int32_t B, int64_t HW, int32_t C,
-                                   int32_t G, int32_t silu, int32_t dtype, void* stream) {
+                                   int32_t G, int32_t silu, const void* add, int32_t dtype, void* stream) {
     COMAT_REQUIRE(dy && x && gamma && beta && stats && dx && ws, "comat_groupnorm_bwd: null pointer");
     COMAT_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "comat_groupnorm_bwd: bad shape");
     COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_bwd: C or G too large");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     if (gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0) {
-        if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
-        else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, st);
+        COMAT_REQUIRE(!add || ((uintptr_t)add % 16) == 0, "comat_groupnorm_bwd: `add` must be 16-byte aligned");
+        if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
+        else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
         return comat_check_launch("comat_groupnorm_bwd");
     }
+    ws += GN_TICKETS / 2;
     if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
         comat_set_error("comat_groupnorm_bwd: memset failed");
         return COMAT_ELAUNCH;
@@ -485,12 +541,13 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
                            gamma, beta, stats, ws, HW, C, G, silu);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)dy,
                            (const bf16_t*)x, gamma, beta, stats, (const double*)ws, (bf16_t*)dx, HW, C, G, silu,
-                           total);
+                           total, (const bf16_t*)add);
     } else {
         hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, sg, dim3(NT), 0, st, (const float*)dy, (const float*)x, gamma,
                            beta, stats, ws, HW, C, G, silu);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)dy,
-                           (const float*)x, gamma, beta, stats, (const double*)ws, (float*)dx, HW, C, G, silu, total);
+                           (const float*)x, gamma, beta, stats, (const double*)ws, (float*)dx, HW, C, G, silu, total,
+                           (const float*)add);
     }
     return comat_check_launch("comat_groupnorm_bwd");
 }
@@ -512,7 +569,7 @@ extern "C" int comat_layernorm_fwd(const void* x, const float* gamma, const floa
 }
 
 extern "C" int comat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx,
-                                   int64_t M, int32_t C, int32_t dtype, void* stream) {
+                                   int64_t M, int32_t C, const void* add, int32_t dtype, void* stream) {
     COMAT_REQUIRE(dy && x && gamma && stats && dx, "comat_layernorm_bwd: null pointer");
     COMAT_REQUIRE(M > 0 && C > 0, "comat_layernorm_bwd: bad shape");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_layernorm_bwd: bad dtype");
@@ -520,9 +577,9 @@ extern "C" int comat_layernorm_bwd(const void* dy, const void* x, const float* g
     dim3 grid((unsigned)cdiv64(M, NT / 64));
     if (dtype == COMAT_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma,
-                           stats, (bf16_t*)dx, M, C);
+                           stats, (bf16_t*)dx, M, C, (const bf16_t*)add);
     else
         hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(NT), 0, st, (const float*)dy, (const float*)x, gamma,
-                           stats, (float*)dx, M, C);
+                           stats, (float*)dx, M, C, (const float*)add);
     return comat_check_launch("comat_layernorm_bwd");
 }

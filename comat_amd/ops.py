@@ -761,54 +761,77 @@ def conv_out_hw(conv: FrozenConv, H, W, ups=1):
 # normalisation
 # ----------------------------------------------------------------------------------------------------------------
 class _GroupNorm(Function):
+    """y = GroupNorm(x) (+ SiLU).  With `fork`, the input is also handed back as a second output (an alias): a branch
+    that bypasses the norm (a ResnetBlock's shortcut, the residual around a transformer block) reads THAT output, so
+    both gradients of x arrive at this node and dx = norm_bwd(gy) + g_bypass is ONE kernel (the `add` operand of
+    comat_groupnorm_bwd) instead of autograd's separate accumulation add."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, B, HW, G, eps, silu_):
+    def forward(ctx, x, gamma, beta, B, HW, G, eps, silu_, fork):
         x = _c(x)
         Cc = x.shape[1]
         assert x.shape[0] == B * HW
         y = torch.empty_like(x)
         stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
-        ws = torch.empty((B * G * 2 * 1025,), dtype=torch.float64, device=x.device)
-        kernels().groupnorm_fwd(x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu_)
+        kernels().groupnorm_fwd(x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu_)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (B, HW, Cc, G, silu_)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_bypass=None):
         x, gamma, beta, stats = ctx.saved_tensors
         B, HW, Cc, G, silu_ = ctx.cfg
+        if g is None:  # the normalised branch is unused: only the bypass gradient flows
+            return (g_bypass,) + (None,) * 8
         dx = torch.empty_like(x)
-        ws = torch.empty((B * G * 2 * 1025,), dtype=torch.float64, device=x.device)
-        kernels().groupnorm_bwd(_c(g), x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu_)
-        return dx, None, None, None, None, None, None, None
+        add = None if g_bypass is None else _c(g_bypass)
+        kernels().groupnorm_bwd(_c(g), x, gamma, beta, stats, dx, B, HW, Cc, G, silu_, add=add)
+        return (dx,) + (None,) * 8
 
 
 def group_norm(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False):
-    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu))
+    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), False)
+
+
+def group_norm_fork(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False):
+    """(GroupNorm(x), x'): use x' for the branch that bypasses the norm (see _GroupNorm)."""
+    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), True)
 
 
 class _LayerNorm(Function):
+    """y = LayerNorm(x); `fork` as in _GroupNorm (the residual connection around a pre-norm sub-layer)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, fork):
         x = _c(x)
         M, Cc = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
         kernels().layernorm_fwd(x, gamma, beta, y, stats, M, Cc, eps)
         ctx.save_for_backward(x, gamma, stats)
-        return y
+        ctx.set_materialize_grads(False)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_bypass=None):
         x, gamma, stats = ctx.saved_tensors
+        if g is None:
+            return g_bypass, None, None, None, None
         dx = torch.empty_like(x)
-        kernels().layernorm_bwd(_c(g), x, gamma, stats, dx, x.shape[0], x.shape[1])
-        return dx, None, None, None
+        add = None if g_bypass is None else _c(g_bypass)
+        kernels().layernorm_bwd(_c(g), x, gamma, stats, dx, x.shape[0], x.shape[1], add=add)
+        return dx, None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
-    return _LayerNorm.apply(x, gamma, beta, float(eps))
+    return _LayerNorm.apply(x, gamma, beta, float(eps), False)
+
+
+def layer_norm_fork(x, gamma, beta, eps=1e-5):
+    """(LayerNorm(x), x'): use x' for the residual that bypasses the norm (see _GroupNorm)."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps), True)
 
 
 # ----------------------------------------------------------------------------------------------------------------

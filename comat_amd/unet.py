@@ -106,7 +106,8 @@ class ResBlock:
 
     def __call__(self, x, B, H, W, temb_act):
         HW = H * W
-        h = ops.group_norm(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True)
+        # x feeds the norm AND the shortcut: the fork hands both gradients to one GroupNorm-backward launch
+        h, x = ops.group_norm_fork(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True)
         b2 = None
         if self.temb is not None:
             b2 = temb_act.get(id(self))
@@ -161,17 +162,19 @@ class CrossAttnBlock:
     def __call__(self, x, B, H, W, ctx, L, want_probs, kv_cache=None):
         """returns (tokens, [cross-attention probabilities of every transformer layer] or None)"""
         N = H * W
-        h = ops.group_norm(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
+        h, x = ops.group_norm_fork(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
         h = ops.linear(h, self.proj_in)
         probs_all = [] if want_probs else None
         for Lr in self.layers:
             att, ln = Lr["att"], Lr["ln"]
-            y = ops.layer_norm(h, *ln[0])
+            y, h = ops.layer_norm_fork(h, *ln[0])  # (norm, residual alias): one LayerNorm-backward launch per fork
             o = self._self_attn(att, y, B, N)
             h = ops.lora_group_linear(o, *att[("attn1", "out")], residual=h)[0]
-            o, probs = self._cross_attn(att, ops.layer_norm(h, *ln[1]), ctx, B, N, L, want_probs, kv_cache)
+            y, h = ops.layer_norm_fork(h, *ln[1])
+            o, probs = self._cross_attn(att, y, ctx, B, N, L, want_probs, kv_cache)
             h = ops.lora_group_linear(o, *att[("attn2", "out")], residual=h)[0]
-            f = ops.geglu(ops.linear(ops.layer_norm(h, *ln[2]), Lr["ff1"]))
+            y, h = ops.layer_norm_fork(h, *ln[2])
+            f = ops.geglu(ops.linear(y, Lr["ff1"]))
             h = ops.linear(f, Lr["ff2"], residual=h)
             if want_probs:
                 probs_all.append(probs)
@@ -377,7 +380,7 @@ class VAEDecoder:
         h = ops.conv2d(h, self.conv_in, B, H, W)
         h = self.mid0(h, B, H, W, None)
         N = H * W
-        hn = ops.group_norm(h, *self.a_norm, B, N, G=g, eps=1e-6, silu=False)
+        hn, h = ops.group_norm_fork(h, *self.a_norm, B, N, G=g, eps=1e-6, silu=False)
         q, k, v = ops.linear(hn, self.a_q), ops.linear(hn, self.a_k), ops.linear(hn, self.a_v)
         o, _ = ops.attention(q, k, v, B, N, N, 1, q.shape[1], need_probs=False)
         h = ops.linear(o, self.a_o, residual=h)

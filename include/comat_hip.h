@@ -122,23 +122,28 @@ int comat_conv2d(const comat_conv_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional fused SiLU) on [B, HW, C] channels-last, G groups.  stats: [B, G, 2] fp32 (mean, rstd),
- * written by fwd and read by bwd.  ws: caller workspace of B*G*2*1025 doubles (final sums + up to 1024 per-block
- * partial slabs, reduced in fixed order: bit-reproducible statistics).
- * gamma/beta fp32 [C].  bwd returns dx only (norm affine parameters are frozen: training_utils/pipeline.py:68-70).
+ * written by fwd and read by bwd.  ws: caller workspace of COMAT_GN_WS_DOUBLES(B, G) doubles: 4 KiB of uint32 ticket
+ * counters (the caller zeroes them ONCE; the kernels re-arm them) followed by the final sums and up to 1024 per-block
+ * partial slabs.  The statistics pass and their fixed-order combination (by the last-arriving block of each sample)
+ * are ONE launch, the normalisation a second one; sums are bit-reproducible.  One workspace per stream.
+ * gamma/beta fp32 [C].  bwd returns dx only (norm affine parameters are frozen: training_utils/pipeline.py:68-70);
+ * `add` (same layout and dtype as dx, or NULL) is added to dx: the gradient of the branch that bypasses the norm (a
+ * ResnetBlock's shortcut, a transformer block's residual), which autograd would otherwise sum in a kernel of its own.
  * Replaces: torch GroupNorm + SiLU in ResnetBlock2D / Transformer2DModel / VAE decoder.
  * ---------------------------------------------------------------------------------------------------------- */
+#define COMAT_GN_WS_DOUBLES(B, G) (512 + (int64_t)(B) * (G) * 2 * 1025)
 int comat_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws,
                         int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype,
                         void* stream);
 int comat_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
                         void* dx, double* ws, int32_t B, int64_t HW, int32_t C, int32_t G, int32_t silu,
-                        int32_t dtype, void* stream);
+                        const void* add, int32_t dtype, void* stream);
 
-/* LayerNorm over the last dim of [M, C]; stats [M, 2] fp32 (mean, rstd). */
+/* LayerNorm over the last dim of [M, C]; stats [M, 2] fp32 (mean, rstd).  bwd: `add` as in comat_groupnorm_bwd. */
 int comat_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t M,
                         int32_t C, float eps, int32_t dtype, void* stream);
 int comat_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int64_t M,
-                        int32_t C, int32_t dtype, void* stream);
+                        int32_t C, const void* add, int32_t dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Row softmax of attention scores.  S: [rows, cols] (s_dtype), P: [rows, cols] (p_dtype).

@@ -107,12 +107,12 @@ class SimKernels:
             y = F.silu(y)
         return y, mean.reshape(B, G), rstd.reshape(B, G)
 
-    def groupnorm_fwd(self, x, gamma, beta, y, stats, ws, B, HW, Cc, G, eps, silu):
+    def groupnorm_fwd(self, x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu):
         yy, mean, rstd = self._gn(x.float(), gamma, beta, B, HW, Cc, G, eps, silu)
         y.copy_(yy.to(y.dtype))
         stats.copy_(torch.stack([mean, rstd], dim=-1))
 
-    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, ws, B, HW, Cc, G, silu):
+    def groupnorm_bwd(self, dy, x, gamma, beta, stats, dx, B, HW, Cc, G, silu, add=None):
         mean = stats[..., 0].reshape(B, 1, G, 1)
         rstd = stats[..., 1].reshape(B, 1, G, 1)
         xf = x.float()
@@ -128,6 +128,8 @@ class SimKernels:
         s1 = gg.mean(dim=(1, 3), keepdim=True)
         s2 = (gg * xhg).mean(dim=(1, 3), keepdim=True)
         out = (rstd * (gg - s1 - xhg * s2)).reshape(B * HW, Cc)
+        if add is not None:
+            out = out + add.float()
         dx.copy_(out.to(dx.dtype))
 
     def layernorm_fwd(self, x, gamma, beta, y, stats, M, Cc, eps):
@@ -137,13 +139,16 @@ class SimKernels:
         y.copy_((((xf - mean) * rstd) * gamma + beta).to(y.dtype))
         stats.copy_(torch.cat([mean, rstd], dim=-1))
 
-    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc):
+    def layernorm_bwd(self, dy, x, gamma, stats, dx, M, Cc, add=None):
         mean, rstd = stats[:, :1], stats[:, 1:]
         xh = (x.float() - mean) * rstd
         g = dy.float() * gamma
         s1 = g.mean(-1, keepdim=True)
         s2 = (g * xh).mean(-1, keepdim=True)
-        dx.copy_((rstd * (g - s1 - xh * s2)).to(dx.dtype))
+        d = rstd * (g - s1 - xh * s2)
+        if add is not None:
+            d = d + add.float()
+        dx.copy_(d.to(dx.dtype))
 
     # ---- softmax -------------------------------------------------------------------------------------------
     def softmax_fwd(self, S, P, rows, cols, q_len=0, causal=False, causal_offset=0, key_mask=None, rows_per_mask=0):
