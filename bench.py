@@ -102,6 +102,10 @@ class TimedKernels:
             B, Cin, Hout, Wout, Cout, KH, KW, stride = a[3], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
             f = 2.0 * B * Hout * Wout * Cout * KH * KW * Cin
             return f / (stride * stride) if kw.get("mode", 0) == 1 else f
+        if name == "flash_attn_fwd":  # (q, k, v, o, lse, B, H, Nq, Nk, d, ...): QK^T + PV
+            return 4.0 * a[5] * a[6] * a[7] * a[8] * a[9]
+        if name == "flash_attn_bwd":  # (q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ...): 5 products
+            return 10.0 * a[10] * a[11] * a[12] * a[13] * a[14]
         return 0.0
 
     def summary(self):
@@ -209,30 +213,99 @@ def build_world(device, dtype, rank, cfg_name):
 
 
 def cpu_baseline(usd, scfg):
-    """Oracle (CPU fp32 port) on a bounded sample of the same workload: ONE no-grad SD1.5 UNet forward of the oracle at
-    the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens) — 1/14 of the UNet calls of a C2 step — with
-    FLOPs counted by torch's FlopCounterMode, extrapolated to the whole step by algorithmic FLOPs."""
-    from torch.utils.flop_counter import FlopCounterMode
-
+    """The CPU oracle (fp32 port of the reference's path: its own Python needs diffusers / torchvision / weights that
+    are absent) on a BOUNDED sample of the same workload, per SURVEY.md 8d: one UNet call without grad and one with
+    grad (LoRA + input gradients) at the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens), one BLIP
+    reward forward + backward at 510^2 -> 384^2, one VAE decode forward + backward on a 32x32 latent (a quarter of the
+    pixels; x4), each timed once after the UNet forward has warmed the thread pool; the step time is these times
+    combined by the step's call counts (the discriminator is the same UNet: G side batch 1 = half a trained call, D
+    side batch 2 = one trained call)."""
+    from comat_amd import config, weights
+    from oracle import blip as OB
     from oracle import sd as O
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
-    ocfg = O.UNetConfig()
+    import dataclasses
+    ocfg = O.UNetConfig(**dataclasses.asdict(config.SD15_UNET))
     g = torch.Generator().manual_seed(0)
     x, ctx = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g)
+    lora = {k: v.clone().requires_grad_(True) for k, v in weights.make_lora_weights(config.SD15_UNET, seed=4321).items()}
+    t = {}
     with torch.no_grad():
-        with FlopCounterMode(display=False) as fc:
-            t0 = time.time()
-            O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
-            dt = time.time() - t0
-    sample_tflop = fc.get_total_flops() / 1e12
-    total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss)
-    est_step_s = dt * total / sample_tflop
-    return {"value": 1.0 / est_step_s, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle/sd.py unet_forward (SD1.5, fp32, CFG batch 2, 64x64 latent): {sample_tflop:.3f} TFLOP in "
-                      f"{dt:.1f} s = {sample_tflop / dt:.3f} TFLOP/s on {threads} of {cores} host threads; step time "
-                      f"extrapolated by algorithmic FLOPs ({total:.1f} TFLOP/step)"}
+        t0 = time.time()
+        O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
+        t["unet_nograd"] = time.time() - t0
+    xg = x.clone().requires_grad_(True)
+    t0 = time.time()
+    O.unet_forward(usd, ocfg, xg, 801, ctx, lora, None).float().square().mean().backward()
+    t["unet_train"] = time.time() - t0
+    del lora, xg
+    vcfg = O.VAEConfig(**dataclasses.asdict(config.SD15_VAE))
+    vsd = weights.make_vae_weights(config.SD15_VAE, seed=2345)
+    z = torch.randn(1, 4, 32, 32, generator=g).requires_grad_(True)
+    t0 = time.time()
+    O.vae_decode(vsd, vcfg, z).square().mean().backward()
+    t["vae_quarter_train"] = time.time() - t0
+    del vsd, z
+    bcfg = OB.BlipConfig(**dataclasses.asdict(config.BLIP_LARGE))
+    bsd = weights.make_blip_weights(config.BLIP_LARGE, seed=3456)
+    img = torch.rand(1, 3, 510, 510, generator=g).requires_grad_(True)
+    ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
+                     torch.tensor([102])]).reshape(1, 16)
+    t0 = time.time()
+    reward, _ = OB.score(bsd, bcfg, img, ids, torch.ones_like(ids), label_smoothing=0.1)
+    reward.backward()
+    t["blip_train"] = time.time() - t0
+    del bsd
+    step_s = (scfg.K * t["unet_train"] + (scfg.total_step - scfg.K) * t["unet_nograd"] + 4 * t["vae_quarter_train"]
+              + t["blip_train"] + (1.5 * t["unet_train"] if scfg.gan_loss else 0.0))
+    return {"value": 1.0 / step_s, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "oracle/ (CPU fp32) components timed once each on " + f"{threads} of {cores} host threads: "
+                      + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
+                      + f"; step = {scfg.K} x unet_train + {scfg.total_step - scfg.K} x unet_nograd + 4 x vae_quarter_train + "
+                      f"blip_train + 1.5 x unet_train (discriminator G and D sides) = {step_s:.0f} s",
+            "components_s": {k: round(v, 2) for k, v in t.items()}}
+
+
+def attn_map_probe():
+    """North-star counter: the attention-map path on its own.  Softmax write-back of one captured SD1.5 `up_64`
+    cross-attention map ([8 heads, 4096 pixels, 77 tokens], fp32 scores -> bf16 probabilities, the map the attribute-
+    concentration loss reads) and the gather of 4 token columns over it, each timed with HIP events on the launch
+    stream over 20 launches; algorithmic bytes / time against the 8 TB/s HBM peak."""
+    from comat_amd import ops
+    k = ops.kernels()
+    dev = torch.device("cuda:0")
+    H, NP, L, NT = 8, 4096, 77, 4
+    S = torch.randn(H, NP, L, device=dev)
+    P = torch.empty(H, NP, L, device=dev, dtype=torch.bfloat16)
+    mask = (torch.rand(2, NP, device=dev) > 0.5).float()
+    tok_idx = torch.tensor([2, 3, 6, 7], dtype=torch.int32, device=dev)
+    tok_obj = torch.tensor([0, 0, 1, 1], dtype=torch.int32, device=dev)
+    num, den = torch.zeros(H, NT, device=dev), torch.zeros(H, NT, device=dev)
+    avg = torch.zeros(NT, NP, device=dev)
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / n * 1e-3
+
+    t_sm = timed(lambda: k.softmax_fwd(S, P, H * NP, L))
+    t_ga = timed(lambda: k.attnmap_gather_fwd(P, mask, tok_idx, tok_obj, num, den, avg, H, NP, L, NT))
+    b_sm = H * NP * L * (4 + 2)            # scores read (fp32) + probabilities written (bf16)
+    b_ga = H * NP * NT * 2 + NT * NP * 4   # selected columns read + per-token head-mean map written
+    return {"softmax_writeback": {"bytes": b_sm, "us": round(t_sm * 1e6, 2), "GB/s": round(b_sm / t_sm / 1e9, 1),
+                                  "frac_of_8TBs": round(b_sm / t_sm / 8e12, 4)},
+            "gather": {"bytes": b_ga, "us": round(t_ga * 1e6, 2), "GB/s": round(b_ga / t_ga / 1e9, 1),
+                       "frac_of_8TBs": round(b_ga / t_ga / 8e12, 4),
+                       "note": "algorithmic bytes = the 4 selected token columns; the kernel touches every 64-byte "
+                               "segment of the [pixels, 77] rows that holds one"}}
 
 
 def main():
@@ -313,10 +386,25 @@ def main():
     dist.barrier()
     sync()
     dt = time.time() - t0
+    per_rank_ms, allreduce_ms = None, None
     if world > 1:
+        # diagnostics for the scaling runs: every rank's own time for the K steps, and the cost of the step's two
+        # all-reduces (flat G and D gradient buffers) measured on their own after the timed region
+        per_rank_ms = [round(v / args.steps * 1e3, 2) for v in dist.all_gather_scalar(dt, device)]
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
+        if not args.selftest:
+            bufs = [trainer.bank.flat_grad] + ([trainer.D.bank.flat_grad] if scfg.gan_loss else [])
+            for b in bufs:
+                torch.distributed.all_reduce(b.clone())
+            sync()
+            t0a = time.time()
+            for _ in range(5):
+                for b in bufs:
+                    torch.distributed.all_reduce(b)
+            sync()
+            allreduce_ms = round((time.time() - t0a) / 5 * 1e3, 3)
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt  # one image (prompt) per rank per step
 
@@ -352,6 +440,9 @@ def main():
                              "share_of_kernel_time": round(v[0] / tot_t, 4)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]},
         }
+    attn_map = None
+    if rank == 0 and not args.no_kernel_timing and not args.selftest:
+        attn_map = attn_map_probe()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "c4" and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)
@@ -371,8 +462,9 @@ def main():
                                    f"fidelity (G+D step)" + (" + attribute concentration" if scfg.attrcon else "") +
                                    ", clip+AdamW for G and D",
                        "parallelism": f"dp{world}", "build_s": round(t_build, 1),
-                       "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 1), "launch_mode": graph_note},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 1), "launch_mode": graph_note,
+                       "per_rank_ms_per_step": per_rank_ms, "allreduce_ms_per_step": allreduce_ms},
+            "roofline": roofline, "cpu_baseline": cpu, "attn_map": attn_map,
         }
         print(json.dumps(out))
 

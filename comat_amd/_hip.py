@@ -403,7 +403,7 @@ class HipKernels:
 
     def attnmap_gather_fwd(self, amap, mask, tok_idx, tok_obj, num, den, avg, heads, npix, L, n_tok):
         assert tok_idx.dtype == torch.int32 and tok_obj.dtype == torch.int32
-        ws = self._scratch(amap.device, (((npix + 255) // 256) * 2 + npix) * heads * n_tok)
+        ws = self._scratch(amap.device, (((npix + 127) // 128) * 2 + npix) * heads * n_tok)
         _check(_lib.comat_attnmap_gather_fwd(_ptr(amap), _ptr(mask), _ptr(tok_idx), _ptr(tok_obj), _ptr(num),
                                              _ptr(den), _ptr(avg), _ptr(ws), heads, npix, L, n_tok, dt(amap),
                                              _stream()), "comat_attnmap_gather_fwd")

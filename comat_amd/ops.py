@@ -1240,7 +1240,7 @@ class _AttnMapGather(Function):
         z = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else _c(t)
         g_num, g_den = z(g_num, (H, n_tok)), z(g_den, (H, n_tok))
         g_avg = None if g_avg is None else _c(g_avg)
-        damap = torch.zeros((H, npix, L), dtype=adt, device=dev)
+        damap = torch.empty((H, npix, L), dtype=adt, device=dev)  # the kernel writes every element
         kernels().attnmap_gather_bwd(g_num, g_den, g_avg, mask, tok_idx, tok_obj, damap, H, npix, L, n_tok)
         return damap, None, None, None
 

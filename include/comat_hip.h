@@ -271,10 +271,13 @@ int comat_disc_head_bwd(const void* x, const float* w, const float* b, const flo
  *   num[h, t] = sum_px A[h,px,tok_t] * mask[obj_t, px];  den[h, t] = sum_px A[h,px,tok_t];
  *   avg[t, px] += (1/heads) * A[h,px,tok_t]   (head-mean map per token, accumulated across layers by the caller)
  * The (tiny) remaining reductions are host-side torch on [heads, n_tok] and [n_tok, res*res] tensors.
- * bwd: dA[h,px,tok_t] += g_num[h,t]*mask + g_den[h,t] + g_avg[t,px]/heads   (dA zero elsewhere; caller zeroes). */
+ * bwd: dA[h,px,tok_t] = sum over the listed t of g_num[h,t]*mask + g_den[h,t] + g_avg[t,px]/heads, zero elsewhere: the
+ * kernel writes EVERY element of dA (no zero-fill by the caller).
+ * Both passes move the map as one coalesced stream staged through LDS (16-byte accesses) and pick / place the token
+ * columns there. */
 int comat_attnmap_gather_fwd(const void* amap, const float* mask, const int32_t* tok_idx, const int32_t* tok_obj,
                              float* num, float* den, float* avg,
-                             float* ws /* (ceil(npix/256)*2 + npix) * heads * n_tok floats */,
+                             float* ws /* (ceil(npix/128)*2 + npix) * heads * n_tok floats */,
                              int32_t heads, int32_t npix, int32_t L, int32_t n_tok, int32_t dtype, void* stream);
 int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float* g_avg, const float* mask,
                              const int32_t* tok_idx, const int32_t* tok_obj, void* damap, int32_t heads,

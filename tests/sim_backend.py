@@ -343,7 +343,7 @@ class SimKernels:
         g = g_num[:, None, :] * m.t()[None] + g_den[:, None, :]
         if g_avg is not None:
             g = g + g_avg.t()[None] / heads
-        d = damap.float()
+        d = torch.zeros(damap.shape, dtype=torch.float32)  # the kernel writes every element of dA
         for t in range(n_tok):
             d[:, :, int(tok_idx[t])] += g[:, :, t]
         damap.copy_(d.to(damap.dtype))

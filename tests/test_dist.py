@@ -19,18 +19,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, gpu=False):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.set_num_threads(2)
     from comat_amd import dist as cdist
     from comat_amd import ops
-    from sim_backend import SimKernels
     from test_step import make_world
-    ops.set_kernel_backend(SimKernels())
-    r, w, dev = cdist.init(backend="gloo")
+    if gpu:  # the real kernels, one process per GPU, RCCL ("nccl" backend on ROCm) over xGMI
+        from comat_amd import _hip
+        ops.set_kernel_backend(_hip.HipKernels())
+        r, w, dev = cdist.init(backend="nccl")
+        assert dev.type == "cuda"
+    else:
+        from sim_backend import SimKernels
+        ops.set_kernel_backend(SimKernels())
+        r, w, dev = cdist.init(backend="gloo")
     assert (r, w) == (rank, world)
     cfg, batch, W, trainer = make_world(torch.float32, dev, False)
     g = torch.Generator().manual_seed(100 + rank)  # each rank: its own prompt / latents
@@ -47,8 +53,9 @@ def _worker(rank, world, port, out_dir):
     # the real step: reduces, clips, updates
     p0 = trainer.bank.flat.clone()
     trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
-    torch.save(dict(mean=mean, reduced=trainer.bank.flat_grad.clone(), params=trainer.bank.flat.clone(), p0=p0,
-                    local=local), os.path.join(out_dir, f"rank{rank}.pt"))
+    cpu = lambda t: t.detach().cpu().clone()
+    torch.save(dict(mean=cpu(mean), reduced=cpu(trainer.bank.flat_grad), params=cpu(trainer.bank.flat), p0=cpu(p0),
+                    local=cpu(local), d_params=cpu(trainer.D.bank.flat)), os.path.join(out_dir, f"rank{rank}.pt"))
     cdist.barrier()
     dist.destroy_process_group()
 
@@ -63,4 +70,24 @@ def test_two_rank_gloo_grad_mean(tmp_path):
         assert torch.allclose(r[i]["reduced"], r[i]["mean"], rtol=1e-5, atol=1e-7)  # all-reduce(mean)
     assert torch.equal(r[0]["reduced"], r[1]["reduced"])
     assert torch.equal(r[0]["params"], r[1]["params"])                  # replicas stay in sync
+    assert not torch.equal(r[0]["params"], r[0]["p0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_grad_mean(tmp_path):
+    """The same check on two real GPUs over RCCL (one process per GPU): all-reduced gradient == mean of the ranks' local
+    gradients, generator and discriminator replicas bit-identical after the step (the G all-reduce is launched while the
+    D step still runs on its own stream).  Skips on a 1-GPU box (gpurun boxes have one GPU; the driver's 8-GPU node runs
+    it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(world)]
+    assert not torch.allclose(r[0]["local"], r[1]["local"])
+    for i in range(world):
+        assert torch.allclose(r[i]["reduced"], r[i]["mean"], rtol=1e-5, atol=1e-7)
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])
+    assert torch.equal(r[0]["params"], r[1]["params"]) and torch.equal(r[0]["d_params"], r[1]["d_params"])
     assert not torch.equal(r[0]["params"], r[0]["p0"])
