@@ -491,20 +491,21 @@ __device__ __forceinline__ void gemm_block(AL& al, BL& bl, int64_t kt0, int64_t 
     if (sk.splits > 1) {
         // split-K: park the fp32 partial tile (lane-linear float4 slabs), take a ticket; the last arriver of the tile
         // adds the slices in slice order and finishes (gemm_shared.h) - no reduce launch
-        f32x4_t* mine = (f32x4_t*)sk.slabs + ((int64_t)sk.sp * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x;
+        const SlabIO io(sk.slabs);
+        const int64_t mine = (((int64_t)sk.sp * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x) * 16;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4_t v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-            mine[q * NT] = v;
+            const f32x4_t v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            io.store(mine + (int64_t)q * NT * 16, v);
         }
-        if (!splitk_arrive_is_last(sk.counter, sk.splits, (unsigned*)&smem[0][0][0])) return;
+        if (!splitk_ticket_is_last(sk.counter, sk.splits, (unsigned*)&smem[0][0][0])) return;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         for (int s2 = 0; s2 < sk.splits; ++s2) {
-            const f32x4_t* src = (const f32x4_t*)sk.slabs + ((int64_t)s2 * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x;
+            const int64_t src = (((int64_t)s2 * sk.ntiles + sk.tile) * 4 * NT + threadIdx.x) * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4_t v = src[q * NT];
+                const f32x4_t v = io.load(src + (int64_t)q * NT * 16);
                 acc[4 * q] += v[0];
                 acc[4 * q + 1] += v[1];
                 acc[4 * q + 2] += v[2];

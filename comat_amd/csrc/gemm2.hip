@@ -30,7 +30,6 @@ namespace {
 
 constexpr int BK = 32;       // k elements per k-tile
 constexpr int RB = 64;       // bytes per LDS row
-constexpr int NST = 4;       // LDS ring depth (k-tiles)
 constexpr int MAXSEG2 = 8;
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised: source of padding taps
@@ -57,6 +56,11 @@ struct Args2 {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `tiles` k-tiles (L DMA instructions each) of this wave are still in flight; tiles in [0, MAXT]
+template <int L, int MAXT> __device__ __forceinline__ void wait_tiles(int tiles) {
+    if (tiles >= MAXT) wait_vmcnt<L * MAXT>();
+    else if constexpr (MAXT > 0) wait_tiles<L, MAXT - 1>(tiles);
+}
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -145,8 +149,9 @@ __device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m,
     }
 }
 
-// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  CONV: implicit-GEMM gather.
-template <int BM, int BN, int WM, int WN, bool CONV>
+// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles; NST-deep LDS ring.
+// CONV: implicit-GEMM gather.
+template <int BM, int BN, int WM, int WN, int NST, bool CONV>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     constexpr int NW = WM * WN, NTH = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be whole MFMA tiles");
     constexpr int L = IA + IB;          // DMA instructions per wave per k-tile
     constexpr int SS = (BM + BN) * RB;  // bytes per ring stage: [A: BM rows][B: BN rows]
-    static_assert(2 * L <= 63, "vmcnt range");
+    static_assert(NST >= 4 && (NST - 3) * L <= 63, "ring depth / vmcnt range");
     __shared__ __attribute__((aligned(1024))) char smem[NST * SS];  // the ONLY LDS object of the kernel
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -301,42 +306,59 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     const int fo0 = r * RB + ((0 + h) ^ sw) * 16, fo1 = r * RB + ((2 + h) ^ sw) * 16;
     const int a_base = wr * WTM * RB, b_base = BM * RB + wc * WTN * RB;
 
-    // ---- pipeline: tiles t+1, t+2 in flight while tile t is consumed; ONE barrier per k-tile ----
+    // ---- pipeline.  DMA runs NST-1 k-tiles ahead of the MFMAs; ONE barrier per k-tile, in the MIDDLE of a tile's MFMA
+    // work: the fragments of k-step 1 are requested from LDS before the MFMAs of k-step 0 issue, the fragments of the
+    // next tile's k-step 0 before the MFMAs of k-step 1, so that with one wave per SIMD (these problems rarely have two
+    // blocks per CU) the LDS latency and the barrier hide under 4 MFMAs instead of stalling the in-order wave.
+    // Iteration t, at its barrier: tiles .. t+NST-2 have been issued, tile t+1 must have landed -> up to NST-3 tiles stay
+    // in flight across the barrier (counted vmcnt); then tile t+NST-1 is issued into the stage of tile t-1, whose reads
+    // were all consumed by MFMAs before any wave reached this barrier. ----
+    auto frags = [&](const char* st, int fo, short8_t (&xf)[TM], short8_t (&wf)[TN]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) xf[a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) wf[b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo);
+    };
+    auto mmas = [&](const short8_t (&xf)[TM], const short8_t (&wf)[TN]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf[b], xf[a]);
+    };
 #pragma unroll
     for (int u = 0; u < NST - 1; ++u)
         if (u < nt) issue(u);
-    for (int t = 0; t < nt; ++t) {
-        const int rem = nt - t;
-        if (rem >= 3) wait_vmcnt<2 * L>();
-        else if (rem == 2) wait_vmcnt<L>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();  // every wave's part of tile t has landed; every wave is done reading tile t-1
+    short8_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    if (nt > 0) {
+        wait_tiles<L, NST - 2>(nt - 1);  // tile 0 landed (this wave's part)
+        __builtin_amdgcn_s_barrier();   // ... and every other wave's
         asm volatile("" ::: "memory");
-        if (t + NST - 1 < nt) issue((t + NST - 1) & (NST - 1));  // overwrites the stage of tile t-1
-        const char* st = smem + (t & (NST - 1)) * SS;
-        short8_t xf[2][TM], wf[2][TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            xf[0][a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo0);
-            xf[1][a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo1);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            wf[0][b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo0);
-            wf[1][b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo1);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf[s][b], xf[s][a]);
+        frags(smem, fo0, xf0, wf0);
+    }
+    int stage = 0;  // ring slot of tile t
+    for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
+        frags(smem + stage * SS, fo1, xf1, wf1);
+        mmas(xf0, wf0);
+        const int nstage = stage + 1 == NST ? 0 : stage + 1;
+        wait_tiles<L, NST - 3>(nt - 2 - t);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);  // the slot of tile t-1
+        frags(smem + nstage * SS, fo0, xf0, wf0);
+        mmas(xf1, wf1);
+        stage = nstage;
+    }
+    if (nt > 0) {  // last tile
+        frags(smem + stage * SS, fo1, xf1, wf1);
+        mmas(xf0, wf0);
+        mmas(xf1, wf1);
     }
 
-    // ---- split-K: combine inside the launch ----
+    // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
     if (g.splits > 1) {
-        constexpr int QPT = TM * TN * 4;  // float4 per thread
-        f32x4_t* mine = (f32x4_t*)(g.ws + WS_COUNTERS) + ((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid;
+        constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
+        const SlabIO io(g.ws + WS_COUNTERS);
+        const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -344,9 +366,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                    mine[((a * TN + b) * 4 + q) * NTH] = v;
+                    io.store(mine + (int64_t)((a * TN + b) * 4 + q) * NTH * 16, v);
                 }
-        if (!splitk_arrive_is_last((unsigned*)g.ws + tile, g.splits, (unsigned*)smem)) return;
+        if (!splitk_ticket_is_last((unsigned*)g.ws + tile, g.splits, (unsigned*)smem)) return;
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -354,14 +376,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
         for (int s2 = 0; s2 < g.splits; ++s2) {
-            const f32x4_t* src = (const f32x4_t*)(g.ws + WS_COUNTERS) + ((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid;
+            const int64_t src = (((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid) * 16;
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4_t v = src[((a * TN + b) * 4 + q) * NTH];
+                        const f32x4_t v = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
                         acc[a][b][4 * q] += v[0];
                         acc[a][b][4 * q + 1] += v[1];
                         acc[a][b][4 * q + 2] += v[2];
@@ -403,7 +425,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4 };
+enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -413,16 +435,21 @@ static Cfg2 cfg_dims(int c) {
         case CFG_128x64: return {128, 64, 256};
         case CFG_256x128: return {256, 128, 512};
         case CFG_64x128: return {64, 128, 256};
+        case CFG_64x64: return {64, 64, 256};
         default: return {128, 128, 256};
     }
 }
 
+// tile, waves, ring depth (LDS = depth * (BM + BN) * 64 B): 128x128 / 4 deep = 64 KB (two blocks per CU), 128x64 and
+// 64x128 / 6 deep = 72 KB (two per CU), 256x128 / 4 deep = 96 KB and 128x128 / 6 deep = 96 KB (one per CU), 64x64 / 8
 template <bool CONV> static void launch_cfg(int c, const Args2& a, unsigned blocks, hipStream_t st) {
     switch (c) {
-        case CFG_128x64: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_256x128: hipLaunchKernelGGL((gemm2_kernel<256, 128, 4, 2, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
-        case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x64: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_256x128: hipLaunchKernelGGL((gemm2_kernel<256, 128, 4, 2, 4, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
 
@@ -436,25 +463,54 @@ static void g2_overrides(int* cfg, int* splits) {
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// tile shape and split count for a problem of M x N with nkt k-tiles, `batch` independent problems
-static void plan2(int64_t M, int64_t N, int nkt, int64_t batch, int64_t ws_bytes, int* cfg_out, int* splits_out) {
+// ---- plans: block tile and split count per problem ----
+// (1) a table of measured plans for the problems of the SD1.5 / SDXL / BLIP steps (tools/tune_gemm2.py on an MI355X ->
+//     tools/make_gemm2_plans.py -> gemm2_plans.inc), keyed by (conv?, M, N, k-tiles, batch);
+// (2) a rule of thumb for everything else, read off the same measurements: these launches are a single wave of blocks
+//     or less, so the block count matters more than the tile's arithmetic intensity - take the largest tile that still
+//     gives ~one block per CU, else the half-size tile; cut k only when even that leaves most CUs idle AND every slice
+//     keeps >= 24 k-tiles (a slice costs an fp32 slab round trip plus the ticket).
+struct Plan2Entry {
+    int conv;
+    int64_t M, N;
+    int nkt, batch, cfg, splits;
+};
+#include "gemm2_plans.inc"
+
+static void plan2(bool conv, int64_t M, int64_t N, int nkt, int64_t batch, int64_t ws_bytes, int* cfg_out, int* splits_out) {
     int fc = 0, fs = 0;
     g2_overrides(&fc, &fs);
     int c = fc;
+    int64_t s = fs;
     if (c == CFG_AUTO) {
-        if (M >= 32768 && N >= 128) c = CFG_256x128;          // VAE-sized: plenty of tiles, take the biggest
-        else if (N % 128 != 0 && N % 128 <= 64) c = CFG_128x64;  // N = 64, 320, 960 ...: no half-empty column tiles
-        else c = CFG_128x128;
+        for (size_t i = 0; i < sizeof(g2_plans) / sizeof(g2_plans[0]); ++i) {
+            const Plan2Entry& e = g2_plans[i];
+            if (e.conv == (conv ? 1 : 0) && e.M == M && e.N == N && e.nkt == nkt && e.batch == batch) {
+                c = e.cfg;
+                if (s == 0) s = e.splits;
+                break;
+            }
+        }
+    }
+    if (c == CFG_AUTO) {
+        const int half = (N % 128 != 0 && N % 128 <= 64) ? CFG_128x64 : CFG_64x128;
+        const int64_t b128 = cdiv64(M, 128) * cdiv64(N, 128) * batch;
+        if (M >= 32768 && N >= 128) c = CFG_256x128;  // VAE-sized: plenty of tiles, take the biggest
+        else if (b128 >= 224 && !(half == CFG_128x64)) c = CFG_128x128;
+        else if (b128 >= 448) c = CFG_128x128;        // N = 64, 320, 960 ...: no half-empty column tiles unless plenty
+        else c = half;
     }
     const Cfg2 d = cfg_dims(c);
     const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
-    int64_t s = 1;
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
-    if (slab_bytes > 0 && ntiles <= WS_COUNTERS) {
-        if (fs > 0) s = fs;
-        else if (ntiles < 192 && nkt >= 16) {  // fewer tiles than 3/4 of the CUs and a long contraction
-            s = cdiv64(256, ntiles);
-            if (s > nkt / 8) s = nkt / 8;
+    if (slab_bytes <= 0 || ntiles > WS_COUNTERS) s = 1;
+    else {
+        if (s == 0) {
+            s = 1;
+            if (ntiles < 112 && nkt >= 48) {
+                s = cdiv64(224, ntiles);
+                if (s > nkt / 24) s = nkt / 24;
+            }
         }
         const int64_t cap = slab_bytes / (ntiles * d.bm * d.bn * 4);
         if (s > cap) s = cap;
@@ -487,7 +543,7 @@ static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t 
 
 static int finish_launch(Args2& a, bool conv, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
     int c, s;
-    plan2(a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
+    plan2(conv, a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
     const Cfg2 d = cfg_dims(c);
     a.tiles_m = (int)cdiv64(a.M, d.bm);
     a.tiles_n = (int)cdiv64(a.N, d.bn);

@@ -27,28 +27,40 @@ __device__ __forceinline__ int64_t xcd_chunk_map(int64_t bid, int64_t n) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Split-K without a reduce launch.  Every block of a tile's `splits` k-slices stores its fp32 partial tile to its
-// slab (plain stores, lane-linear layout: the reader loads exactly what the writer stored, 16 bytes per lane, fully
-// coalesced), then takes a ticket on the tile's counter.  The block that draws the last ticket adds the slabs IN
-// SLICE ORDER (its own slice from the slab too, so the summation order does not depend on who arrives last: results
-// are bit-reproducible) and runs the fused epilogue.  Visibility between workgroups (per-CU L1, per-XCD L2 are not
-// coherent) follows the agent-scope release / acquire recipe of the CDNA4 guide (cdna_hip_programming.md, guideline
-// 16): every storing wave drains its stores, one lane releases at agent scope before the ticket, the last arriver
-// acquires at agent scope before any wave of its block reads.  The counter is re-armed (0) by the last arriver, so
-// the caller zeroes the counter region ONCE (include/comat_hip.h: COMAT_WS_COUNTER_BYTES).
-// `lds_flag`: one dword of the block's single LDS array (no second __shared__ object).
+// slab (lane-linear layout: the reader loads exactly what the writer stored, 16 bytes per lane, fully coalesced), then
+// takes a ticket on the tile's counter.  The block that draws the last ticket adds the slabs IN SLICE ORDER (its own
+// slice from the slab too, so the summation order does not depend on who arrives last: results are bit-reproducible)
+// and runs the fused epilogue.
+// Visibility between workgroups (per-CU L1 and per-XCD L2 are not coherent): the slabs are stored WRITE-THROUGH
+// (sc1) and read back with sc1 loads, every storing wave drains its stores (s_waitcnt vmcnt(0)) before the block's
+// ticket - the fence-free form of the CDNA4 guide's hand-off recipe (cdna_hip_programming.md, guideline 16, R1: "sc1
+// loads may replace the acquire only when the producer stored sc1").  The first version of this code used plain stores
+// + an agent-scope release fence per block + an acquire in the last arriver: correct, but every block's release
+// (buffer_wbl2) writes back its XCD's dirty L2 lines, which cost ~10 us per launch on MI355X
+// (profiles/r02_b_*: GroupNorm statistics 9 -> 19 us, 64-slice weight-gradient GEMMs 25 -> 40 us).
+// The counter is re-armed (0) by the last arriver, so the caller zeroes the counter region ONCE
+// (include/comat_hip.h: COMAT_WS_COUNTER_BYTES).  `lds_flag`: one dword of the block's single LDS array.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool splitk_arrive_is_last(unsigned* counter, int splits, unsigned* lds_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slab stores have left
+struct SlabIO {
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ explicit SlabIO(float* base)
+        : rs(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000)) {}
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    __device__ __forceinline__ void store(int64_t byte_off, const f32x4_t& v) const {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)byte_off, 0, /*sc1*/ 16);
+    }
+    __device__ __forceinline__ f32x4_t load(int64_t byte_off) const {
+        return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, /*sc1*/ 16));
+    }
+};
+
+__device__ __forceinline__ bool splitk_ticket_is_last(unsigned* counter, int splits, unsigned* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through slab stores have left
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = old == (unsigned)(splits - 1);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
-        }
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
         *lds_flag = last ? 1u : 0u;
     }
     __syncthreads();

@@ -251,23 +251,28 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
             }
         // per-block partial (no atomics): reduced in block order by gn_reduce_kernel -> bit-reproducible statistics
         double* part = ws + ((int64_t)(1 + blockIdx.x) * gridDim.y + b) * G * 2;
-        part[threadIdx.x * 2 + 0] = (double)f1;
-        part[threadIdx.x * 2 + 1] = (double)f2;
+        if (tickets) {  // write-through (sc1) stores: another workgroup of THIS launch reads them (gemm_shared.h)
+            __hip_atomic_store(part + threadIdx.x * 2 + 0, (double)f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + threadIdx.x * 2 + 1, (double)f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            part[threadIdx.x * 2 + 0] = (double)f1;
+            part[threadIdx.x * 2 + 1] = (double)f2;
+        }
     }
     if (tickets == nullptr) return;  // three-launch form: gn_reduce(_finalize)_kernel combines the partials
     // Two-launch form: the LAST block of this sample to arrive combines the per-block partials of its G groups, in the
     // same fixed order as gn_reduce(_finalize)_kernel (lane l takes slabs l, l+64, ..., then a fixed butterfly), so the
     // statistics stay bit-reproducible and identical to the three-launch form.
-    if (!splitk_arrive_is_last(tickets + b, (int)gridDim.x, (unsigned*)p_a)) return;
+    if (!splitk_ticket_is_last(tickets + b, (int)gridDim.x, (unsigned*)p_a)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = gridDim.x;
     const int64_t n = (int64_t)gridDim.y * G * 2;
     for (int g2 = wave; g2 < G; g2 += NT / 64) {
         const int64_t i = (int64_t)b * G + g2;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < nblk; k += 64) {
-            s1 += ws[(int64_t)(1 + k) * n + 2 * i];
-            s2 += ws[(int64_t)(1 + k) * n + 2 * i + 1];
+        for (int k = lane; k < nblk; k += 64) {  // sc1 loads: the partials come from other workgroups of this launch
+            s1 += __hip_atomic_load(ws + (int64_t)(1 + k) * n + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s2 += __hip_atomic_load(ws + (int64_t)(1 + k) * n + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         s1 = wave_sum_f64(s1);
         s2 = wave_sum_f64(s2);

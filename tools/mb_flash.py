@@ -1,0 +1,61 @@
+"""Fused-attention microbenchmark on the step's shapes: forward and backward (prep + dQ + dK/dV [+ reduce]) under the four
+flash_trim x flash_tr variants.  python tools/mb_flash.py  (GPU box)"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from comat_amd import _hip, ops  # noqa: E402
+
+SHAPES = [  # B, H, Nq, Nk, d
+    (2, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160), (2, 8, 64, 64, 160),
+    (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (1, 16, 577, 577, 64), (1, 12, 16, 577, 64),
+    (1, 1, 4096, 4096, 512 // 4)]
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def main():
+    dev = torch.device("cuda:0")
+    k = _hip.HipKernels()
+    ops.set_kernel_backend(k)
+    T = torch.bfloat16
+    for (B, H, Nq, Nk, d) in SHAPES:
+        HD = H * d
+        q = torch.randn(B * Nq, HD, device=dev).to(T)
+        kk = torch.randn(B * Nk, HD, device=dev).to(T)
+        v = torch.randn(B * Nk, HD, device=dev).to(T)
+        g = torch.randn(B * Nq, HD, device=dev).to(T)
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, Nq, device=dev)
+        dbuf = torch.empty(B, H, Nq, device=dev)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
+        sc = d ** -0.5
+        for trim in (0, 1):
+            for tr in (0, 1):
+                _hip.set_option("flash_trim", trim)
+                _hip.set_option("flash_tr", tr)
+                tf = timeit(lambda: k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, sc))
+                tb = timeit(lambda: k.flash_attn_bwd(q, kk, v, o, g, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, HD, HD, HD, HD, sc))
+                fl = 4.0 * B * H * Nq * Nk * d
+                print(f"flash B={B} H={H} Nq={Nq} Nk={Nk} d={d:3d} trim={trim} tr={tr}  fwd {tf:8.1f} us {fl / tf / 1e6:7.1f} TF/s   "
+                      f"bwd {tb:8.1f} us {2.5 * fl / tb / 1e6:7.1f} TF/s", flush=True)
+    _hip.set_option("flash_trim", 1)
+    _hip.set_option("flash_tr", 1)
+
+
+if __name__ == "__main__":
+    main()

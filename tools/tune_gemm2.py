@@ -1,0 +1,146 @@
+"""Per-shape plan tuning of the pipelined GEMM / conv kernel (gemm2.hip) on the GPU box.
+
+    python tools/tune_gemm2.py c2 [c4 ...]  > gpurun_out/g2_tune.jsonl
+
+1. builds the bench world of each configuration, runs one eager step with a recorder around the kernel backend and
+   collects the distinct GEMM / K-segmented GEMM / conv problems of the step with their call counts;
+2. replays every problem the pipelined kernel accepts on synthetic operands under each block tile (g2_cfg) and split
+   count, 10 timed launches per variant (HIP events);
+3. prints one JSON line per problem: key (kind, M, N, k-tiles, batch), calls per step, microseconds per variant, best.
+tools/make_gemm2_plans.py turns the output into comat_amd/csrc/gemm2_plans.inc (the static plan table)."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+os.environ["COMAT_STEP_GRAPH"] = "0"
+import bench  # noqa: E402
+from comat_amd import _hip, ops  # noqa: E402
+
+CFGS = {1: (128, 128), 2: (128, 64), 3: (256, 128), 4: (64, 128), 6: (64, 64)}
+
+
+class Recorder:
+    def __init__(self, inner):
+        self.inner, self.seen = inner, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self.inner, name)
+        if name not in ("gemm", "gemm_segments", "conv2d"):
+            return fn
+
+        def wrapped(*a, **kw):
+            sig = None
+            if name == "gemm" and a[0].dtype == torch.bfloat16 and not kw.get("transA") and not kw.get("transB"):
+                b = kw.get("batch", (1, 1))
+                if b[1] == 1 and a[5] % 32 == 0 and a[3] >= 48:
+                    sig = ("gemm", a[3], a[4], a[5] // 32, b[0], a[5], kw.get("R") is not None, str(a[2].dtype))
+            elif name == "gemm_segments" and a[0][0][0].dtype == torch.bfloat16 and a[2] >= 48:
+                ks = tuple(sg[2] for sg in a[0])
+                if all(k_ % 32 == 0 for k_ in ks):
+                    sig = ("seg", a[2], a[3], sum(ks) // 32, kw.get("batch", 1), ks, kw.get("R") is not None, str(a[1].dtype))
+            elif name == "conv2d" and a[0].dtype == torch.bfloat16 and kw.get("mode", 0) == 0 and a[6] % 32 == 0:
+                B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad = a[3:14]
+                if B * Hout * Wout >= 48:
+                    sig = ("conv", B * Hout * Wout, Cout, KH * KW * Cin // 32, 1,
+                           (B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, kw.get("ups", 1)),
+                           kw.get("R") is not None, str(a[2].dtype))
+            if sig is not None:
+                self.seen[sig] = self.seen.get(sig, 0) + 1
+            return fn(*a, **kw)
+        return wrapped
+
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def make_call(k, sig, dev):
+    T = torch.bfloat16
+    kind, M, N, nkt, batch, extra, has_r, out_dt = sig
+    odt = torch.float32 if "float32" in out_dt else T
+    r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(T)
+    if kind == "gemm":
+        K = extra
+        a, b = r(batch, M, K), r(batch, N, K)
+        c = torch.empty((batch, M, N), dtype=odt, device=dev)
+        R = torch.zeros_like(c) if has_r else None
+        return lambda: k.gemm(a, b, c, M, N, K, K, K, N, R=R, ldr=N, beta=1.0 if has_r else 0.0, batch=(batch, 1),
+                              sA=(M * K, 0), sB=(N * K, 0), sC=(M * N, 0), sR=(M * N, 0))
+    if kind == "seg":
+        segs = [(r(batch, M, K_), r(batch, N, K_), K_, K_, K_, M * K_, N * K_) for K_ in extra]
+        c = torch.empty((batch, M, N), dtype=odt, device=dev)
+        R = torch.zeros_like(c) if has_r else None
+        return lambda: k.gemm_segments(segs, c, M, N, N, R=R, ldr=N, beta=1.0 if has_r else 0.0, batch=batch, sC=M * N,
+                                       sR=M * N)
+    B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, ups = extra
+    x, w = r(B * Hin * Win, Cin), r(Cout, KH, KW, Cin)
+    y = torch.empty((B * Hout * Wout, Cout), dtype=odt, device=dev)
+    R = torch.zeros_like(y) if has_r else None
+    bias = torch.zeros(Cout, device=dev)
+    return lambda: k.conv2d(x, w, y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=ups, bias=bias, R=R,
+                            beta=1.0 if has_r else 0.0)
+
+
+def main():
+    dev = torch.device("cuda:0")
+    k = _hip.HipKernels()
+    seen = {}
+    for cfg_name in sys.argv[1:] or ["c2"]:
+        ops.set_kernel_backend(k)
+        trainer, batch, fixed, scfg, _, _ = bench.build_world(dev, torch.bfloat16, 0, cfg_name)
+        trainer.train_step(batch, **fixed)
+        rec = Recorder(k)
+        ops.set_kernel_backend(rec)
+        trainer.train_step(batch, **fixed)
+        torch.cuda.synchronize()
+        ops.set_kernel_backend(k)
+        for sig, n in rec.seen.items():
+            seen[sig] = max(seen.get(sig, 0), n)
+        del trainer, batch
+        torch.cuda.empty_cache()
+    print(f"# {len(seen)} distinct problems", file=sys.stderr, flush=True)
+    for sig, calls in sorted(seen.items(), key=lambda kv: -kv[1]):
+        kind, M, N, nkt, batch = sig[:5]
+        call = make_call(k, sig, dev)
+        res = {}
+        for c, (bm, bn) in CFGS.items():
+            if c == 3 and M < 16384:
+                continue
+            blocks = -(-M // bm) * -(-N // bn) * batch
+            for s in (1, 2, 3, 4, 6, 8, 12, 16):
+                if s > 1 and (nkt // s < 8 or blocks * s > 1536 or blocks >= 512):
+                    continue
+                _hip.set_option("gemm2", 1)
+                _hip.set_option("g2_cfg", c)
+                _hip.set_option("g2_splits", s)
+                res[f"{c}:{s}"] = round(timeit(call), 2)
+        _hip.set_option("gemm2", 0)
+        res["general"] = round(timeit(call), 2)
+        _hip.set_option("gemm2", 1)
+        _hip.set_option("g2_cfg", 0)
+        _hip.set_option("g2_splits", 0)
+        res["auto"] = round(timeit(call), 2)
+        best = min((v, kk) for kk, v in res.items() if ":" in kk)
+        print(json.dumps(dict(kind=kind, M=M, N=N, nkt=nkt, batch=batch, calls=calls, extra=sig[5], best=best[1],
+                              best_us=best[0], us=res)), flush=True)
+        del call
+    _hip.set_option("g2_cfg", 0)
+    _hip.set_option("g2_splits", 0)
+
+
+if __name__ == "__main__":
+    main()
