@@ -310,10 +310,13 @@ class HipKernels:
                                          ldo, scale, dt(q), _stream()), "comat_flash_attn_fwd")
 
     def flash_attn_bwd(self, q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+        # the fp32 partials of the split dK/dV pass live BEHIND the GEMMs' ticket counters (the head of the workspace
+        # must stay zero: include/comat_hip.h, COMAT_WS_COUNTER_BYTES)
         ws = self._workspace(q.device)
         _check(_lib.comat_flash_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(do), _ptr(lse), _ptr(dbuf), _ptr(dq),
                                          _ptr(dk), _ptr(dv), B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale, dt(q),
-                                         ws.data_ptr(), self.WS_BYTES, _stream()), "comat_flash_attn_bwd")
+                                         ws.data_ptr() + WS_COUNTER_BYTES, self.WS_BYTES - WS_COUNTER_BYTES, _stream()),
+               "comat_flash_attn_bwd")
 
     # ---- elementwise ---------------------------------------------------------------------------------------
     def unary(self, op, x, y, n, p0=0.0, p1=0.0):

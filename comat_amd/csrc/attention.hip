@@ -45,6 +45,20 @@ __device__ __forceinline__ void mma(f32x16_t& acc, const f32x4_t& a, const f32x4
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
 }
 
+// combine a per-lane value with the value of the lane 32 away (the other half of the 32x32 accumulator's columns):
+// v_permlane32_swap hands each lane {own, partner} in one VALU instruction (a __shfl_xor(.., 32) goes through LDS)
+__device__ __forceinline__ float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+// exp(x) for x given in log2 units (v_exp_f32 is 2^x: no multiply in front of it)
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // accumulator register i of lane-half hh  <->  row index inside the 32x32 tile
 __device__ __forceinline__ int crow(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
 
@@ -209,7 +223,8 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     for (int t = 0; t < G::NT32; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oT[t][i] = 0.f;
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;  // running max in log2 units (scores are scaled by scale * log2(e)), running sum
+    const float c2 = a.scale * LOG2E;
 
     TileMover<T, DMAX> km, vm;
     const int ntiles = (a.Nk + 31) / 32;
@@ -233,21 +248,21 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
         float mt = -INFINITY;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float v = (t * 32 + crow(i, hh) < a.Nk) ? st[i] * a.scale : -INFINITY;
+            const float v = (t * 32 + crow(i, hh) < a.Nk) ? st[i] * c2 : -INFINITY;
             st[i] = v;
             mt = fmaxf(mt, v);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = half_max(mt);
         const float m_new = fmaxf(m, mt);
-        const float alpha = __expf(m - m_new);
+        const float alpha = exp2_fast(m - m_new);
         float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = __expf(st[i] - m_new);
+            const float p = exp2_fast(st[i] - m_new);
             st[i] = p;
             ps += p;
         }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = half_sum(ps);
         l = l * alpha + ps;
         m = m_new;
 #pragma unroll
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
             }
-        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m + __logf(l);
+        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * LN2 + __logf(l);  // natural-log units
     }
 }
 
@@ -323,8 +338,9 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     F qf[NK], gf[NK];
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
-    const float lse_q = q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
+    const float lse_q = (q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f) * LOG2E;  // log2 units
     const float D_q = q < a.Nq ? a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
+    const float c2 = a.scale * LOG2E;
     f32x16_t dqT[G::NT32];
 #pragma unroll
     for (int t = 0; t < G::NT32; ++t)
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = (t * 32 + crow(i, hh) < a.Nk) ? __expf(st[i] * a.scale - lse_q) : 0.f;
+            const float p = (t * 32 + crow(i, hh) < a.Nk) ? exp2_fast(st[i] * c2 - lse_q) : 0.f;
             st[i] = p * (dp[i] - D_q) * a.scale;
         }
 #pragma unroll
@@ -420,12 +436,13 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     const int per = (ntq + a.qsplit - 1) / a.qsplit;
     const int tbeg = (int)blockIdx.z * per;
     const int ntiles = tbeg + per < ntq ? tbeg + per : ntq;
-    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31
+    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31 (lse in log2 units)
+    const float c2 = a.scale * LOG2E;
     qm.load(Qb, a.ldq, tbeg * 32, a.Nq, a.d);
     gm.load(Gb, a.ldo, tbeg * 32, a.Nq, a.d);
     if (threadIdx.x < 32) {
         const int qi = tbeg * 32 + threadIdx.x;
-        lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
+        lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
         D_r = qi < a.Nq ? D_g[qi] : 0.f;
     }
     qm.store(Qt);
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
             gm.load(Gb, a.ldo, (t + 1) * 32, a.Nq, a.d);
             if (threadIdx.x < 32) {
                 const int qi = (t + 1) * 32 + threadIdx.x;
-                lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
+                lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
                 D_r = qi < a.Nq ? D_g[qi] : 0.f;
             }
         }
@@ -459,7 +476,7 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int qr = crow(i, hh);
             const bool valid = (t * 32 + qr < a.Nq) && (key < a.Nk);
-            const float p = valid ? __expf(sc[i] * a.scale - lse_s[qr]) : 0.f;
+            const float p = valid ? exp2_fast(sc[i] * c2 - lse_s[qr]) : 0.f;
             sc[i] = p;
             dp[i] = p * (dp[i] - D_s[qr]) * a.scale;
         }

@@ -466,10 +466,10 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // ---- plans: block tile and split count per problem ----
 // (1) a table of measured plans for the problems of the SD1.5 / SDXL / BLIP steps (tools/tune_gemm2.py on an MI355X ->
 //     tools/make_gemm2_plans.py -> gemm2_plans.inc), keyed by (conv?, M, N, k-tiles, batch);
-// (2) a rule of thumb for everything else, read off the same measurements: these launches are a single wave of blocks
-//     or less, so the block count matters more than the tile's arithmetic intensity - take the largest tile that still
-//     gives ~one block per CU, else the half-size tile; cut k only when even that leaves most CUs idle AND every slice
-//     keeps >= 24 k-tiles (a slice costs an fp32 slab round trip plus the ticket).
+// (2) a rule of thumb for everything else, read off the same measurements: the 128x128 tile (highest arithmetic
+//     intensity per LDS-DMA byte) with the k-range cut into as many slices as it takes to put about one block on every
+//     CU, each slice >= 8 k-tiles - the in-launch combine (write-through slabs, no fences) is cheap enough that
+//     filling the chip beats a longer serial k-loop on every short-on-tiles problem of this workload.
 struct Plan2Entry {
     int conv;
     int64_t M, N;
@@ -493,23 +493,21 @@ static void plan2(bool conv, int64_t M, int64_t N, int nkt, int64_t batch, int64
         }
     }
     if (c == CFG_AUTO) {
-        const int half = (N % 128 != 0 && N % 128 <= 64) ? CFG_128x64 : CFG_64x128;
         const int64_t b128 = cdiv64(M, 128) * cdiv64(N, 128) * batch;
         if (M >= 32768 && N >= 128) c = CFG_256x128;  // VAE-sized: plenty of tiles, take the biggest
-        else if (b128 >= 224 && !(half == CFG_128x64)) c = CFG_128x128;
-        else if (b128 >= 448) c = CFG_128x128;        // N = 64, 320, 960 ...: no half-empty column tiles unless plenty
-        else c = half;
+        else if (N % 128 != 0 && N % 128 <= 64 && b128 < 448) c = CFG_128x64;  // N = 64, 320, 960: no half-empty tiles
+        else c = CFG_128x128;
     }
     const Cfg2 d = cfg_dims(c);
     const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
     if (slab_bytes <= 0 || ntiles > WS_COUNTERS) s = 1;
     else {
-        if (s == 0) {
+        if (s == 0) {  // about one block per CU, every slice at least 8 k-tiles long
             s = 1;
-            if (ntiles < 112 && nkt >= 48) {
-                s = cdiv64(224, ntiles);
-                if (s > nkt / 24) s = nkt / 24;
+            if (ntiles < 256) {
+                s = cdiv64(256, ntiles);
+                if (s > nkt / 8) s = nkt / 8;
             }
         }
         const int64_t cap = slab_bytes / (ntiles * d.bm * d.bn * 4);

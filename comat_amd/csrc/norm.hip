@@ -481,6 +481,130 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
     }
 }
 
+// ---- vectorised LayerNorm: one wave per row, the row lives in registers (ONE 16-byte read per element group) --------
+// VPL = 16-byte vectors per lane (C <= 64 * VPL * EPV).  Same two-pass formulas as the scalar kernels above.
+template <typename T, int VPL>
+__global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, T* __restrict__ y,
+                                                        float* __restrict__ stats, int64_t M, int C, float eps) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = C / EPV;
+    float v[VPL][EPV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vi = lane + i * 64;
+        GV16 t;
+        t.u = make_uint4(0, 0, 0, 0);
+        if (vi < nvec) t.u = *(const uint4*)(x + row * C + (int64_t)vi * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            v[i][e] = vi < nvec ? gv_get<T>(t, e) : 0.f;
+            s += v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        if (lane + i * 64 < nvec) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            const float4 g0 = *(const float4*)(gamma + vi * EPV), b0 = *(const float4*)(beta + vi * EPV);
+            float gg[8], bb[8];
+            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w;
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w;
+            if (EPV == 8) {
+                const float4 g1 = *(const float4*)(gamma + vi * EPV + 4), b1 = *(const float4*)(beta + vi * EPV + 4);
+                gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+                bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+            }
+            GV16 o;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) gv_set<T>(o, e, (v[i][e] - mean) * rstd * gg[e] + bb[e]);
+            *(uint4*)(y + row * C + (int64_t)vi * EPV) = o.u;
+        }
+    }
+    if (lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+}
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                        T* __restrict__ dx, int64_t M, int C, const T* __restrict__ add) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nvec = C / EPV;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float g[VPL][EPV], xh[VPL][EPV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            GV16 tg, tx;
+            tg.u = *(const uint4*)(dy + row * C + (int64_t)vi * EPV);
+            tx.u = *(const uint4*)(x + row * C + (int64_t)vi * EPV);
+            const float4 g0 = *(const float4*)(gamma + vi * EPV);
+            float gg[8];
+            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w;
+            if (EPV == 8) {
+                const float4 g1 = *(const float4*)(gamma + vi * EPV + 4);
+                gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                g[i][e] = gv_get<T>(tg, e) * gg[e];
+                xh[i][e] = (gv_get<T>(tx, e) - mean) * rstd;
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
+        }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
+            GV16 o, ta;
+            if (add) ta.u = *(const uint4*)(add + row * C + (int64_t)vi * EPV);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float d = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+                if (add) d += gv_get<T>(ta, e);
+                gv_set<T>(o, e, d);
+            }
+            *(uint4*)(dx + row * C + (int64_t)vi * EPV) = o.u;
+        }
+    }
+}
+
+static inline int ln_vpl(int C, int dtype, const void* a, const void* b, const void* c, const void* d) {
+    const int epv = dtype == COMAT_BF16 ? 8 : 4;
+    if (C % epv) return 0;
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) != 0) return 0;
+    const int vpl = (C / epv + 63) / 64;
+    return vpl <= 4 ? vpl : 0;
+}
+
 }  // namespace
 
 extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
@@ -564,6 +688,17 @@ extern "C" int comat_layernorm_fwd(const void* x, const float* gamma, const floa
     COMAT_REQUIRE(dtype_ok(dtype), "comat_layernorm_fwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv64(M, NT / 64));
+    const int vpl = ln_vpl(C, dtype, x, y, gamma, beta);
+#define LN_FWD(T, V) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, V>), grid, dim3(NT), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, C, eps)
+    if (vpl && dtype == COMAT_BF16) {
+        if (vpl == 1) LN_FWD(bf16_t, 1); else if (vpl == 2) LN_FWD(bf16_t, 2); else if (vpl == 3) LN_FWD(bf16_t, 3); else LN_FWD(bf16_t, 4);
+        return comat_check_launch("comat_layernorm_fwd");
+    }
+    if (vpl && dtype == COMAT_F32) {
+        if (vpl == 1) LN_FWD(float, 1); else if (vpl == 2) LN_FWD(float, 2); else if (vpl == 3) LN_FWD(float, 3); else LN_FWD(float, 4);
+        return comat_check_launch("comat_layernorm_fwd");
+    }
+#undef LN_FWD
     if (dtype == COMAT_BF16)
         hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)y,
                            stats, M, C, eps);
@@ -580,6 +715,17 @@ extern "C" int comat_layernorm_bwd(const void* dy, const void* x, const float* g
     COMAT_REQUIRE(dtype_ok(dtype), "comat_layernorm_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv64(M, NT / 64));
+    const int vpl = (!add || ((uintptr_t)add & 15) == 0) ? ln_vpl(C, dtype, dy, x, dx, gamma) : 0;
+#define LN_BWD(T, V) hipLaunchKernelGGL((ln_bwd_vec_kernel<T, V>), grid, dim3(NT), 0, st, (const T*)dy, (const T*)x, gamma, stats, (T*)dx, M, C, (const T*)add)
+    if (vpl && dtype == COMAT_BF16) {
+        if (vpl == 1) LN_BWD(bf16_t, 1); else if (vpl == 2) LN_BWD(bf16_t, 2); else if (vpl == 3) LN_BWD(bf16_t, 3); else LN_BWD(bf16_t, 4);
+        return comat_check_launch("comat_layernorm_bwd");
+    }
+    if (vpl && dtype == COMAT_F32) {
+        if (vpl == 1) LN_BWD(float, 1); else if (vpl == 2) LN_BWD(float, 2); else if (vpl == 3) LN_BWD(float, 3); else LN_BWD(float, 4);
+        return comat_check_launch("comat_layernorm_bwd");
+    }
+#undef LN_BWD
     if (dtype == COMAT_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(NT), 0, st, (const bf16_t*)dy, (const bf16_t*)x, gamma,
                            stats, (bf16_t*)dx, M, C, (const bf16_t*)add);

@@ -43,7 +43,8 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
-    {"norm_fused", "COMAT_NORM_FUSED", 1, 0, false},      // GroupNorm statistics finalised by the last-arriving block
+    {"norm_fused", "COMAT_NORM_FUSED", 0, 0, false},      // GroupNorm statistics finalised by the last-arriving block
+                                                          // (2 launches instead of 3; measured 5 % slower per step)
 };
 }  // namespace
 

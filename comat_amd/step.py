@@ -129,6 +129,8 @@ class CoMatTrainer:
         self.device = torch.device(pipeline.device)
         self._d_stream = None
         self._d_pending = False
+        self._d_keep = None
+        self.serial_d = False  # GraphedStep: D step on the main stream (a forked D stream crashes hipStreamEndCapture)
 
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
@@ -208,14 +210,16 @@ class CoMatTrainer:
         logs = {k: v for k, v in out.items() if k in ("Blip", "G_loss", "token_loss", "pixel_loss")}
         logs["step_loss"] = out["loss"].detach()
         self._last = (out["training_steps"], out["crop"])
-        concurrent = (cfg.gan_loss and self.device.type == "cuda" and ops.side_streams_enabled()
+        concurrent = (cfg.gan_loss and self.device.type == "cuda" and ops.side_streams_enabled() and not self.serial_d
                       and os.environ.get("COMAT_D_STREAM", "1") != "0")
         if concurrent:
             main = torch.cuda.current_stream(self.device)
             if self._d_stream is None:
                 self._d_stream = torch.cuda.Stream(device=self.device)
             self._d_stream.wait_stream(main)  # the G forward (latents, the discriminator's compute copies) is queued
-            out["training_latents"].record_stream(self._d_stream)  # read there: the allocator must not recycle it early
+            # the D stream reads the final latents: they stay referenced until that stream has been joined
+            # (_apply_updates), so the allocator cannot hand their memory to main-stream work in the meantime
+            self._d_keep = out["training_latents"]
             with torch.cuda.stream(self._d_stream):
                 logs["D_loss"] = self._d_step(out, batch)
         out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
@@ -235,6 +239,7 @@ class CoMatTrainer:
         if self._d_pending:
             torch.cuda.current_stream(self.device).wait_stream(self._d_stream)
             self._d_pending = False
+            self._d_keep = None
         if self.cfg.gan_loss:
             self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
         self.reducer.finish()
@@ -270,6 +275,9 @@ class GraphedStep:
         `training_steps` tuple (C2: N = K, a single tuple), captured lazily at its first use after one eager step;
       * no host synchronisation and no host-side data dependence inside the step (asserted by
         tests/test_step.py::test_step_is_enqueue_only).
+    The D step is captured in stream order, not on its own stream: forking it inside the capture crashes
+    hipStreamEndCapture on ROCm 7.2 (profiles/r02_c_*: every other part of the step captures, including the
+    weight-gradient side streams).
     Not captured (the eager path runs instead): attribute-concentration steps (their masks are resized on the host),
     data-parallel runs (the RCCL all-reduce stays outside graphs until it can be tested on a multi-GPU node).
     Results are bit-identical to eager steps (`tests/test_step.py::test_graphed_step_matches_eager`)."""
@@ -330,6 +338,7 @@ class GraphedStep:
             tr.blip.static_tables = st
         key = tuple(training_steps)
         ent = self.graphs.get(key)
+        tr.serial_d = True  # eager pre-step and capture run the D step in stream order (bit-identical either way)
         if ent is None:
             # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
             # tables, workspaces of the default stream) and is a real optimisation step of its own

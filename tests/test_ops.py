@@ -867,3 +867,23 @@ def test_merged_nograd_weights(dev, dtype, G, monkeypatch):
     xg = dv(x, dev, dtype, grad=True)
     y = ops.lora_group_linear(xg, lins, store.groups[0], residual=rd)
     assert y[0].grad_fn is not None
+
+
+@pytest.mark.gpu
+def test_flash_backward_partials_do_not_touch_the_gemm_tickets(hip, default_opts):
+    """Regression (round 2): the fused-attention backward with few keys (cross-attention, 77 text tokens) parks fp32
+    dK / dV partials in the stream's workspace; they must live behind the split-K ticket counters at its head, or every
+    later split-K GEMM on that stream combines garbage.  Run such a backward, then split-K GEMMs of both kernels."""
+    dtype = torch.bfloat16
+    B, Nq, Nk, H, d = 2, 4096, 77, 8, 40
+    q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
+    qd, kd, vd = (dv(t, hip, dtype, grad=True) for t in (q, k_, v))
+    o, _ = ops.attention(qd, kd, vd, B, Nq, Nk, H, d, need_probs=False)
+    o.backward(dv(rnd(B * Nq, H * d, dtype=dtype, seed=4), hip, dtype))
+    k = ops.kernels()
+    A, Bm = rnd(512, 4096, dtype=dtype, seed=5, scale=0.3), rnd(256, 4096, dtype=dtype, seed=6, scale=0.3)
+    for g2, opt in ((1, "g2_splits"), (0, "force_splits")):
+        _set_opts(gemm2=g2, **{opt: 4})
+        out = torch.full((512, 256), float("nan"), dtype=torch.float32, device=hip)
+        k.gemm(dv(A, hip, dtype), dv(Bm, hip, dtype), out, 512, 256, 4096, 4096, 4096, 256)
+        check(out, A @ Bm.t(), dtype, f"split-K GEMM after a split flash backward (gemm2={g2})")
