@@ -348,8 +348,8 @@ def main():
     # whole step is captured once into a hipGraph (comat_amd.step.GraphedStep) and the timed steps are replays with
     # fresh inputs.  COMAT_STEP_GRAPH=0 times eager launches.  Capture happens here, before warm-up and timing.
     stepper, graph_note = None, "eager launches"
-    if (not args.selftest and world == 1 and not scfg.attrcon and os.environ.get("COMAT_STEP_GRAPH", "1") != "0"
-            and "training_steps" in fixed):
+    mode = os.environ.get("COMAT_STEP_GRAPH", "auto")  # auto | 1 (graph) | 0 (eager)
+    if (not args.selftest and world == 1 and not scfg.attrcon and mode != "0" and "training_steps" in fixed):
         from comat_amd.step import GraphedStep
         cand = GraphedStep(trainer)
         try:
@@ -362,6 +362,24 @@ def main():
             graph_note = f"eager launches (graph capture failed: {type(e).__name__})"
             trainer.blip.static_tables = None
             sync()
+        if stepper is not None and mode == "auto":
+            # the graph runs the D step in stream order, eager launches overlap it with the G backward on a second
+            # stream but pay ~10 us of host time per launch: take whichever is faster on this box (3 steps each)
+            def probe(fn):
+                fn()
+                sync()
+                t0 = time.time()
+                for _ in range(3):
+                    fn()
+                sync()
+                return (time.time() - t0) / 3
+            trainer.serial_d = False
+            t_eager = probe(lambda: trainer.train_step(batch, **fixed))
+            t_graph = probe(lambda: stepper(batch, **fixed))
+            if t_eager < t_graph:
+                stepper, graph_note = None, f"eager launches (probe: eager {t_eager * 1e3:.0f} ms < graph {t_graph * 1e3:.0f} ms)"
+            else:
+                graph_note += f" (probe: graph {t_graph * 1e3:.0f} ms <= eager {t_eager * 1e3:.0f} ms)"
 
     def run_step():
         if stepper is not None:

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     for (int t = 0; t < G::NT32; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oT[t][i] = 0.f;
-    float m = -INFINITY, l = 0.f;  // running max in log2 units (scores are scaled by scale * log2(e)), running sum
+    float m = -INFINITY, l = 0.f;  // running max of the RAW scores, running sum of exp(scale * (s - m))
     const float c2 = a.scale * LOG2E;
 
     TileMover<T, DMAX> km, vm;
@@ -245,30 +245,37 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
         for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
         for (int s = 0; s < NK; ++s) mma(st, frag_kc<T, DMAX>(Kt, r, s, hh), qf[s]);
-        float mt = -INFINITY;
+        // online softmax on the RAW scores (c2 = scale * log2 e > 0 keeps their order): 4 VALU ops per score - max,
+        // fma + exp2, sum.  Keys beyond Nk exist only in the last tile (uniform branch).
+        if ((t + 1) * 32 > a.Nk) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float v = (t * 32 + crow(i, hh) < a.Nk) ? st[i] * c2 : -INFINITY;
-            st[i] = v;
-            mt = fmaxf(mt, v);
+            for (int i = 0; i < 16; ++i)
+                if (t * 32 + crow(i, hh) >= a.Nk) st[i] = -INFINITY;
         }
+        float mt = st[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, st[i]);
         mt = half_max(mt);
-        const float m_new = fmaxf(m, mt);
-        const float alpha = exp2_fast(m - m_new);
+        const float m_new = fmaxf(m, mt);  // raw units
+        const float neg = -m_new * c2;
         float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = exp2_fast(st[i] - m_new);
+            const float p = exp2_fast(__builtin_fmaf(st[i], c2, neg));
             st[i] = p;
             ps += p;
         }
         ps = half_sum(ps);
-        l = l * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {  // some query's maximum moved: rescale (rare after the first tiles)
+            const float alpha = exp2_fast((m - m_new) * c2);
+            l *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oT[t2][i] *= alpha;
+        }
+        l += ps;
         m = m_new;
-#pragma unroll
-        for (int t2 = 0; t2 < G::NT32; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oT[t2][i] *= alpha;
 #pragma unroll
         for (int j = 0; j < G::NJ; ++j) {
             const F pb = pack_acc<T>(st, j);
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
             }
-        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * LN2 + __logf(l);  // natural-log units
+        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * a.scale + __logf(l);  // natural-log units
     }
 }
 
@@ -370,8 +377,13 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float p = (t * 32 + crow(i, hh) < a.Nk) ? exp2_fast(st[i] * c2 - lse_q) : 0.f;
-            st[i] = p * (dp[i] - D_q) * a.scale;
+            const float p = exp2_fast(__builtin_fmaf(st[i], c2, -lse_q));
+            st[i] = p * a.scale * (dp[i] - D_q);
+        }
+        if ((t + 1) * 32 > a.Nk) {  // keys beyond Nk exist only in the last tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (t * 32 + crow(i, hh) >= a.Nk) st[i] = 0.f;
         }
 #pragma unroll
         for (int j = 0; j < G::NJ; ++j) {
@@ -472,13 +484,14 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
             mma(sc, frag_kc<T, DMAX>(Qt, r, s, hh), kf[s]);
             mma(dp, frag_kc<T, DMAX>(Gt, r, s, hh), vf[s]);
         }
+        const bool edge = (t + 1) * 32 > a.Nq || key >= a.Nk;  // rows beyond Nq: last tile only; keys beyond Nk: last block
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qr = crow(i, hh);
-            const bool valid = (t * 32 + qr < a.Nq) && (key < a.Nk);
-            const float p = valid ? exp2_fast(sc[i] * c2 - lse_s[qr]) : 0.f;
+            float p = exp2_fast(__builtin_fmaf(sc[i], c2, -lse_s[qr]));
+            if (edge && !((t * 32 + qr < a.Nq) && (key < a.Nk))) p = 0.f;
             sc[i] = p;
-            dp[i] = p * (dp[i] - D_s[qr]) * a.scale;
+            dp[i] = p * a.scale * (dp[i] - D_s[qr]);
         }
 #pragma unroll
         for (int j = 0; j < G::NJ; ++j) {

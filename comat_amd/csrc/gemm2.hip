@@ -466,10 +466,10 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // ---- plans: block tile and split count per problem ----
 // (1) a table of measured plans for the problems of the SD1.5 / SDXL / BLIP steps (tools/tune_gemm2.py on an MI355X ->
 //     tools/make_gemm2_plans.py -> gemm2_plans.inc), keyed by (conv?, M, N, k-tiles, batch);
-// (2) a rule of thumb for everything else, read off the same measurements: the 128x128 tile (highest arithmetic
-//     intensity per LDS-DMA byte) with the k-range cut into as many slices as it takes to put about one block on every
-//     CU, each slice >= 8 k-tiles - the in-launch combine (write-through slabs, no fences) is cheap enough that
-//     filling the chip beats a longer serial k-loop on every short-on-tiles problem of this workload.
+// (2) a rule of thumb for everything else, fitted to the same measurements (profiles/r02_d_g2_tune.jsonl: 73.7 ms for
+//     the step's 3535 launches against 65.3 ms with the table and 154 ms with the general kernel): the largest tile
+//     that still yields >= 192 (128x128) / >= 128 (half tile) blocks, else 64x64; then cut k until ~1.5 blocks per CU,
+//     every slice >= 24 k-tiles (a slice costs an fp32 slab round trip and a ticket).
 struct Plan2Entry {
     int conv;
     int64_t M, N;
@@ -493,21 +493,25 @@ static void plan2(bool conv, int64_t M, int64_t N, int nkt, int64_t batch, int64
         }
     }
     if (c == CFG_AUTO) {
+        const int half = (N % 128 != 0 && N % 128 <= 64) ? CFG_128x64 : CFG_64x128;  // N = 64, 320, 960: no half-empty tiles
         const int64_t b128 = cdiv64(M, 128) * cdiv64(N, 128) * batch;
+        const Cfg2 hd = cfg_dims(half);
+        const int64_t bhalf = cdiv64(M, hd.bm) * cdiv64(N, hd.bn) * batch;
         if (M >= 32768 && N >= 128) c = CFG_256x128;  // VAE-sized: plenty of tiles, take the biggest
-        else if (N % 128 != 0 && N % 128 <= 64 && b128 < 448) c = CFG_128x64;  // N = 64, 320, 960: no half-empty tiles
-        else c = CFG_128x128;
+        else if (b128 >= 192) c = CFG_128x128;
+        else if (bhalf >= 128) c = half;
+        else c = CFG_64x64;
     }
     const Cfg2 d = cfg_dims(c);
     const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
     if (slab_bytes <= 0 || ntiles > WS_COUNTERS) s = 1;
     else {
-        if (s == 0) {  // about one block per CU, every slice at least 8 k-tiles long
+        if (s == 0) {  // about 1.5 blocks per CU, every slice at least 24 k-tiles long
             s = 1;
-            if (ntiles < 256) {
-                s = cdiv64(256, ntiles);
-                if (s > nkt / 8) s = nkt / 8;
+            if (ntiles < 384) {
+                s = cdiv64(384, ntiles);
+                if (s > nkt / 24) s = nkt / 24;
             }
         }
         const int64_t cap = slab_bytes / (ntiles * d.bm * d.bn * 4);

@@ -307,14 +307,13 @@ class GraphedStep:
             self.static["noises"] = [torch.empty_like(n, device=dev) for n in batch["noises"]]
             self.static_key = key
             self.graphs = {}
-        for k, v in self.static.items():
-            if k == "noises":
-                for dst, src in zip(v, batch["noises"]):
-                    dst.copy_(src, non_blocking=True)
-            else:
-                v.copy_(batch[k], non_blocking=True)
-        for k in batch:  # host-side metadata passes through untouched
-            if k not in self.static:
+        for k in self.BATCH_KEYS:
+            if k in batch:
+                self.static[k].copy_(batch[k], non_blocking=True)
+        for dst, src in zip(self.static["noises"], batch["noises"]):
+            dst.copy_(src, non_blocking=True)
+        for k in batch:  # host-side metadata (masks, token lists, time ids) passes through untouched
+            if k not in self.BATCH_KEYS and k != "noises":
                 self.static[k] = batch[k]
         return self.static
 

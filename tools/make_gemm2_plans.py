@@ -1,0 +1,34 @@
+"""tools/tune_gemm2.py output (JSON lines) -> comat_amd/csrc/gemm2_plans.inc (the static plan table of gemm2.hip).
+    python tools/make_gemm2_plans.py gpurun_out/g2_tune.jsonl [more.jsonl ...]
+Per problem the fastest measured (tile, splits); among variants within 3 % of the fastest the one with the fewest slices
+(less slab traffic, least sensitivity to what else runs on the chip)."""
+import json
+import sys
+
+rows = {}
+for path in sys.argv[1:]:
+    for line in open(path):
+        if not line.startswith("{"):
+            continue
+        r = json.loads(line)
+        key = (1 if r["kind"] == "conv" else 0, r["M"], r["N"], r["nkt"], r["batch"])
+        var = {k: v for k, v in r["us"].items() if ":" in k}
+        best = min(var.values())
+        ok = [(int(k.split(":")[1]), v, k) for k, v in var.items() if v <= best * 1.03]
+        s, us, k = min(ok)
+        cfg = int(k.split(":")[0])
+        old = rows.get(key)
+        if old is None or r["calls"] > old[3]:
+            rows[key] = (cfg, s, us, r["calls"], r["us"].get("general", 0.0))
+out = ["// gemm2_plans.inc - measured plans of the pipelined GEMM / conv kernel for the problems of the SD1.5 (C2) step:",
+       "// tools/tune_gemm2.py on an MI355X -> tools/make_gemm2_plans.py.  {conv, M, N, k-tiles, batch, tile code, slices}",
+       "// tile codes: 1 128x128, 2 128x64, 3 256x128, 4 64x128, 6 64x64.  Trailing comment: us per launch with this plan,",
+       "// with the general 64x64 kernel, calls per step.",
+       "static const Plan2Entry g2_plans[] = {"]
+for key in sorted(rows, key=lambda k: (-rows[k][3] * rows[k][2])):
+    cfg, s, us, calls, gen = rows[key]
+    out.append(f"    {{{key[0]}, {key[1]}, {key[2]}, {key[3]}, {key[4]}, {cfg}, {s}}},  // {us:.1f} us (general {gen:.1f}), {calls} calls")
+out.append("};")
+open("comat_amd/csrc/gemm2_plans.inc", "w").write("\n".join(out) + "\n")
+print(f"{len(rows)} plans; step total {sum(v[2] * v[3] for v in rows.values()) / 1e3:.1f} ms "
+      f"(general kernel {sum(v[4] * v[3] for v in rows.values()) / 1e3:.1f} ms)")
