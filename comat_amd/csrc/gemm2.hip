@@ -425,7 +425,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6 };
+enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
+       CFG_128x128_W8 = 7 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -436,6 +437,7 @@ static Cfg2 cfg_dims(int c) {
         case CFG_256x128: return {256, 128, 512};
         case CFG_64x128: return {64, 128, 256};
         case CFG_64x64: return {64, 64, 256};
+        case CFG_128x128_W8: return {128, 128, 512};
         default: return {128, 128, 256};
     }
 }
@@ -449,6 +451,8 @@ template <bool CONV> static void launch_cfg(int c, const Args2& a, unsigned bloc
         case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
         case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
         case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
+            hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }

@@ -21,7 +21,7 @@ os.environ["COMAT_STEP_GRAPH"] = "0"
 import bench  # noqa: E402
 from comat_amd import _hip, ops  # noqa: E402
 
-CFGS = {1: (128, 128), 2: (128, 64), 3: (256, 128), 4: (64, 128), 6: (64, 64)}
+CFGS = {1: (128, 128), 2: (128, 64), 3: (256, 128), 4: (64, 128), 6: (64, 64), 7: (128, 128)}
 
 
 class Recorder:
