@@ -149,6 +149,78 @@ __device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m,
     }
 }
 
+// split-K combine (inside the launch) + fused epilogue of one block tile; shared by the k-contiguous and the k-major kernel
+template <int TM, int TN, int WTM, int WTN, int NTH>
+__device__ __forceinline__ void g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
+                                          int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
+    // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
+    if (g.splits > 1) {
+        constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
+        const SlabIO io(g.ws + WS_COUNTERS);
+        const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    io.store(mine + (int64_t)((a * TN + b) * 4 + q) * NTH * 16, v);
+                }
+        if (!splitk_ticket_is_last((unsigned*)g.ws + tile, g.splits, (unsigned*)smem)) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        for (int s2 = 0; s2 < g.splits; ++s2) {
+            const int64_t src = (((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid) * 16;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4_t v = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
+                        acc[a][b][4 * q] += v[0];
+                        acc[a][b][4 * q + 1] += v[1];
+                        acc[a][b][4 * q + 2] += v[2];
+                        acc[a][b][4 * q + 3] += v[3];
+                    }
+        }
+    }
+
+    // ---- epilogue.  acc[a][b][i]: output row m = lane & 31 of the (a)-th 32-row tile, column (i & 3) + 8 (i >> 2) + 4 h
+    // of the (b)-th 32-column tile.  Half-swapping quad 0 <-> 1 and 2 <-> 3 gives lane h = 0 columns 0..7 and 16..23,
+    // lane h = 1 columns 8..15 and 24..31 ----
+    Epi ep = g.ep;
+    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
+    if (ep.bias) ep.bias += z * g.sBias;
+    const bool vec = g.vec != 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int64_t m = m0 + wr * WTM + a * 32 + r;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half_swap(v[j], v[4 + j]);
+                half_swap(v[8 + j], v[12 + j]);
+            }
+            const int64_t nb = n0 + wc * WTN + b * 32 + 8 * h;
+            if (m < g.M) {
+                if (nb < g.N) epilogue_run(ep, v, m, nb, g.N, vec);
+                if (nb + 16 < g.N) epilogue_run(ep, v + 8, m, nb + 16, g.N, vec);
+            }
+        }
+    }
+}
+
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles; NST-deep LDS ring.
 // CONV: implicit-GEMM gather.
 template <int BM, int BN, int WM, int WN, int NST, bool CONV>
@@ -354,72 +426,153 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
         mmas(xf1, wf1);
     }
 
-    // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
-    if (g.splits > 1) {
-        constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
-        const SlabIO io(g.ws + WS_COUNTERS);
-        const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
+    g2_finish<TM, TN, WTM, WTN, NTH>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k-major operands: C[M, N] (+)= A^T B with A stored [K, M] and B stored [K, N] (rows = k).  This is every LoRA weight
+// gradient of the step: dU = g^T h and dD = u^T x contract over the TOKEN axis of two row-major token matrices
+// (training_utils/pipeline.py:94-115 leaves them to autograd's addmm).  The general kernel gathers such fragments
+// with eight 2-byte LDS reads each; here the k-tile is DMA'd as it lies in memory ([32 k-rows][128 columns], 256-byte
+// rows) and the MFMA fragments come out of LDS through the hardware transpose read ds_read_b64_tr_b16.
+// Its semantics, probed on gfx950 (tools/probes/tr_read_probe.hip, profiles/r02_e_tr_probe.txt): inside every group
+// of 16 lanes, lane 4k + q supplies the address of 4 consecutive 16-bit elements = columns 4q .. 4q+3 of row k of a
+// 4 x 16 matrix, and lane i receives column i (rows 0 .. 3).  With "row" = k and "column" = the operand's row index,
+// two reads hand lane (r, h) its 8 consecutive k of operand row r.
+// Bank layout: 16-byte slot p of k-row kk is stored at slot p ^ (4 * (kk & 3)) (source-side swizzle of the DMA, same
+// XOR on the read): the 8 x 32-byte pieces that one 32-lane pass of the read touches then cover all 64 banks once.
+// One tile shape (128 x 128, 4 waves, 4-deep ring); few output tiles and K = thousands of tokens, so the launch is
+// always split along k and combined in-launch (g2_finish).
+// ---------------------------------------------------------------------------------------------------------------
+struct TTFrag {
+    unsigned long long lo, hi;
+};
+
+template <int NST> __global__ __launch_bounds__(256) void gemm2_tt_kernel(Args2 g) {
+    constexpr int BM = 128, BN = 128, NW = 4, NTH = 256, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int RBT = 256;                    // bytes per k-row of an operand image (128 columns)
+    constexpr int OPB = BK * RBT;               // 8 KiB per operand per stage
+    constexpr int SS = 2 * OPB;
+    constexpr int IO = BK / (4 * NW);           // DMA instructions per wave per operand per k-tile (4 k-rows each)
+    constexpr int L = 2 * IO;
+    static_assert(IO == 2 && (NST - 3) * L <= 63, "k-major tile geometry");
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    unsigned lin = (unsigned)xcd_chunk_map(blockIdx.x, gridDim.x);
+    const int sp = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.splits));
+    lin /= (unsigned)g.splits;
+    const int64_t tile = __builtin_amdgcn_readfirstlane((int)lin);
+    const int tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
+    lin /= (unsigned)g.tiles_n;
+    const int tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
+    const int64_t z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int per = (g.nkt + g.splits - 1) / g.splits;
+    int kt0 = sp * per;
+    if (kt0 > g.nkt) kt0 = g.nkt;
+    const int kt1 = kt0 + per < g.nkt ? kt0 + per : g.nkt;
+    const int nt = __builtin_amdgcn_readfirstlane(kt1 - kt0);
+
+    // DMA source: lane -> k-row kr = lane / 16 of the instruction's 4 rows, 16-byte slot p = lane % 16 of the 256-byte
+    // row, fetching source chunk p ^ (4 kr).  Columns beyond the operand are clamped (their outputs are never stored).
+    const Seg2 sg = g.seg[0];
+    const int kr = lane >> 4, chunk = (lane & 15) ^ (4 * kr);
+    int64_t ca = m0 + chunk * 8, cb = n0 + chunk * 8;
+    if (ca > g.M - 8) ca = g.M - 8;
+    if (cb > g.N - 8) cb = g.N - 8;
+    const bf16_t* pa[IO];
+    const bf16_t* pb[IO];
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+    for (int i = 0; i < IO; ++i) {
+        const int64_t krow = (int64_t)kt0 * BK + (i * NW + wave) * 4 + kr;
+        pa[i] = sg.A + z * sg.sA + krow * sg.lda + ca;
+        pb[i] = sg.B + z * sg.sB + krow * sg.ldb + cb;
+    }
+    const int64_t stepa = (int64_t)BK * sg.lda, stepb = (int64_t)BK * sg.ldb;
+    auto issue = [&](int st) {
+        char* sbase = smem + st * SS + wave * 1024;
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+        for (int i = 0; i < IO; ++i) {
+            dma16(pa[i], sbase + i * NW * 1024);
+            pa[i] += stepa;
+        }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                    io.store(mine + (int64_t)((a * TN + b) * 4 + q) * NTH * 16, v);
-                }
-        if (!splitk_ticket_is_last((unsigned*)g.ws + tile, g.splits, (unsigned*)smem)) return;
+        for (int i = 0; i < IO; ++i) {
+            dma16(pb[i], sbase + OPB + i * NW * 1024);
+            pb[i] += stepb;
+        }
+    };
+
+    f32x16_t acc[TM][TN];
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-        for (int s2 = 0; s2 < g.splits; ++s2) {
-            const int64_t src = (((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid) * 16;
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    // transpose-read addressing.  16-lane group gq = lane >> 4: columns 16 (gq & 1) .. + 16 of the 32-row MFMA tile,
+    // k half 8 (gq >> 1); inside the group lane 4 kq + q points at row k0 + kq, columns 4 q .. 4 q + 3.  Byte offset in
+    // the row: (column * 2) ^ (64 * kq) (the slot swizzle; tile bases are multiples of 64 bytes, kq = row & 3).
+    const int kq = (lane & 15) >> 2;
+    const int colb = ((wr * WTM + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const int colb_b = ((wc * WTN + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned rowoff = (unsigned)((8 * h + kq) * RBT);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned fa[TM], fb[TN];  // byte offsets of the (k-step 0, first read) fragment piece of each MFMA tile
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fa[a] = rowoff + (unsigned)((colb + a * 64) ^ (64 * kq));
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[b] = (unsigned)OPB + rowoff + (unsigned)((colb_b + b * 64) ^ (64 * kq));
+
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u)
+        if (u < nt) issue(u);
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        wait_tiles<L, NST - 2>(nt - 1 - t);
+        __builtin_amdgcn_s_barrier();  // tile t landed everywhere; every wave is done reading tile t-1
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);
+        const unsigned sb = smem_base + (unsigned)(stage * SS);
+        // all 16 transpose reads of the k-tile (2 k-steps x (2 + 2) fragments x 2 reads) in one statement: the compiler
+        // does not track asm loads, so the wait sits in the same statement (cdna_hip_programming.md 5.7, form i)
+        TTFrag xa[2][TM], xb[2][TN];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %8, %16 offset:4096\n\tds_read_b64_tr_b16 %9, %16 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %10, %17 offset:4096\n\tds_read_b64_tr_b16 %11, %17 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %12, %18 offset:4096\n\tds_read_b64_tr_b16 %13, %18 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %14, %19 offset:4096\n\tds_read_b64_tr_b16 %15, %19 offset:5120\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(xa[0][0].lo), "=&v"(xa[0][0].hi), "=&v"(xa[0][1].lo), "=&v"(xa[0][1].hi), "=&v"(xb[0][0].lo),
+              "=&v"(xb[0][0].hi), "=&v"(xb[0][1].lo), "=&v"(xb[0][1].hi), "=&v"(xa[1][0].lo), "=&v"(xa[1][0].hi),
+              "=&v"(xa[1][1].lo), "=&v"(xa[1][1].hi), "=&v"(xb[1][0].lo), "=&v"(xb[1][0].hi), "=&v"(xb[1][1].lo),
+              "=&v"(xb[1][1].hi)
+            : "v"(sb + fa[0]), "v"(sb + fa[1]), "v"(sb + fb[0]), "v"(sb + fb[1])
+            : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4_t v = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
-                        acc[a][b][4 * q] += v[0];
-                        acc[a][b][4 * q + 1] += v[1];
-                        acc[a][b][4 * q + 2] += v[2];
-                        acc[a][b][4 * q + 3] += v[3];
-                    }
-        }
+                for (int b = 0; b < TN; ++b) {
+                    short8_t xf, wf;
+                    __builtin_memcpy(&xf, &xa[s2][a], 16);
+                    __builtin_memcpy(&wf, &xb[s2][b], 16);
+                    mma_t(acc[a][b], wf, xf);
+                }
+        stage = stage + 1 == NST ? 0 : stage + 1;
     }
-
-    // ---- epilogue.  acc[a][b][i]: output row m = lane & 31 of the (a)-th 32-row tile, column (i & 3) + 8 (i >> 2) + 4 h
-    // of the (b)-th 32-column tile.  Half-swapping quad 0 <-> 1 and 2 <-> 3 gives lane h = 0 columns 0..7 and 16..23,
-    // lane h = 1 columns 8..15 and 24..31 ----
-    Epi ep = g.ep;
-    ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
-    if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
-    if (ep.bias) ep.bias += z * g.sBias;
-    const bool vec = g.vec != 0;
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int64_t m = m0 + wr * WTM + a * 32 + r;
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half_swap(v[j], v[4 + j]);
-                half_swap(v[8 + j], v[12 + j]);
-            }
-            const int64_t nb = n0 + wc * WTN + b * 32 + 8 * h;
-            if (m < g.M) {
-                if (nb < g.N) epilogue_run(ep, v, m, nb, g.N, vec);
-                if (nb + 16 < g.N) epilogue_run(ep, v + 8, m, nb + 16, g.N, vec);
-            }
-        }
-    }
+    g2_finish<TM, TN, WTM, WTN, NTH>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -470,7 +623,7 @@ static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // ---- plans: block tile and split count per problem ----
 // (1) a table of measured plans for the problems of the SD1.5 / SDXL / BLIP steps (tools/tune_gemm2.py on an MI355X ->
 //     tools/make_gemm2_plans.py -> gemm2_plans.inc), keyed by (conv?, M, N, k-tiles, batch);
-// (2) a rule of thumb for everything else, fitted to the same measurements (profiles/r02_d_g2_tune.jsonl: 73.7 ms for
+// (2) a rule of thumb for everything else, fitted to the same measurements (profiles/r02_e_g2_tune.jsonl: 73.7 ms for
 //     the step's 3535 launches against 65.3 ms with the table and 154 ms with the general kernel): the largest tile
 //     that still yields >= 192 (128x128) / >= 128 (half tile) blocks, else 64x64; then cut k until ~1.5 blocks per CU,
 //     every slice >= 24 k-tiles (a slice costs an fp32 slab round trip and a ticket).
@@ -566,8 +719,45 @@ static int finish_launch(Args2& a, bool conv, int64_t batch, void* ws, int64_t w
 
 }  // namespace
 
+// k-major x k-major (LoRA weight gradients): C[M, N] = A^T B, A stored [K, M], B stored [K, N]
+static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
+    if (p->K % BK || p->lda % 8 || p->ldb % 8 || !al16(p->A) || !al16(p->B) || p->M % 8 || p->N % 8) return 0;
+    if (p->batch1 > 1 && (p->sA1 % 8 || p->sB1 % 8)) return 0;
+    if (p->K < 256 || p->M >= (1ll << 31) || p->N >= (1ll << 31) || !p->ws) return 0;
+    Args2 a = {};
+    a.seg[0].A = (const bf16_t*)p->A; a.seg[0].B = (const bf16_t*)p->B;
+    a.seg[0].lda = p->lda; a.seg[0].ldb = p->ldb; a.seg[0].sA = p->sA1; a.seg[0].sB = p->sB1;
+    a.seg[0].nkt = (int)(p->K / BK);
+    a.nseg = 1;
+    a.nkt = a.seg[0].nkt;
+    a.M = p->M; a.N = p->N;
+    a.sC = p->sC1; a.sR = p->sR1; a.sBias = 0;
+    fill_epi(a, p);
+    a.tiles_m = (int)cdiv64(a.M, 128);
+    a.tiles_n = (int)cdiv64(a.N, 128);
+    a.ntiles = (int64_t)a.tiles_m * a.tiles_n * p->batch1;
+    // a handful of output tiles, thousands of tokens to contract: ~one block per CU, every slice >= 8 k-tiles
+    int fc = 0, fs = 0;
+    g2_overrides(&fc, &fs);
+    int64_t s = fs > 0 ? fs : cdiv64(256, a.ntiles);
+    if (s > a.nkt / 8) s = a.nkt / 8;
+    const int64_t slab_bytes = p->ws_bytes - COMAT_WS_COUNTER_BYTES;
+    if (slab_bytes <= 0 || a.ntiles > WS_COUNTERS) s = 1;
+    else if (s > slab_bytes / (a.ntiles * 128 * 128 * 4)) s = slab_bytes / (a.ntiles * 128 * 128 * 4);
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    s = cdiv64(a.nkt, cdiv64(a.nkt, s));
+    a.splits = (int)s;
+    a.ws = (float*)p->ws;
+    a.vec = epi_vec_ok(a.ep, a.N, a.sC, a.sR, a.sBias, a.M);
+    hipLaunchKernelGGL((gemm2_tt_kernel<4>), dim3((unsigned)(a.ntiles * s)), dim3(256), 0, (hipStream_t)stream, a);
+    return 1;
+}
+
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
-    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->transA || p->transB || p->batch2 != 1) return 0;
+    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->batch2 != 1) return 0;
+    if (p->transA && p->transB) return comat_option(COMAT_OPT_GEMM2_TT) ? try_gemm_tt(p, stream) : 0;
+    if (p->transA || p->transB) return 0;
     if (p->K % BK || p->lda % 8 || p->ldb % 8 || !al16(p->A) || !al16(p->B)) return 0;
     if (p->batch1 > 1 && (p->sA1 % 8 || p->sB1 % 8)) return 0;
     if (p->M < 48 || p->M >= (1ll << 31) || p->N >= (1ll << 31)) return 0;  // skinny problems: the 64x64 kernel + split-K

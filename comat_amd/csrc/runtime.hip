@@ -45,6 +45,8 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
     {"norm_fused", "COMAT_NORM_FUSED", 0, 0, false},      // GroupNorm statistics finalised by the last-arriving block
                                                           // (2 launches instead of 3; measured 5 % slower per step)
+    {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
+                                                          // kernel with hardware transpose reads
 };
 }  // namespace
 

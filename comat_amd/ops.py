@@ -159,7 +159,7 @@ class LoRAGroup:
         self.rank, self.scale, self.size = rank, scale, len(ups)
 
     def compute_copies(self):
-        """(down_cat [G*r, in], [up_i [out_i, r]], down_cat^T [in, G*r]) in the compute dtype."""
+        """(down_cat [G*r, in], [up_i [out_i, r]], down_cat^T [in, G*r], [up_i^T [r, out_i]]) in the compute dtype."""
         self.store.ensure_compute_copy()
         return self.store.group_views[self.index]
 
@@ -179,7 +179,7 @@ class LoRAStore:
         for members in spec:
             r, cin = members[0][2].shape
             assert all(tuple(m[2].shape) == (r, cin) and m[3].shape[1] == r for m in members)
-            g = dict(down_off=off, rank=r, cin=cin, n=len(members), t_off=toff, ups=[])
+            g = dict(down_off=off, rank=r, cin=cin, n=len(members), t_off=toff, ups=[], ut_offs=[])
             for dn, _, d, _ in members:
                 self.names.append(dn)
                 shapes.append((off, tuple(d.shape)))
@@ -190,6 +190,9 @@ class LoRAStore:
                 g["ups"].append((off, tuple(u.shape)))
                 off += u.shape[0] * r
             toff += len(members) * r * cin
+            for _, _, _, u in members:  # transposed up factors U^T [r, out] follow the group's transposed down block
+                g["ut_offs"].append(toff)
+                toff += u.shape[0] * r
             layout.append(g)
         total = off
         src = {}
@@ -221,11 +224,16 @@ class LoRAStore:
             self._leaves += [dcat] + ups
             self.groups.append(LoRAGroup(self, gi, dcat, ups, r, scale))
             cv = lambda o, shp: comp[o:o + shp[0] * shp[1]].view(shp)
+            uts = [self.flat_t[to:to + shp[0] * shp[1]].view(shp[1], shp[0]) for to, (_, shp) in zip(g["ut_offs"], g["ups"])]
             self.group_views.append((cv(g["down_off"], (n * r, cin)), [cv(o, shp) for o, shp in g["ups"]],
-                                     self.flat_t[g["t_off"]:g["t_off"] + n * r * cin].view(cin, n * r)))
+                                     self.flat_t[g["t_off"]:g["t_off"] + n * r * cin].view(cin, n * r), uts))
             for r0 in range(0, n * r, 32):
                 for c0 in range(0, cin, 32):
                     tiles.append((g["down_off"], g["t_off"], n * r, cin, r0, c0))
+            for to, (o, shp) in zip(g["ut_offs"], g["ups"]):
+                for r0 in range(0, shp[0], 32):
+                    for c0 in range(0, shp[1], 32):
+                        tiles.append((o, to, shp[0], shp[1], r0, c0))
         self._tiles = torch.tensor(tiles, dtype=torch.int64).to(device)
 
     def ensure_compute_copy(self):
@@ -264,7 +272,7 @@ class LoRAStore:
 
     def _merge_into(self, ent):
         grp, lins, wm = ent["grp"], ent["lins"], ent["wm"]
-        _, ucs, dct = self.group_views[grp.index]
+        _, ucs, dct, _ = self.group_views[grp.index]
         G, r = grp.size, grp.rank
         Gr = G * r
         k = kernels()
@@ -568,7 +576,7 @@ class _LoRAGroupLinear(Function):
         M, Kd = x.shape
         G, r = grp.size, grp.rank
         Gr = G * r
-        dc, ucs, dct = grp.compute_copies()
+        dc, ucs, dct, uts = grp.compute_copies()
         k = kernels()
         h = x.new_empty((M, Gr))
         k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
@@ -591,7 +599,7 @@ class _LoRAGroupLinear(Function):
                 k.gemm_segments([(x, lin.w, Kd, Kd, Kd), (h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r)], y, M, N, N,
                                 bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
                 ys.append(y)
-        ctx.save_for_backward(x, h, dct, *ucs)
+        ctx.save_for_backward(x, h, dct, *uts)
         ctx.grp, ctx.lins = grp, lins
         ctx.has_res = residual is not None
         assert down_cat.grad is not None and all(u.grad is not None for u in ups), \
@@ -600,7 +608,7 @@ class _LoRAGroupLinear(Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        x, h, dct, *ucs = ctx.saved_tensors
+        x, h, dct, *uts = ctx.saved_tensors
         grp, lins = ctx.grp, ctx.lins
         M, Kd = x.shape
         G, r = grp.size, grp.rank
@@ -611,16 +619,18 @@ class _LoRAGroupLinear(Function):
         N0 = lins[0].out_features
         # when the incoming gradients sit at a constant spacing in one buffer (dQ/dK/dV of the fused attention
         # backward) and so do the up factors, the G per-projection GEMMs below are ONE batched launch each
-        sg, su = _uniform_stride(gs), _uniform_stride(ucs)
+        # u_i = s * g_i U_i through the transposed copies U_i^T [r, N] (refreshed with the other compute copies once per
+        # optimizer step): both operands k-contiguous, i.e. the pipelined kernel instead of a k-major gather
+        sg, su = _uniform_stride(gs), _uniform_stride(uts)
         sgu = _uniform_stride([grp.ups[i].grad for i in range(G)])
         batched = sg is not None and su is not None and sgu is not None
         if batched:  # u[:, i*r:(i+1)*r] = s * g_i U_i for all i
-            k.gemm(gs[0], ucs[0], u, M, r, N0, N0, r, Gr, transB=True, alpha=grp.scale, batch=(G, 1), sA=(sg, 0),
-                   sB=(su, 0), sC=(r, 0))
+            k.gemm(gs[0], uts[0], u, M, r, N0, N0, N0, Gr, alpha=grp.scale, batch=(G, 1), sA=(sg, 0), sB=(su, 0),
+                   sC=(r, 0))
         else:
-            for i, lin in enumerate(lins):  # u_i = s * g_i U_i   (U_i stored [N(k), r(n)] -> k-major B operand)
+            for i, lin in enumerate(lins):
                 N = lin.out_features
-                k.gemm(gs[i], ucs[i], u[:, i * r:(i + 1) * r], M, r, N, N, r, Gr, transB=True, alpha=grp.scale)
+                k.gemm(gs[i], uts[i], u[:, i * r:(i + 1) * r], M, r, N, N, N, Gr, alpha=grp.scale)
         want_down = ctx.needs_input_grad[4]
         want_ups = ctx.needs_input_grad[5:]
 

@@ -341,10 +341,11 @@ class GraphedStep:
         if ent is None:
             # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
             # tables, workspaces of the default stream) and is a real optimisation step of its own
+            if tr.blip.static_tables is not None:
+                tr.blip.static_tables.load(real_tab)  # the installed fixed-address tables serve the eager step too
             logs = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
             if tr.blip.static_tables is None:
                 tr.blip.static_tables = real_tab.static_copy()
-            tr.blip.static_tables.load(real_tab)
             tr.bank.mark_updated()
             if tr.D is not None:
                 tr.D.bank.mark_updated()

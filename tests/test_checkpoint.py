@@ -38,8 +38,9 @@ def test_lora_wire_format_round_trip(dev, tmp_path):
     other.ensure_compute_copy()
     assert torch.equal(other.flat_c.cpu(), bank.flat.to(torch.bfloat16).cpu())
     g = other.groups[0]
-    dc, ucs, dct = g.compute_copies()
+    dc, ucs, dct, uts = g.compute_copies()
     assert torch.equal(dct.cpu(), dc.t().cpu())
+    assert all(torch.equal(ut.cpu(), uc.t().cpu()) for ut, uc in zip(uts, ucs))
 
 
 def test_checkpoint_with_discriminator(dev, tmp_path):

@@ -605,7 +605,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=1)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=0)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -887,3 +887,28 @@ def test_flash_backward_partials_do_not_touch_the_gemm_tickets(hip, default_opts
         out = torch.full((512, 256), float("nan"), dtype=torch.float32, device=hip)
         k.gemm(dv(A, hip, dtype), dv(Bm, hip, dtype), out, 512, 256, 4096, 4096, 4096, 256)
         check(out, A @ Bm.t(), dtype, f"split-K GEMM after a split flash backward (gemm2={g2})")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("splits", [0, 1, 5])
+def test_gemm2_k_major_operands(hip, splits, default_opts):
+    """C (+)= A^T B with both operands stored k-major (the LoRA weight gradients dU = g^T h, dD = u^T x: contraction over
+    the token axis) on the pipelined kernel: DMA of the [k][column] tiles + hardware transpose reads.  Ragged column counts
+    (multiples of 8), in-place fp32 accumulation, a batched launch, against an fp32 reference and the general kernel."""
+    dtype = torch.bfloat16
+    k = ops.kernels()
+    for (M, N, K_, nb) in ((320, 128, 8192, 1), (384, 320, 8192, 1), (1280, 128, 512, 3), (128, 640, 2048, 1), (200, 136, 1024, 1),
+                           (8, 8, 256, 1)):
+        A = rnd(nb, K_, M, dtype=dtype, seed=1, scale=0.3)
+        B = rnd(nb, K_, N, dtype=dtype, seed=2, scale=0.3)
+        C0 = rnd(nb, M, N, seed=3)
+        ref = torch.einsum("bkm,bkn->bmn", A, B) + C0
+        outs = []
+        for tt in (1, 0):
+            _set_opts(gemm2=1, gemm2_tt=tt, g2_splits=splits, force_splits=splits)
+            out = dv(C0, hip)
+            k.gemm(dv(A, hip, dtype), dv(B, hip, dtype), out, M, N, K_, M, N, N, transA=True, transB=True, R=out, ldr=N,
+                   beta=1.0, batch=(nb, 1), sA=(K_ * M, 0), sB=(K_ * N, 0), sC=(M * N, 0), sR=(M * N, 0))
+            outs.append(out)
+        check(outs[0], ref, dtype, f"k-major gemm2 M={M} N={N} K={K_} b={nb} splits={splits}")
+        check(outs[0], outs[1], dtype, f"k-major gemm2 vs general kernel M={M} N={N}", factor=0.02)
