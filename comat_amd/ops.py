@@ -41,6 +41,7 @@ def _c(t):
 _side = {}
 _side_keep = []
 _side_enabled = True
+_side_suspended = 0  # >0: weight gradients stay on the issuing stream (see no_side_streams)
 
 
 def set_side_stream_enabled(flag: bool):
@@ -56,13 +57,27 @@ def _side_stream(dev):
     """A second HIP stream (None on CPU / when disabled), one per stream that issues backward work: the K = B*H*W
     split-K GEMMs of the LoRA weight gradients have few tiles each and no consumer until the optimizer, so they
     overlap the main backward chain."""
-    if dev.type != "cuda" or not _side_enabled:
+    if dev.type != "cuda" or not _side_enabled or _side_suspended:
         return None
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     st = _side.get(key)
     if st is None:
         st = _side[key] = torch.cuda.Stream(device=dev)
     return st
+
+
+class no_side_streams:
+    """Context: LoRA weight gradients of backward passes started inside it run on their issuing stream.  Used for the
+    D step when it is itself forked onto its own stream inside a hipGraph capture: a fork from a forked stream (nested)
+    crashes hipStreamEndCapture on ROCm 7.2, a single level of forks captures fine."""
+
+    def __enter__(self):
+        global _side_suspended
+        _side_suspended += 1
+
+    def __exit__(self, *exc):
+        global _side_suspended
+        _side_suspended -= 1
 
 
 _join_queued = False

@@ -130,7 +130,8 @@ class CoMatTrainer:
         self._d_stream = None
         self._d_pending = False
         self._d_keep = None
-        self.serial_d = False  # GraphedStep: D step on the main stream (a forked D stream crashes hipStreamEndCapture)
+        self.serial_d = False  # GraphedStep: D step in stream order on the main stream
+        self.flat_d = False    # GraphedStep: forked D stream, but no second-level fork for its weight gradients
 
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
@@ -221,7 +222,11 @@ class CoMatTrainer:
             # (_apply_updates), so the allocator cannot hand their memory to main-stream work in the meantime
             self._d_keep = out["training_latents"]
             with torch.cuda.stream(self._d_stream):
-                logs["D_loss"] = self._d_step(out, batch)
+                if self.flat_d:
+                    with ops.no_side_streams():
+                        logs["D_loss"] = self._d_step(out, batch)
+                else:
+                    logs["D_loss"] = self._d_step(out, batch)
         out["loss"].backward()  # LoRA weight gradients run on the side stream; joined at end of backward
         _dbg("G backward")
         self._d_pending = concurrent  # joined in _apply_updates, after the G all-reduce has been launched
@@ -337,7 +342,12 @@ class GraphedStep:
             tr.blip.static_tables = st
         key = tuple(training_steps)
         ent = self.graphs.get(key)
-        tr.serial_d = True  # eager pre-step and capture run the D step in stream order (bit-identical either way)
+        # D step inside the capture: COMAT_GRAPH_D=serial (default, known good) runs it in stream order; =fork forks it onto
+        # its own stream with its weight gradients kept on that stream (a nested fork crashes hipStreamEndCapture)
+        if os.environ.get("COMAT_GRAPH_D", "serial") == "fork":
+            tr.serial_d, tr.flat_d = False, True
+        else:
+            tr.serial_d = True
         if ent is None:
             # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
             # tables, workspaces of the default stream) and is a real optimisation step of its own

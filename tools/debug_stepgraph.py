@@ -6,7 +6,8 @@ one stage per process (run each with `python -X faulthandler tools/debug_stepgra
   opt      ... + clip / AdamW
   gan0     full step with the discriminator, D step serial (COMAT_D_STREAM=0)
   gan1     full step, D step on its own stream
-  full     GraphedStep itself (eager step, capture, replay)"""
+  gan2     full step, D step on its own stream but its weight gradients NOT forked again (no nested fork)
+  full     GraphedStep itself (eager step, capture, replay);  full2: with COMAT_GRAPH_D=fork"""
 import os
 import sys
 
@@ -18,6 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 stage = sys.argv[1]
 if stage == "gan0":
     os.environ["COMAT_D_STREAM"] = "0"
+if stage in ("gan2", "full2"):
+    os.environ["COMAT_GRAPH_D"] = "fork"
 from comat_amd import _hip, ops  # noqa: E402
 from test_step import make_world  # noqa: E402
 
@@ -41,7 +44,9 @@ def body():
     return tr.train_step(sb, training_steps=ts, crop=crop)["step_loss"]
 
 
-if stage == "full":
+if stage == "gan2":
+    tr.flat_d = True
+if stage in ("full", "full2"):
     from comat_amd.step import GraphedStep
     gs = GraphedStep(tr)
     for i in range(3):
