@@ -363,8 +363,8 @@ def main():
             trainer.blip.static_tables = None
             sync()
         if stepper is not None and mode == "auto":
-            # the graph runs the D step in stream order, eager launches overlap it with the G backward on a second
-            # stream but pay ~10 us of host time per launch: take whichever is faster on this box (3 steps each)
+            # eager launches pay ~10 us of host time per kernel, graph replay pays the capture-safe stream topology (no
+            # nested forks): take whichever is faster on this box (3 steps each)
             def probe(fn):
                 fn()
                 sync()
@@ -373,7 +373,7 @@ def main():
                     fn()
                 sync()
                 return (time.time() - t0) / 3
-            trainer.serial_d = False
+            trainer.serial_d, trainer.flat_d = False, False
             t_eager = probe(lambda: trainer.train_step(batch, **fixed))
             t_graph = probe(lambda: stepper(batch, **fixed))
             if t_eager < t_graph:

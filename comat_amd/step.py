@@ -280,9 +280,9 @@ class GraphedStep:
         `training_steps` tuple (C2: N = K, a single tuple), captured lazily at its first use after one eager step;
       * no host synchronisation and no host-side data dependence inside the step (asserted by
         tests/test_step.py::test_step_is_enqueue_only).
-    The D step is captured in stream order, not on its own stream: forking it inside the capture crashes
-    hipStreamEndCapture on ROCm 7.2 (profiles/r02_c_*: every other part of the step captures, including the
-    weight-gradient side streams).
+    Streams inside the capture: the LoRA weight gradients of the G backward fork onto a side stream, the D step forks onto
+    its own stream (its weight gradients stay on that stream: a fork from a forked stream crashes hipStreamEndCapture on
+    ROCm 7.2 - located stage by stage in profiles/r02_c_stepgraph_stages.txt); both rejoin before the optimizer.
     Not captured (the eager path runs instead): attribute-concentration steps (their masks are resized on the host),
     data-parallel runs (the RCCL all-reduce stays outside graphs until it can be tested on a multi-GPU node).
     Results are bit-identical to eager steps (`tests/test_step.py::test_graphed_step_matches_eager`)."""
@@ -342,12 +342,13 @@ class GraphedStep:
             tr.blip.static_tables = st
         key = tuple(training_steps)
         ent = self.graphs.get(key)
-        # D step inside the capture: COMAT_GRAPH_D=serial (default, known good) runs it in stream order; =fork forks it onto
-        # its own stream with its weight gradients kept on that stream (a nested fork crashes hipStreamEndCapture)
-        if os.environ.get("COMAT_GRAPH_D", "serial") == "fork":
-            tr.serial_d, tr.flat_d = False, True
+        # D step inside the capture: forked onto its own stream (it overlaps the G backward chain: 187 -> 168 ms per C2 step
+        # on MI355X) with its weight gradients kept on that stream - a fork from a forked stream (nested) crashes
+        # hipStreamEndCapture on ROCm 7.2.  COMAT_GRAPH_D=serial runs it in stream order on the main stream instead.
+        if os.environ.get("COMAT_GRAPH_D", "fork") == "serial":
+            tr.serial_d, tr.flat_d = True, False
         else:
-            tr.serial_d = True
+            tr.serial_d, tr.flat_d = False, True
         if ent is None:
             # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
             # tables, workspaces of the default stream) and is a real optimisation step of its own

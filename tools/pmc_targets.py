@@ -20,6 +20,28 @@ W = torch.randn(320, 3, 3, 320, device=dev).to(T)
 Y = torch.empty(2 * 64 * 64, 320, device=dev, dtype=T)
 for _ in range(N):
     K.conv2d(X, W, Y, 2, 64, 64, 320, 64, 64, 320, 3, 3, 1, 1)
+# conv 3x3, B=1, 128x128, 512 -> 512 (VAE decoder up block: the largest convs of the step)
+Xv = torch.randn(128 * 128, 512, device=dev).to(T)
+Wv = torch.randn(512, 3, 3, 512, device=dev).to(T)
+Yv = torch.empty(128 * 128, 512, device=dev, dtype=T)
+for _ in range(N):
+    K.conv2d(Xv, Wv, Yv, 1, 128, 128, 512, 128, 128, 512, 3, 3, 1, 1)
+# LoRA weight gradient dU [320, 128] += g^T h over 8192 tokens (k-major operands)
+G_ = torch.randn(8192, 320, device=dev).to(T)
+H_ = torch.randn(8192, 128, device=dev).to(T)
+DU = torch.zeros(320, 128, device=dev)
+for _ in range(N):
+    K.gemm(G_, H_, DU, 320, 128, 8192, 320, 128, 128, transA=True, transB=True, R=DU, ldr=128, beta=1.0)
+# fused attention, SD1.5 self-attention at the 64x64 level (2 x 8 heads, 4096 tokens, d = 40): forward + backward
+HD = 8 * 40
+Qa, Ka, Va, Ga = (torch.randn(2 * 4096, HD, device=dev).to(T) for _ in range(4))
+Oa = torch.empty_like(Qa)
+lse = torch.empty(2, 8, 4096, device=dev)
+dbuf = torch.empty(2, 8, 4096, device=dev)
+dQ, dK, dV = torch.empty_like(Qa), torch.empty_like(Ka), torch.empty_like(Va)
+for _ in range(N):
+    K.flash_attn_fwd(Qa, Ka, Va, Oa, lse, 2, 8, 4096, 4096, 40, HD, HD, HD, HD, 40 ** -0.5)
+    K.flash_attn_bwd(Qa, Ka, Va, Oa, Ga, lse, dbuf, dQ, dK, dV, 2, 8, 4096, 4096, 40, HD, HD, HD, HD, 40 ** -0.5)
 # GEGLU projection GEMM 8192 x 2560 x 320
 A = torch.randn(8192, 320, device=dev).to(T)
 Bw = torch.randn(2560, 320, device=dev).to(T)

@@ -1,0 +1,78 @@
+"""rocprofv3 --pmc passes (rocpd databases) of tools/pmc_targets.py -> profiles/r02_pmc_kernels.json.
+
+    python tools/pmc_to_json.py fetch_results.db write_results.db busy_results.db > profiles/r02_pmc_kernels.json
+
+Per kernel: average duration, HBM-side bytes per launch (FETCH_SIZE is in KiB and, on gfx950, counts a wide coalesced read
+stream at half its bytes: x 2 as MI355X_MICROARCH.md prescribes; WRITE_SIZE in KiB, uncorrected), MFMA busy share =
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), and the algorithmic bytes / FLOPs of the probe's launches."""
+import json
+import sqlite3
+import sys
+from collections import defaultdict
+
+# (kernel-name fragment, occurrence among the groups with that fragment in launch order) -> label, algorithmic FLOP and
+# bytes of one launch in tools/pmc_targets.py
+ALGO = [
+    (("gemm2_kernel", "true>"), 0, "conv 3x3 B=2 64x64 320->320", 2.0 * 8192 * 320 * 2880, 8192 * 320 * 2 * 2 + 320 * 2880 * 2),
+    (("gemm2_kernel", "true>"), 1, "conv 3x3 B=1 128x128 512->512 (VAE)", 2.0 * 16384 * 512 * 4608, 16384 * 512 * 2 * 2 + 512 * 4608 * 2),
+    (("gemm2_tt_kernel",), 0, "LoRA weight gradient 320x128 over 8192 tokens", 2.0 * 320 * 128 * 8192, 8192 * (320 + 128) * 2 + 320 * 128 * 8),
+    (("gemm2_kernel", "false>"), 0, "GEGLU projection 8192x2560x320", 2.0 * 8192 * 2560 * 320, (8192 * 320 + 2560 * 320 + 8192 * 2560) * 2),
+    (("flash_fwd_kernel",), 0, "fused attention fwd 2x8 heads, 4096^2, d=40", 4.0 * 16 * 4096 * 4096 * 40, 4 * 2 * 4096 * 320 * 2),
+    (("flash_dkdv_kernel",), 0, "fused attention bwd dK/dV", 6.0 * 16 * 4096 * 4096 * 40, 6 * 2 * 4096 * 320 * 2),
+    (("flash_dq_kernel",), 0, "fused attention bwd dQ", 4.0 * 16 * 4096 * 4096 * 40, 5 * 2 * 4096 * 320 * 2),
+    (("softmax_fwd_kernel",), 0, "captured map write-back [8, 4096, 77]", 0.0, 8 * 4096 * 77 * 6),
+    (("attnmap_fwd_lds_kernel",), 0, "attention-map gather, 4 token columns", 0.0, 8 * 4096 * 77 * 2 + 4 * 4096 * 4),
+]
+
+
+def main():
+    ctr = defaultdict(dict)
+    first = {}
+    for db in sys.argv[1:]:
+        cur = sqlite3.connect(db).cursor()
+        for k, gs, c, v, st, d, n in cur.execute("select kernel_name, grid_size, counter_name, avg(value), min(start), avg(duration), "
+                                                 "count(*) from counters_collection group by kernel_name, grid_size, counter_name"):
+            ctr[(k, gs)][c] = v
+            ctr[(k, gs)].setdefault("_us", d / 1e3)
+            ctr[(k, gs)].setdefault("_n", n)
+            first.setdefault((k, gs), st)
+    groups = sorted((g for g in ctr if "anonymous" in g[0]), key=lambda g: first[g])
+    seen = defaultdict(int)
+    out = {}
+    for g in groups:
+        k, gs = g
+        c = ctr[g]
+        label, flop, abytes = None, 0.0, 0.0
+        for frags, occ, lab, fl, ab in ALGO:
+            if all(f in k for f in frags):
+                if seen[frags] == occ:
+                    label, flop, abytes = lab, fl, ab
+                break
+        for frags, _, _, _, _ in ALGO:
+            if all(f in k for f in frags):
+                seen[frags] += 1
+                break
+        us = c["_us"]
+        ent = {"kernel": k[:110], "grid_threads": gs, "probe": label, "launches": c["_n"], "avg_us": round(us, 2)}
+        if "FETCH_SIZE" in c:
+            ent["hbm_read_bytes"] = int(c["FETCH_SIZE"] * 1024 * 2)
+        if "WRITE_SIZE" in c:
+            ent["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+            # GRBM_GUI_ACTIVE comes summed over the 8 XCDs (1.3e6 "cycles" for a 67.6 us kernel in round 1 = 8 x 2.4 GHz x t)
+            ent["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        if label:
+            ent["algorithmic_bytes"] = int(abytes)
+            if flop and us:
+                ent["algorithmic_tflop_per_s"] = round(flop / us / 1e6, 1)
+            if "hbm_read_bytes" in ent and "hbm_write_bytes" in ent and us:
+                tot = ent["hbm_read_bytes"] + ent["hbm_write_bytes"]
+                ent["hbm_GB_per_s"] = round(tot / us / 1e3, 1)
+                ent["traffic_over_algorithmic"] = round(tot / abytes, 2) if abytes else None
+        out[f"{len(out):02d} {label or k[:60]}"] = ent
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
