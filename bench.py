@@ -56,39 +56,65 @@ def step_tflop(total_step, K, gan, sdxl=False):
     return f
 
 
-class TimedKernels:
-    """Wraps the kernel backend for ONE instrumented step: brackets every launch with HIP events on the launch stream
-    (torch's current stream, the one the C ABI enqueues on) and tallies algorithmic FLOPs / bytes per kernel family."""
+MFMA_CALLS = ("gemm", "gemm_segments", "conv2d", "flash_attn_fwd", "flash_attn_bwd")
+
+
+class CallRecorder:
+    """Wraps the kernel backend for ONE eager step after the timed region: counts every launch and keeps, for each
+    distinct MFMA problem of the step (GEMM / K-segmented GEMM / conv / fused attention: entry point, shape, strides,
+    epilogue), the arguments of its first call and its call count.  measure() then replays each distinct problem on its
+    own operands, back to back from a hipGraph of `n` launches bracketed by HIP events on the launch stream: the
+    per-launch durations are kernel time, not the host's launch cadence (an event pair around a single eager launch
+    measures the ~10 us the host needs between two launches whenever the GPU has run dry)."""
 
     def __init__(self, inner):
         self.inner = inner
-        self.records = []
+        self.calls = {}
+        self.other = {}
 
     def __getattr__(self, name):
         fn = getattr(self.inner, name)
         if not callable(fn):
             return fn
+        if name not in MFMA_CALLS:
+            def counted(*a, **kw):
+                self.other[name] = self.other.get(name, 0) + 1
+                return fn(*a, **kw)
+            return counted
 
         def wrapped(*a, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
+            sig = self._sig(name, a, kw)
+            rec = self.calls.get(sig)
             r = fn(*a, **kw)
-            e.record()
-            self.records.append((name, self._flops(name, a, kw), s, e, self._sig(name, a, kw)))
+            if rec is None:
+                from comat_amd import _hip
+                kid = _hip.last_gemm_kernel() if name in ("gemm", "gemm_segments", "conv2d") else -1
+                self.calls[sig] = [name, a, kw, self._flops(name, a, kw), 1, kid]
+            else:
+                rec[4] += 1
             return r
         return wrapped
 
     @staticmethod
-    def _sig(name, a, kw):
+    def _epi(kw):
+        return (f"bias={int(kw.get('bias') is not None)}{int(kw.get('bias2') is not None)} R={int(kw.get('R') is not None)} "
+                f"act={kw.get('act', 0)}")
+
+    @classmethod
+    def _sig(cls, name, a, kw):
         if name == "gemm":
-            return (f"gemm M={a[3]} N={a[4]} K={a[5]} tA={int(kw.get('transA', False))} tB={int(kw.get('transB', False))} "
-                    f"b={kw.get('batch', (1, 1))} in={a[0].dtype} out={a[2].dtype}")
+            return (f"gemm M={a[3]} N={a[4]} K={a[5]} ld={a[6]},{a[7]},{a[8]} tA={int(kw.get('transA', False))} "
+                    f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={a[2].dtype} "
+                    + cls._epi(kw))
         if name == "gemm_segments":
-            return f"gemm_segments M={a[2]} N={a[3]} K={'+'.join(str(sg[2]) for sg in a[0])} out={a[1].dtype}"
+            return (f"gemm_segments M={a[2]} N={a[3]} K={'+'.join(str(sg[2]) for sg in a[0])} b={kw.get('batch', 1)} "
+                    f"in={a[0][0][0].dtype} out={a[1].dtype} " + cls._epi(kw))
         if name == "conv2d":
             return (f"conv B={a[3]} HWin={a[4]}x{a[5]} Cin={a[6]} HWout={a[7]}x{a[8]} Cout={a[9]} k={a[10]} s={a[12]} "
-                    f"mode={kw.get('mode', 0)} ups={kw.get('ups', 1)}")
-        return name
+                    f"mode={kw.get('mode', 0)} ups={kw.get('ups', 1)} in={a[0].dtype} out={a[2].dtype} " + cls._epi(kw))
+        if name == "flash_attn_fwd":
+            return f"flash_fwd B={a[5]} H={a[6]} Nq={a[7]} Nk={a[8]} d={a[9]} {a[0].dtype}"
+        return f"flash_bwd B={a[10]} H={a[11]} Nq={a[12]} Nk={a[13]} d={a[14]} {a[0].dtype}"
 
     @staticmethod
     def _flops(name, a, kw):
@@ -97,37 +123,54 @@ class TimedKernels:
             b = kw.get("batch", (1, 1))
             return 2.0 * M * N * K * b[0] * b[1]
         if name == "gemm_segments":
-            return 2.0 * a[2] * a[3] * sum(sg[2] for sg in a[0])
+            return 2.0 * a[2] * a[3] * sum(sg[2] for sg in a[0]) * kw.get("batch", 1)
         if name == "conv2d":
             B, Cin, Hout, Wout, Cout, KH, KW, stride = a[3], a[6], a[7], a[8], a[9], a[10], a[11], a[12]
             f = 2.0 * B * Hout * Wout * Cout * KH * KW * Cin
             return f / (stride * stride) if kw.get("mode", 0) == 1 else f
         if name == "flash_attn_fwd":  # (q, k, v, o, lse, B, H, Nq, Nk, d, ...): QK^T + PV
             return 4.0 * a[5] * a[6] * a[7] * a[8] * a[9]
-        if name == "flash_attn_bwd":  # (q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ...): 5 products
-            return 10.0 * a[10] * a[11] * a[12] * a[13] * a[14]
-        return 0.0
+        return 10.0 * a[10] * a[11] * a[12] * a[13] * a[14]  # flash_attn_bwd: 5 products
 
-    def summary(self):
-        torch.cuda.synchronize()
-        fam = {}
-        shapes = {}
-        for name, fl, s, e, sig in self.records:
-            ms = s.elapsed_time(e)
-            d = fam.setdefault(name, [0.0, 0.0, 0])
-            d[0] += ms * 1e-3
-            d[1] += fl
-            d[2] += 1
-            q = shapes.setdefault(sig, [0.0, 0.0, 0])
-            q[0] += ms
-            q[1] += fl
-            q[2] += 1
+    def measure(self, n=10):
+        """-> {family: [seconds per step, flops per step, launches per step]}; family = kernel that served the problem"""
+        from comat_amd import _hip
+        side = torch.cuda.Stream()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fam, rows = {}, []
+        for sig, (name, a, kw, fl, count, kid) in self.calls.items():
+            fn = getattr(self.inner, name)
+            with torch.cuda.stream(side):  # workspaces of this stream exist before the capture
+                fn(*a, **kw)
+                fn(*a, **kw)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(n):
+                    fn(*a, **kw)
+            g.replay()
+            torch.cuda.synchronize()
+            s.record()
+            g.replay()
+            e.record()
+            torch.cuda.synchronize()
+            t = s.elapsed_time(e) * 1e-3 / n
+            del g
+            family = _hip.GEMM_KERNEL_NAMES[kid] if kid >= 0 else ("flash_fwd_kernel" if name == "flash_attn_fwd"
+                                                                   else "flash_bwd (dq + dkdv kernels)")
+            d = fam.setdefault(family, [0.0, 0.0, 0])
+            d[0] += t * count
+            d[1] += fl * count
+            d[2] += count
+            rows.append((t * count * 1e3, count, fl / t / 1e12, t * 1e6, family.split(" ")[0], sig))
         dump = os.environ.get("COMAT_BENCH_DUMP")
         if dump:
             with open(dump, "w") as f:
-                for sig, (ms, fl, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
-                    tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-                    f.write(f"{ms:9.2f} ms  n={n:5d}  {tf:8.1f} TF/s  {sig}\n")
+                f.write("# ms/step  calls  TF/s  us/launch  kernel  problem   (back-to-back replays, HIP events)\n")
+                for ms, cnt, tf, us, kname, sig in sorted(rows, reverse=True):
+                    f.write(f"{ms:9.3f} {cnt:5d} {tf:8.1f} {us:9.2f}  {kname:16s} {sig}\n")
+                f.write(f"# other launches per step: {sum(self.other.values())} "
+                        f"{dict(sorted(self.other.items(), key=lambda kv: -kv[1]))}\n")
         return fam
 
 
@@ -268,6 +311,17 @@ def cpu_baseline(usd, scfg):
             "components_s": {k: round(v, 2) for k, v in t.items()}}
 
 
+def load_pmc_summary():
+    """HBM traffic / MFMA-busy figures of the dominant kernel from the committed counter pass (separate rocprofv3 --pmc
+    runs of tools/pmc_targets.py, converted by tools/pmc_to_json.py).  Counters cannot be collected inside a timed run."""
+    p = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        d = json.load(f)
+    return d.get("bench_roofline")
+
+
 def attn_map_probe():
     """North-star counter: the attention-map path on its own.  Softmax write-back of one captured SD1.5 `up_64`
     cross-attention map ([8 heads, 4096 pixels, 77 tokens], fp32 scores -> bf16 probabilities, the map the attribute-
@@ -300,12 +354,16 @@ def attn_map_probe():
     t_ga = timed(lambda: k.attnmap_gather_fwd(P, mask, tok_idx, tok_obj, num, den, avg, H, NP, L, NT))
     b_sm = H * NP * L * (4 + 2)            # scores read (fp32) + probabilities written (bf16)
     b_ga = H * NP * NT * 2 + NT * NP * 4   # selected columns read + per-token head-mean map written
+    m_ga = H * NP * L * 2 + NT * NP * 4    # what the kernel moves: it streams the whole [pixels, 77] map, coalesced
     return {"softmax_writeback": {"bytes": b_sm, "us": round(t_sm * 1e6, 2), "GB/s": round(b_sm / t_sm / 1e9, 1),
                                   "frac_of_8TBs": round(b_sm / t_sm / 8e12, 4)},
             "gather": {"bytes": b_ga, "us": round(t_ga * 1e6, 2), "GB/s": round(b_ga / t_ga / 1e9, 1),
                        "frac_of_8TBs": round(b_ga / t_ga / 8e12, 4),
-                       "note": "algorithmic bytes = the 4 selected token columns; the kernel touches every 64-byte "
-                               "segment of the [pixels, 77] rows that holds one"}}
+                       "moved_bytes": m_ga, "moved_GB/s": round(m_ga / t_ga / 1e9, 1),
+                       "note": "algorithmic bytes = the 4 selected token columns; the probabilities are stored "
+                               "[pixels, 77] (the layout the softmax and its backward stream), so every 64-byte segment "
+                               "of a row holds a wanted element and the gather streams the map once through LDS "
+                               "(two launches: per-head partial sums, then the head mean)"}}
 
 
 def main():
@@ -428,35 +486,41 @@ def main():
 
     roofline = None
     if not args.no_kernel_timing and not args.selftest:
-        # one extra, instrumented step.  EVERY rank runs it (the step contains the gradient all-reduce: a rank-0-only
-        # step would deadlock the collective); only rank 0 brackets its kernels with events.
-        timed = None
+        # one extra eager step with a recorder around the kernel backend.  EVERY rank runs it (the step contains the
+        # gradient all-reduce: a rank-0-only step would deadlock the collective); only rank 0 records and replays.
+        rec = None
         if rank == 0:
-            timed = TimedKernels(ops.kernels())
-            ops.set_kernel_backend(timed)
-        ops.set_side_stream_enabled(False)  # per-kernel event timing needs one stream (no overlapping kernels)
+            rec = CallRecorder(ops.kernels())
+            ops.set_kernel_backend(rec)
+        trainer.serial_d, trainer.flat_d = False, False
         trainer.train_step(batch, **fixed)
         sync()
-        ops.set_side_stream_enabled(True)
         if rank == 0:
-            fam = timed.summary()
-            ops.set_kernel_backend(timed.inner)
+            ops.set_kernel_backend(rec.inner)
+            fam = rec.measure()
     if rank == 0 and not args.no_kernel_timing and not args.selftest:
-        tot_t = sum(v[0] for v in fam.values())
-        dom = max((k for k in fam if fam[k][1] > 0), key=lambda k: fam[k][0])
+        dom = max(fam, key=lambda k: fam[k][0])
         t_dom, f_dom, n_dom = fam[dom]
         total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config == "c4")
+        pmc = load_pmc_summary()
+        n_other = sum(rec.other.values())
         roofline = {
-            "bound": "mfma", "kernel": {"gemm": "gemm_kernel<bf16>", "gemm_segments": "gemm_seg_kernel<bf16>",
-                                     "conv2d": "conv_kernel<bf16> (implicit GEMM)"}.get(dom, dom),
+            "bound": "mfma", "kernel": dom,
             "achieved": f_dom / t_dom / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": f_dom / t_dom / 1e12 / PEAK_BF16_TFLOPS, "traffic": None,
+            "frac": f_dom / t_dom / 1e12 / PEAK_BF16_TFLOPS,
+            "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
+            "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r02_pmc_kernels.json)",
+            "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
             "launches_per_step": n_dom, "avg_launch_ms": t_dom / n_dom * 1e3,
             "algorithmic_tflop_per_step_in_kernel": f_dom / 1e12,
+            "timing": "every distinct problem of one recorded step replayed back to back (hipGraph of 10 launches, HIP "
+                      "events on the launch stream), weighted by its call count",
             "step_algorithmic_tflop": total, "step_frac": total / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS,
+            "mfma_kernel_ms_per_step": round(sum(v[0] for v in fam.values()) * 1e3, 2),
+            "other_launches_per_step": n_other,
             "families": {k: {"ms": round(v[0] * 1e3, 2), "tflop": round(v[1] / 1e12, 3), "launches": v[2],
-                             "share_of_kernel_time": round(v[0] / tot_t, 4)}
-                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])[:10]},
+                             "TFLOP/s": round(v[1] / v[0] / 1e12, 1)}
+                         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
         }
     attn_map = None
     if rank == 0 and not args.no_kernel_timing and not args.selftest:

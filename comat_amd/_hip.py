@@ -97,6 +97,7 @@ SIGNATURES = {
     "comat_adamw_tick": [_vp, _vp, _vp],
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
     "comat_set_option": [C.c_char_p, _i32],
+    "comat_last_gemm_kernel": [],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
@@ -125,6 +126,16 @@ def load_library(path: str | None = None):
         raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_kernel (LDS-DMA pipelined)",
+                     2: "gemm2_tt_kernel (pipelined, k-major operands)"}
+
+
+def last_gemm_kernel() -> int:
+    """which kernel served this thread's last gemm / gemm_segments / conv2d call (include/comat_hip.h)"""
+    load_library()
+    return int(_lib.comat_last_gemm_kernel())
 
 
 def set_option(name: str, value: int):

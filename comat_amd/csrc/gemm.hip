@@ -713,7 +713,9 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
-    if (const int rc = comat_gemm2_try_gemm(p, stream)) return rc < 0 ? rc : comat_check_launch("comat_gemm");
+    const int rc2 = comat_gemm2_try_gemm(p, stream);
+    comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
+    if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
     GemmArgs g;
     g.A = p->A; g.B = p->B;
     g.M = p->M; g.N = p->N; g.K = p->K; g.lda = p->lda; g.ldb = p->ldb;
@@ -761,8 +763,9 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
         COMAT_REQUIRE(segs[s].lda >= segs[s].K && segs[s].ldb >= segs[s].K,
                       "comat_gemm_segments: leading dimension of segment %d too small", s);
     }
-    if (const int rc = comat_gemm2_try_segments(p, segs, nseg, stream))
-        return rc < 0 ? rc : comat_check_launch("comat_gemm_segments");
+    const int rc2 = comat_gemm2_try_segments(p, segs, nseg, stream);
+    comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
+    if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm_segments");
     GemmSegArgs g;
     const int bke = p->in_dtype == COMAT_BF16 ? KTB / 2 : KTB / 4;
     g.nk = 0;
@@ -811,7 +814,9 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     COMAT_REQUIRE(p->ups == 1 || (p->ups == 2 && p->mode == 0), "comat_conv2d: ups must be 1, or 2 with mode 0");
     COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_conv2d: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_conv2d: bad residual dtype");
-    if (const int rc = comat_gemm2_try_conv(p, stream)) return rc < 0 ? rc : comat_check_launch("comat_conv2d");
+    const int rc2 = comat_gemm2_try_conv(p, stream);
+    comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
+    if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_conv2d");
     ConvArgs g;
     g.X = p->X; g.W = p->W;
     g.geo.B = p->B; g.geo.Hin = p->Hin; g.geo.Win = p->Win; g.geo.Cin = p->Cin;

@@ -751,7 +751,7 @@ static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
     a.ws = (float*)p->ws;
     a.vec = epi_vec_ok(a.ep, a.N, a.sC, a.sR, a.sBias, a.M);
     hipLaunchKernelGGL((gemm2_tt_kernel<4>), dim3((unsigned)(a.ntiles * s)), dim3(256), 0, (hipStream_t)stream, a);
-    return 1;
+    return 2;
 }
 
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {

@@ -70,7 +70,7 @@ __device__ __forceinline__ bool splitk_ticket_is_last(unsigned* counter, int spl
 // ---- host side ------------------------------------------------------------------------------------------------
 constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters at the head of the workspace
 
-// gemm2.hip: the pipelined bf16 kernel.  Each returns 1 when it took the problem (launched), 0 when the shape is not
+// gemm2.hip: the pipelined bf16 kernel.  Each returns >0 when it took the problem (1 pipelined, 2 k-major), 0 when the shape is not
 // eligible (the caller falls through to the general kernel), <0 on error.
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream);
 int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream);

@@ -24,6 +24,10 @@ int comat_check_launch(const char* what) {
 extern "C" int comat_abi_version(void) { return COMAT_ABI_VERSION; }
 extern "C" const char* comat_last_error(void) { return g_err; }
 
+static thread_local int g_last_gemm_kernel = -1;
+void comat_note_gemm_kernel(int id) { g_last_gemm_kernel = id; }
+extern "C" int comat_last_gemm_kernel(void) { return g_last_gemm_kernel; }
+
 // ---- tuning options -------------------------------------------------------------------------------------------
 // Kernel-selection switches (A/B runs, microbenchmarks, parity tests of every variant).  Each option takes its value
 // from the environment variable COMAT_<NAME> the first time it is read (a launch has a budget of a few microseconds:

@@ -36,6 +36,10 @@ const char* comat_last_error(void);
  * COMAT_<NAME> (read once) or its built-in default.  They select among kernels that compute the same function; results
  * differ at most in floating-point summation order. */
 int comat_set_option(const char* name, int32_t value);
+/* Which kernel served the calling thread's last comat_gemm / comat_gemm_segments / comat_conv2d call: 0 the general
+ * 64x64 kernel, 1 the LDS-DMA pipelined kernel, 2 its k-major (transA && transB) variant; -1 before the first call.
+ * bench.py and the tests use it to attribute time and to assert that a problem runs on the kernel the docs say. */
+int comat_last_gemm_kernel(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM:  C = act(alpha * op(A) op(B)^T + bias + bias2) + beta * R         (fp32 accumulate on MFMA)

@@ -20,9 +20,21 @@ from oracle import blip as OB
 from oracle import step as OS
 
 DTYPES = [torch.float32, torch.bfloat16]
+# bf16 storage against the fp32 oracle on the SAME (bf16-representable) weights: the gradient error is the rounding of
+# every stored activation (2^-9 relative each) carried through ~100 layers and three denoise steps.
+BF16_GRAD_LIMIT = 0.12
 
 
-def make_world(dtype, dev, attrcon):
+def report(name, dtype, dev, **vals):
+    """measured errors of the whole-step comparisons, appended to $COMAT_TEST_REPORT (evidence for the bf16 limits below)"""
+    path = os.environ.get("COMAT_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{name} {str(dtype).replace('torch.', '')} {torch.device(dev).type if not hasattr(dev, 'type') else dev.type} "
+                    + " ".join(f"{k}={v:.3e}" for k, v in vals.items()) + "\n")
+
+
+def make_world(dtype, dev, attrcon, gan=True):
     usd, vsd, lsd = tiny_weights(dtype)
     q = lambda d: {k: v.to(dtype).float() for k, v in d.items()}
     bsd = q(weights.make_blip_weights(config.TINY_BLIP, perturb_norms=True))
@@ -30,7 +42,7 @@ def make_world(dtype, dev, attrcon):
     dl = q({k: (v * 5 if k.endswith("up.weight") else v) for k, v in weights.make_lora_weights(config.TINY_UNET, seed=78).items()})
     g = torch.Generator().manual_seed(5)
     head_w, head_b = torch.randn(4, generator=g) * 0.5, torch.randn(1, generator=g) * 0.1
-    cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=attrcon, attrcon_train_steps=1,
+    cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=gan, attrcon=attrcon, attrcon_train_steps=1,
                      train_layer_ls=("mid_2", "up_4", "up_8"), attn_reses=(8, 4, 2), lr=1e-2, lr_D=1e-2,
                      mask_token_loss_weight=0.5, mask_pixel_loss_weight=0.1)
     bs, L, cd, T = 2, 7, config.TINY_UNET.cross_attention_dim, 9
@@ -100,10 +112,12 @@ def test_train_step_matches_oracle(dev, dtype, attrcon):
     bank, dbank = trainer.bank, trainer.D.bank
     g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
     d_ref = torch.cat([ref["d_grads"][n].reshape(-1) for n in dbank.names])
-    lim = 1e-3 if dtype == torch.float32 else 0.12
+    lim = 1e-3 if dtype == torch.float32 else BF16_GRAD_LIMIT
+    hg = torch.cat([ref["head_grads"][0].reshape(-1), ref["head_grads"][1].reshape(-1)])
+    report(f"tiny_step attrcon={int(attrcon)}", dtype, dev, g=rel_l2(bank.flat_grad, g_ref), d=rel_l2(dbank.flat_grad, d_ref),
+           head=rel_l2(trainer.D.head_grad, hg))
     assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
     assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
-    hg = torch.cat([ref["head_grads"][0].reshape(-1), ref["head_grads"][1].reshape(-1)])
     assert rel_l2(trainer.D.head_grad, hg) < lim * 3
     # parameters after clip + AdamW.  The first Adam update is sign-like (lr * g / (|g| + eps)): elements whose
     # gradient is ~0 amplify summation-order differences, hence 3e-4 rather than the 1e-3-of-gradient bound / 10
@@ -111,6 +125,33 @@ def test_train_step_matches_oracle(dev, dtype, attrcon):
     assert rel_l2(bank.flat, p_ref) < (3e-4 if dtype == torch.float32 else 2e-2)
     pd_ref = torch.cat([W["d_lora"][n].detach().reshape(-1) for n in dbank.names])
     assert rel_l2(dbank.flat, pd_ref) < (3e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_cm_only_step_matches_oracle(dev, dtype):
+    """BASELINE config C1's loss set in miniature: concept matching alone (--gan_loss off, no attribute concentration):
+    the step loss is minus the BLIP caption reward, there is no discriminator pass, no D update, and the discriminator's
+    parameters stay untouched (reference training_script.py:902-907: the GAN branch is skipped as a whole)."""
+    cfg, batch, W, trainer = make_world(dtype, dev, False, gan=False)
+    ts, crop = [0, 2], (0, 1, 63, 63)
+    opt = torch.optim.AdamW(list(W["lora"].values()), lr=cfg.lr, betas=(cfg.adam_beta1, cfg.adam_beta2),
+                            eps=cfg.adam_epsilon, weight_decay=cfg.adam_weight_decay)
+    d0 = trainer.D.bank.flat.clone()
+    ref = OS.train_step(W, batch, cfg, ts, crop, None, opt, None)
+    logs = trainer.train_step(batch, training_steps=ts, crop=crop)
+    f = 1.0 if dtype == torch.float32 else 4.0
+    check(logs["Blip"], ref["Blip"], dtype, "Blip reward", factor=f)
+    check(logs["step_loss"], ref["loss"], dtype, "step loss", factor=f)
+    check(logs["step_loss"], -logs["Blip"], torch.float32, "loss == -reward (the caption log-likelihood)")
+    assert "G_loss" not in logs and "D_loss" not in logs
+    bank = trainer.bank
+    g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
+    lim = 1e-3 if dtype == torch.float32 else BF16_GRAD_LIMIT
+    report("tiny_step cm_only", dtype, dev, g=rel_l2(bank.flat_grad, g_ref))
+    assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
+    p_ref = torch.cat([W["lora"][n].detach().reshape(-1) for n in bank.names])
+    assert rel_l2(bank.flat, p_ref) < (3e-4 if dtype == torch.float32 else 2e-2)
+    assert torch.equal(trainer.D.bank.flat, d0)
 
 
 def test_second_step_uses_updated_lora(sim):
@@ -191,7 +232,8 @@ def test_train_step_sdxl_matches_oracle(dev, dtype):
         check(logs[key], ref[rk], dtype, key, factor=f)
     g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
     d_ref = torch.cat([ref["d_grads"][n].reshape(-1) for n in dbank.names])
-    lim = 1e-3 if dtype == torch.float32 else 0.15
+    lim = 1e-3 if dtype == torch.float32 else BF16_GRAD_LIMIT
+    report("tiny_step sdxl", dtype, dev, g=rel_l2(bank.flat_grad, g_ref), d=rel_l2(dbank.flat_grad, d_ref))
     assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
     assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
 

@@ -18,6 +18,49 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 pytestmark = [pytest.mark.gpu]
+BF16_FULL_GRAD_LIMIT = 0.5  # provisional until the first measurement (profiles/r02_g_bf16_errors.txt)
+
+
+def test_c1_full_size_bf16_error_is_bounded(hip):
+    """The same C1 step with bf16 storage (the bench's dtype) against the fp32 golden: there is no 1e-3 claim in bf16 -
+    this test RECORDS the error of the flat LoRA gradient at the real model size ($COMAT_TEST_REPORT) and bounds it, so a
+    kernel change that degrades bf16 numerics (accumulation dtype, a dropped rounding step) shows up at full size."""
+    from make_c1_golden import c1_inputs, rademacher
+
+    from comat_amd.blip import Blip
+    from comat_amd.pipeline import TrainableSDPipeline
+    from comat_amd.step import CoMatTrainer
+    from comat_amd.unet import LoRABank, UNet, VAEDecoder
+    gold = np.load(os.path.join(HERE, "golden", "c1_full.npz"))
+    (ucfg, vcfg, bcfg), sd, batch, scfg, ts, crop = c1_inputs()
+    dtype = torch.bfloat16
+    bank = LoRABank(ucfg, sd["lora"], dtype, hip)
+    pipe = TrainableSDPipeline(UNet(ucfg, sd["unet"], dtype, hip, bank), VAEDecoder(vcfg, sd["vae"], dtype, hip))
+    trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], dtype, hip), None, scfg, seed=0)
+    bank.set_requires_grad(True)
+    bank.zero_grad()
+    out = trainer.compute_losses(batch, training_steps=ts, crop=crop)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    names = [str(n) for n in gold["names"]]
+    total_ref = float(np.sqrt((gold["grad_norm"] ** 2).sum()))
+    err_sq, norm_sq = 0.0, 0.0
+    for i, n in enumerate(names):
+        gr = bank.params[n].grad.detach().double().cpu().reshape(-1)
+        p = (rademacher(n, gr.numel()).double() @ gr).numpy()
+        err_sq += float(np.mean((p - gold["grad_proj"][i]) ** 2))
+        norm_sq += float(gr.norm()) ** 2
+    rel = float(np.sqrt(err_sq)) / total_ref
+    loss_rel = abs(float(out["loss"]) - float(gold["loss"])) / abs(float(gold["loss"]))
+    logp_err = float(np.abs(out["token_logp"].detach().float().cpu().numpy() - gold["token_logp"]).max())
+    path = os.environ.get("COMAT_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"c1_full bfloat16 cuda grad_rel_err={rel:.3e} grad_norm_ratio={np.sqrt(norm_sq) / total_ref:.4f} "
+                    f"loss_rel={loss_rel:.3e} token_logp_maxerr={logp_err:.3e}\n")
+    assert np.isfinite(rel) and rel < BF16_FULL_GRAD_LIMIT, f"bf16 flat LoRA gradient: estimated rel. error {rel:.3e}"
+    assert abs(np.sqrt(norm_sq) / total_ref - 1.0) < BF16_FULL_GRAD_LIMIT
+    assert loss_rel < 2e-2 and logp_err < 0.25
 
 
 def test_c1_full_size_matches_oracle_golden(hip):
