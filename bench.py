@@ -44,15 +44,17 @@ F_UNET, F_VAE, F_BLIP = 0.839, 2.515, 0.408
 F_UNET_SDXL = 1.678  # SDXL UNet @64x64 latent incl. LoRA r=128, per sample forward
 
 
-def step_tflop(total_step, K, gan, sdxl=False):
+def step_tflop(total_step, K, gan, sdxl=False, res=512):
     """Algorithmic TFLOP of one step (SURVEY.md 8d counting convention).  The discriminator is the SD1.5 UNet in every
-    configuration (scripts of the reference)."""
-    fu = F_UNET_SDXL if sdxl else F_UNET
+    configuration (scripts of the reference).  The per-call figures are quoted at 512^2 (64^2 latents); at 1024^2 the
+    UNets and the VAE see 4x the positions (self-attention grows 16x: undercounted here), BLIP still sees 384^2."""
+    px = (res / 512.0) ** 2
+    fu = (F_UNET_SDXL if sdxl else F_UNET) * px
     nograd = (total_step - K) * 2 * fu
     train = K * 2 * fu * 2
-    f = nograd + train + F_VAE * 2 + F_BLIP * 2
+    f = nograd + train + F_VAE * px * 2 + F_BLIP * 2
     if gan:
-        f += F_UNET * 2 + 2 * F_UNET * 2
+        f += F_UNET * px * 2 + 2 * F_UNET * px * 2
     return f
 
 
@@ -89,7 +91,7 @@ class CallRecorder:
             if rec is None:
                 from comat_amd import _hip
                 kid = _hip.last_gemm_kernel() if name in ("gemm", "gemm_segments", "conv2d") else -1
-                self.calls[sig] = [name, a, kw, self._flops(name, a, kw), 1, kid]
+                self.calls[sig] = [name, a, kw, self._flops(name, a, kw), 1, kid, self._bytes(name, a, kw)]
             else:
                 rec[4] += 1
             return r
@@ -132,13 +134,33 @@ class CallRecorder:
             return 4.0 * a[5] * a[6] * a[7] * a[8] * a[9]
         return 10.0 * a[10] * a[11] * a[12] * a[13] * a[14]  # flash_attn_bwd: 5 products
 
+    @staticmethod
+    def _bytes(name, a, kw):
+        """algorithmic HBM bytes of one launch: every operand read once, the output written once"""
+        sz = lambda t: t.element_size()
+        if name == "gemm":
+            M, N, K = a[3], a[4], a[5]
+            b = kw.get("batch", (1, 1))
+            nb = b[0] * b[1]
+            r = M * N * sz(kw["R"]) if kw.get("R") is not None else 0
+            return nb * ((M * K + N * K) * sz(a[0]) + M * N * sz(a[2]) + r)
+        if name == "gemm_segments":
+            M, N, nb = a[2], a[3], kw.get("batch", 1)
+            r = M * N * sz(kw["R"]) if kw.get("R") is not None else 0
+            return nb * (sum((M + N) * sg[2] for sg in a[0]) * sz(a[0][0][0]) + M * N * sz(a[1]) + r)
+        if name == "conv2d":
+            B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW = a[3:12]
+            r = B * Hout * Wout * Cout * sz(kw["R"]) if kw.get("R") is not None else 0
+            return (B * Hin * Win * Cin + Cout * KH * KW * Cin) * sz(a[0]) + B * Hout * Wout * Cout * sz(a[2]) + r
+        return 0
+
     def measure(self, n=10):
         """-> {family: [seconds per step, flops per step, launches per step]}; family = kernel that served the problem"""
         from comat_amd import _hip
         side = torch.cuda.Stream()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fam, rows = {}, []
-        for sig, (name, a, kw, fl, count, kid) in self.calls.items():
+        for sig, (name, a, kw, fl, count, kid, nbytes) in self.calls.items():
             fn = getattr(self.inner, name)
             with torch.cuda.stream(side):  # workspaces of this stream exist before the capture
                 fn(*a, **kw)
@@ -158,10 +180,11 @@ class CallRecorder:
             del g
             family = _hip.GEMM_KERNEL_NAMES[kid] if kid >= 0 else ("flash_fwd_kernel" if name == "flash_attn_fwd"
                                                                    else "flash_bwd (dq + dkdv kernels)")
-            d = fam.setdefault(family, [0.0, 0.0, 0])
+            d = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
             d[0] += t * count
             d[1] += fl * count
             d[2] += count
+            d[3] += nbytes * count
             rows.append((t * count * 1e3, count, fl / t / 1e12, t * 1e6, family.split(" ")[0], sig))
         dump = os.environ.get("COMAT_BENCH_DUMP")
         if dump:
@@ -186,12 +209,18 @@ def build_world(device, dtype, rank, cfg_name):
     tiny = cfg_name == "selftest"
     if tiny:
         ucfg, vcfg, bcfg = config.TINY_UNET, config.TINY_VAE, config.TINY_BLIP
-    sdxl = cfg_name == "c4"
-    if sdxl:  # BASELINE config C4: SDXL generator at 512^2 (64^2 latents), SD1.5 discriminator, full CoMat losses
+    sdxl = cfg_name in ("c4", "c5")
+    res = 1024 if cfg_name == "c5" else 512
+    if sdxl:  # BASELINE config C4: SDXL generator at 512^2 (64^2 latents), SD1.5 discriminator, full CoMat losses;
+        # C5: the same at 1024^2 (128^2 latents) with the generator UNet's forward on the fp8 MFMA, bf16 backward
         from comat_amd.pipeline import TrainableSDXLPipeline
         ucfg, vcfg = config.SDXL_UNET, config.SDXL_VAE
-        scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True,
-                          train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
+        if cfg_name == "c5":
+            scfg = StepConfig(resolution=1024, total_step=50, K=5, gan_loss=True, attrcon=True,
+                              train_layer_ls=("mid_32", "up_32", "up_64"), attn_reses=(64, 32))
+        else:
+            scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True,
+                              train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
     elif tiny:
         scfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=False)
     elif cfg_name == "c2":
@@ -205,7 +234,7 @@ def build_world(device, dtype, rank, cfg_name):
     usd = weights.make_unet_weights(ucfg, seed=1234)
     lsd = weights.make_lora_weights(ucfg, seed=4321)
     bank = LoRABank(ucfg, lsd, dtype, device)
-    unet = UNet(ucfg, usd, dtype, device, bank)
+    unet = UNet(ucfg, usd, dtype, device, bank, fp8_forward=cfg_name == "c5")
     keep_for_cpu = usd if (rank == 0) else None
     vae = VAEDecoder(vcfg, weights.make_vae_weights(vcfg, seed=2345), dtype, device)
     blip = Blip(bcfg, weights.make_blip_weights(bcfg, seed=3456), dtype, device)
@@ -218,7 +247,7 @@ def build_world(device, dtype, rank, cfg_name):
     del dsd
     pipe = TrainableSDXLPipeline(unet, vae) if sdxl else TrainableSDPipeline(unet, vae)
     trainer = CoMatTrainer(pipe, bank, blip, disc, scfg, seed=rank)
-    if scfg.total_step > scfg.K and os.environ.get("COMAT_PRECAPTURE", "0") != "0":
+    if scfg.total_step > scfg.K and os.environ.get("COMAT_PRECAPTURE", "1") != "0" and torch.device(device).type == "cuda":
         trainer.pipe.prepare_graphs(1, scfg.resolution, scfg.resolution, 77, scfg.total_step)
     # synthetic batch; per-rank seeds differ (each rank has its own prompt)
     g = torch.Generator().manual_seed(1000 + rank)
@@ -241,15 +270,15 @@ def build_world(device, dtype, rank, cfg_name):
     if sdxl:
         batch.update(pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
                      negative_pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
-                     add_time_ids=(512, 512, 0, 0, 512, 512))
+                     add_time_ids=(res, res, 0, 0, res, res))
     if scfg.attrcon:
         import numpy as np
-        m = np.zeros((2, 512, 512), dtype=bool)
-        m[0, 60:250, 40:230] = True
-        m[1, 280:480, 260:500] = True
+        m = np.zeros((2, res, res), dtype=bool)
+        m[0, 60 * res // 512:250 * res // 512, 40 * res // 512:230 * res // 512] = True
+        m[1, 280 * res // 512:480 * res // 512, 260 * res // 512:500 * res // 512] = True
         batch["masks"] = [m]
         batch["attributes"] = [[[2, 3], [6, 7]]]
-    fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, 510, 510))
+    fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, res - 2, res - 2))
     if cfg_name == "c2":
         fixed["training_steps"] = [0, 1, 2, 3, 4]
     return trainer, batch, fixed, scfg, keep_for_cpu, time.time() - t0
@@ -371,7 +400,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -396,6 +425,8 @@ def main():
         ops.set_kernel_backend(_hip.HipKernels())
         sync = torch.cuda.synchronize
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if not args.selftest:
+        torch.cuda.set_per_process_memory_fraction(0.92)  # an over-sized configuration must fail as a Python OOM
     trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank,
                                                                 "selftest" if args.selftest else args.config)
 
@@ -500,8 +531,8 @@ def main():
             fam = rec.measure()
     if rank == 0 and not args.no_kernel_timing and not args.selftest:
         dom = max(fam, key=lambda k: fam[k][0])
-        t_dom, f_dom, n_dom = fam[dom]
-        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config == "c4")
+        t_dom, f_dom, n_dom, b_dom = fam[dom]
+        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config in ("c4", "c5"), res=scfg.resolution)
         pmc = load_pmc_summary()
         n_other = sum(rec.other.values())
         roofline = {
@@ -511,6 +542,7 @@ def main():
             "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
             "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r02_pmc_kernels.json)",
             "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
+            "algorithmic_bytes_per_launch": int(b_dom / n_dom),
             "launches_per_step": n_dom, "avg_launch_ms": t_dom / n_dom * 1e3,
             "algorithmic_tflop_per_step_in_kernel": f_dom / 1e12,
             "timing": "every distinct problem of one recorded step replayed back to back (hipGraph of 10 launches, HIP "
@@ -526,20 +558,23 @@ def main():
     if rank == 0 and not args.no_kernel_timing and not args.selftest:
         attn_map = attn_map_probe()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config != "c4" and not args.selftest:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)
     if rank == 0 and os.environ.get("COMAT_BENCH_LOGS"):  # loss terms of the last timed step (sanity evidence)
         print({k: (float(v) if torch.is_tensor(v) else v) for k, v in last_logs.items()}, file=sys.stderr)
     if rank == 0:
         out = {
-            "metric": f"CoMat train-step images/sec ({'SDXL' if args.config == 'c4' else 'SD1.5'} 512^2, bs=1/GPU)",
+            "metric": f"CoMat train-step images/sec ({'SDXL' if args.config in ('c4', 'c5') else 'SD1.5'} "
+                      f"{scfg.resolution}^2, bs=1/GPU)",
             "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if dtype == torch.bfloat16 else "f32",
+            "dtype": ("bf16 (fp8 e4m3 forward products of the generator UNet)" if args.config == "c5" else "bf16")
+            if dtype == torch.bfloat16 else "f32",
             "data": "SELFTEST (CPU simulator, tiny model): not a measurement" if args.selftest else "synthetic",
-            "config": {"workload": f"{args.config.upper()}: {'SDXL (SD1.5 discriminator)' if args.config == 'c4' else 'SD1.5'} "
-                                   f"512x512 bs=1/GPU, N={scfg.total_step} denoise steps "
+            "config": {"workload": f"{args.config.upper()}: "
+                                   f"{'SDXL (SD1.5 discriminator' + (', fp8 UNet forward)' if args.config == 'c5' else ')') if args.config in ('c4', 'c5') else 'SD1.5'} "
+                                   f"{scfg.resolution}x{scfg.resolution} bs=1/GPU, N={scfg.total_step} denoise steps "
                                    f"(K={scfg.K} with grad), CFG 7.5, LoRA r=128, concept-matching (BLIP-large) + GAN "
                                    f"fidelity (G+D step)" + (" + attribute concentration" if scfg.attrcon else "") +
                                    ", clip+AdamW for G and D",

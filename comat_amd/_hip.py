@@ -11,7 +11,7 @@ import os
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2  # COMAT_F32, COMAT_BF16, COMAT_FP8_E4M3
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 UN_COPY, UN_SILU, UN_GELU, UN_AFFINE = 0, 1, 2, 3
 
@@ -32,6 +32,7 @@ class GemmParams(C.Structure):
         ("transA", C.c_int32), ("transB", C.c_int32), ("act", C.c_int32),
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
     ]
 
 
@@ -51,6 +52,7 @@ class ConvParams(C.Structure):
         ("alpha", C.c_float), ("beta", C.c_float),
         ("act", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+        ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
     ]
 
 
@@ -98,6 +100,8 @@ SIGNATURES = {
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
     "comat_set_option": [C.c_char_p, _i32],
     "comat_last_gemm_kernel": [],
+    "comat_fp8_scale": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "comat_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
@@ -122,14 +126,14 @@ def load_library(path: str | None = None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, C.c_int)
-    if lib.comat_abi_version() != 2:
+    if lib.comat_abi_version() != 3:
         raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
 GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_kernel (LDS-DMA pipelined)",
-                     2: "gemm2_tt_kernel (pipelined, k-major operands)"}
+                     2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)"}
 
 
 def last_gemm_kernel() -> int:
@@ -155,6 +159,8 @@ def dt(t: torch.Tensor) -> int:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.uint8:  # fp8 e4m3 bytes (comat_fp8_quantize): operand dtype of gemm / conv2d only
+        return FP8
     raise TypeError(f"comat_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
 
 
@@ -205,7 +211,8 @@ class HipKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
              sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
-             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE):
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
+        """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h)"""
         p = GemmParams()
         p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(Cout)
         p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
@@ -225,6 +232,9 @@ class HipKernels:
         p.transA, p.transB, p.act = int(transA), int(transB), act
         assert A.dtype == B.dtype
         p.in_dtype, p.out_dtype = dt(A), dt(Cout)
+        assert (scales is not None) == (p.in_dtype == FP8), "fp8 operands come with their scales"
+        if scales is not None:
+            p.scale_a, p.scale_b = _ptr(scales[0]), _ptr(scales[1])
         p.r_dtype = dt(R) if R is not None else 0
         ws = self._workspace(A.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
@@ -260,7 +270,7 @@ class HipKernels:
                "comat_transpose_cast_tiles")
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
-               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
         p = ConvParams()
         p.X, p.W, p.Y = _ptr(X), _ptr(W), _ptr(Y)
         p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
@@ -273,10 +283,31 @@ class HipKernels:
         p.alpha, p.beta, p.act = alpha, beta, act
         assert X.dtype == W.dtype
         p.in_dtype, p.out_dtype = dt(X), dt(Y)
+        assert (scales is not None) == (p.in_dtype == FP8), "fp8 operands come with their scales"
+        if scales is not None:
+            p.scale_a, p.scale_b = _ptr(scales[0]), _ptr(scales[1])
         p.r_dtype = dt(R) if R is not None else 0
         ws = self._workspace(X.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_conv2d(C.byref(p), _stream()), "comat_conv2d")
+
+    # ---- fp8 operands ---------------------------------------------------------------------------------------
+    def fp8_quantize(self, x, out=None, scale=None):
+        """per-tensor e4m3 quantisation of a contiguous fp32 / bf16 tensor: -> (bytes [same shape] uint8, scale [1] fp32);
+        value = scale * fp8.  Two launches (abs-max -> scale, then the bytes)."""
+        assert x.is_contiguous()
+        n = x.numel()
+        key = ("fp8", x.device, _stream())
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = torch.zeros(2, dtype=torch.int32, device=x.device)  # ticket + running max, re-armed
+        if scale is None:
+            scale = torch.empty(1, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _check(_lib.comat_fp8_scale(_ptr(x), n, dt(x), _ptr(scale), _ptr(ws), _stream()), "comat_fp8_scale")
+        _check(_lib.comat_fp8_quantize(_ptr(x), n, dt(x), _ptr(scale), _ptr(out), _stream()), "comat_fp8_quantize")
+        return out, scale
 
     # ---- normalisation -------------------------------------------------------------------------------------
     def _gn_workspace(self, dev, B, G):

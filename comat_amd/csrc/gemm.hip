@@ -706,7 +706,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->A && p->B && p->C, "comat_gemm: null operand");
     COMAT_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "comat_gemm: bad shape M=%ld N=%ld K=%ld", (long)p->M,
                   (long)p->N, (long)p->K);
-    COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_gemm: bad dtype");
+    COMAT_REQUIRE((dtype_ok(p->in_dtype) || p->in_dtype == COMAT_FP8_E4M3) && dtype_ok(p->out_dtype), "comat_gemm: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_gemm: bad residual dtype");
     COMAT_REQUIRE(p->batch1 >= 1 && p->batch2 >= 1 && p->batch1 * p->batch2 <= 65535, "comat_gemm: bad batch");
     COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm: bias2 needs rows_per_bias2");
@@ -716,6 +716,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
+    COMAT_REQUIRE(p->in_dtype != COMAT_FP8_E4M3,
+                  "comat_gemm: fp8 operands need transA = transB = 0, K %% 64 == 0, 16-byte aligned rows, batch2 == 1");
     GemmArgs g;
     g.A = p->A; g.B = p->B;
     g.M = p->M; g.N = p->N; g.K = p->K; g.lda = p->lda; g.ldb = p->ldb;
@@ -812,11 +814,12 @@ extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
                       (int64_t)p->KH * p->KW * p->Cin < (1ll << 30),
                   "comat_conv2d: input tensor too large for 32-bit gather offsets");
     COMAT_REQUIRE(p->ups == 1 || (p->ups == 2 && p->mode == 0), "comat_conv2d: ups must be 1, or 2 with mode 0");
-    COMAT_REQUIRE(dtype_ok(p->in_dtype) && dtype_ok(p->out_dtype), "comat_conv2d: bad dtype");
+    COMAT_REQUIRE((dtype_ok(p->in_dtype) || p->in_dtype == COMAT_FP8_E4M3) && dtype_ok(p->out_dtype), "comat_conv2d: bad dtype");
     COMAT_REQUIRE(!p->R || dtype_ok(p->r_dtype), "comat_conv2d: bad residual dtype");
     const int rc2 = comat_gemm2_try_conv(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_conv2d");
+    COMAT_REQUIRE(p->in_dtype != COMAT_FP8_E4M3, "comat_conv2d: fp8 operands need mode 0, Cin %% 64 == 0, 16-byte aligned tensors");
     ConvArgs g;
     g.X = p->X; g.W = p->W;
     g.geo.B = p->B; g.geo.Hin = p->Hin; g.geo.Win = p->Win; g.geo.Cin = p->Cin;

@@ -28,16 +28,16 @@
 
 namespace {
 
-constexpr int BK = 32;       // k elements per k-tile
-constexpr int RB = 64;       // bytes per LDS row
+constexpr int BK = 32;       // bf16 k elements per k-tile
+constexpr int RB = 64;       // bytes per LDS row = bytes of k per k-tile (32 bf16, or 64 fp8 e4m3)
 constexpr int MAXSEG2 = 8;
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];  // zero-initialised: source of padding taps
 
 struct Seg2 {
-    const bf16_t* A;
-    const bf16_t* B;
-    int64_t lda, ldb, sA, sB;
+    const char* A;
+    const char* B;
+    int64_t lda, ldb, sA, sB;  // in BYTES (the host multiplies the element strides by the element size)
     int nkt;  // k-tiles of this segment
 };
 
@@ -53,6 +53,8 @@ struct Args2 {
     float* ws;
     Epi ep;
     int vec;  // 16-byte epilogue accesses are legal (alignment / divisibility checked by the host)
+    const float* scale_a;  // fp8 operands: device pointers to the per-tensor dequantisation scales (NULL = 1)
+    const float* scale_b;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -71,6 +73,21 @@ __device__ __forceinline__ void mma_t(f32x16_t& acc, const short8_t& wfrag, cons
     // D[n][m] += W[n][k] X[m][k]: A operand = weight fragment (lane&31 = n), B operand = activation fragment (lane&31 = m)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfrag), __builtin_bit_cast(bf16x8_t, xfrag),
                                                   acc, 0, 0, 0);
+}
+
+// fp8 (OCP e4m3): one 32x32x64 MFMA consumes the whole 64-byte k-tile; lane (r, h) supplies the two 16-byte chunks it
+// would read for bf16 k-steps 0 and 1 (chunks h and 2 + h of row r) as ONE 32-byte operand.  The instruction's own
+// lane -> k assignment is the same for A and B, so - as for bf16 - the k-permutation cancels.  Block scales are unused
+// (scale 0 selects the unscaled v_mfma_f32_32x32x64_f8f6f4 form); per-tensor scales are applied in the epilogue.
+__device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, const short8_t& w1, const short8_t& x0,
+                                          const short8_t& x1) {
+    typedef int v8i __attribute__((ext_vector_type(8)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i wa = __builtin_bit_cast(v4i, w0), wb = __builtin_bit_cast(v4i, w1);
+    const v4i xa = __builtin_bit_cast(v4i, x0), xb = __builtin_bit_cast(v4i, x1);
+    const v8i wv = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
+    const v8i xv = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc, 0 /* A: fp8 e4m3 */, 0 /* B: fp8 e4m3 */, 0, 0, 0, 0);
 }
 
 // lanes 32..63 of `lo` <-> lanes 0..31 of `hi`
@@ -195,6 +212,8 @@ __device__ __forceinline__ void g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     // of the (b)-th 32-column tile.  Half-swapping quad 0 <-> 1 and 2 <-> 3 gives lane h = 0 columns 0..7 and 16..23,
     // lane h = 1 columns 8..15 and 24..31 ----
     Epi ep = g.ep;
+    if (g.scale_a) ep.alpha *= *g.scale_a;
+    if (g.scale_b) ep.alpha *= *g.scale_b;
     ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
     if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
     if (ep.bias) ep.bias += z * g.sBias;
@@ -223,8 +242,10 @@ __device__ __forceinline__ void g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
 
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles; NST-deep LDS ring.
 // CONV: implicit-GEMM gather.
-template <int BM, int BN, int WM, int WN, int NST, bool CONV>
+// EB: bytes per operand element (2 = bf16, 1 = fp8 e4m3); a k-tile is always 64 bytes of k.
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
+    constexpr int KE = RB / EB;  // k elements per k-tile
     constexpr int NW = WM * WN, NTH = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr int IA = BM / (16 * NW), IB = BN / (16 * NW);  // DMA instructions per wave per k-tile, per operand
@@ -261,9 +282,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     // slot ^ ((row >> 2) & 3) of that row (the LDS swizzle, applied on the source side) ----
     const int drow = lane >> 2;
     const int csrc = (lane & 3) ^ ((drow >> 2) & 3);
-    const bf16_t* pb[IB];   // running source pointers, B operand
+    const char* pb[IB];     // running source pointers, B operand
     int64_t brow_[IB];      // clamped global row of the lane's B chunk
-    const bf16_t* pa[IA];   // GEMM: running source pointers, A operand
+    const char* pa[IA];     // GEMM: running source pointers, A operand
     int64_t arow_[IA];      // GEMM: clamped global row
     int by[IA], bx[IA], bb[IA];  // CONV: oy*stride - pad, ox*stride - pad (upsampled coordinates), b * Hin
     bool rv[IA];
@@ -288,13 +309,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
             by[i] = oy * g.stride - g.pad;
             bx[i] = ox * g.stride - g.pad;
         }
-        const int k0 = kt0 * BK;
+        const int k0 = kt0 * KE;
         const int tap = k0 / g.Cin;
         ci0 = k0 - tap * g.Cin;
         ky = tap / g.KW;
         kx = tap - ky * g.KW;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) pb[i] = g.seg[0].B + brow_[i] * g.seg[0].ldb + k0 + csrc * 8;
+        for (int i = 0; i < IB; ++i) pb[i] = g.seg[0].B + brow_[i] * g.seg[0].ldb + (int64_t)kt0 * RB + csrc * 16;
     } else {
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
@@ -311,9 +332,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
         seg_left = g.seg[seg].nkt - t0;
         const Seg2 sg = g.seg[seg];
 #pragma unroll
-        for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + t0 * BK + csrc * 8;
+        for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + (int64_t)t0 * RB + csrc * 16;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + t0 * BK + csrc * 8;
+        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + (int64_t)t0 * RB + csrc * 16;
     }
 
     // issue the DMA of the next k-tile of this block's range into ring stage `st`
@@ -329,11 +350,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
                     sy >>= 1;
                     sx >>= 1;
                 }
-                const int off = ((bb[i] + sy) * g.Win + sx) * g.Cin + ci0 + csrc * 8;
+                const int off = (((bb[i] + sy) * g.Win + sx) * g.Cin + ci0) * EB + csrc * 16;  // bytes (host: < 2^31)
                 const void* src = ok ? (const void*)(g.seg[0].A + off) : (const void*)(g_zero_page + (lane & 15) * 16);
                 dma16(src, sbase + i * NW * 1024);
             }
-            ci0 += BK;
+            ci0 += KE;
             if (ci0 >= g.Cin) {
                 ci0 = 0;
                 if (++kx == g.KW) {
@@ -347,21 +368,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
                 const Seg2 sg = g.seg[seg];
                 seg_left = sg.nkt;
 #pragma unroll
-                for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + csrc * 8;
+                for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + csrc * 16;
 #pragma unroll
-                for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + csrc * 8;
+                for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + csrc * 16;
             }
             --seg_left;
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 dma16(pa[i], sbase + i * NW * 1024);
-                pa[i] += BK;
+                pa[i] += RB;
             }
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             dma16(pb[i], sbase + BM * RB + i * NW * 1024);
-            pb[i] += BK;
+            pb[i] += RB;
         }
     };
 
@@ -397,6 +418,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf[b], xf[a]);
     };
+    auto mmas8 = [&](const short8_t (&x0)[TM], const short8_t (&w0)[TN], const short8_t (&x1)[TM], const short8_t (&w1)[TN]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) mma_t_fp8(acc[a][b], w0[b], w1[b], x0[a], x1[a]);
+    };
 #pragma unroll
     for (int u = 0; u < NST - 1; ++u)
         if (u < nt) issue(u);
@@ -408,22 +435,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
         frags(smem, fo0, xf0, wf0);
     }
     int stage = 0;  // ring slot of tile t
-    for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
-        frags(smem + stage * SS, fo1, xf1, wf1);
-        mmas(xf0, wf0);
-        const int nstage = stage + 1 == NST ? 0 : stage + 1;
-        wait_tiles<L, NST - 3>(nt - 2 - t);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);  // the slot of tile t-1
-        frags(smem + nstage * SS, fo0, xf0, wf0);
-        mmas(xf1, wf1);
-        stage = nstage;
-    }
-    if (nt > 0) {  // last tile
-        frags(smem + stage * SS, fo1, xf1, wf1);
-        mmas(xf0, wf0);
-        mmas(xf1, wf1);
+    if constexpr (EB == 2) {
+        for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
+            frags(smem + stage * SS, fo1, xf1, wf1);
+            mmas(xf0, wf0);
+            const int nstage = stage + 1 == NST ? 0 : stage + 1;
+            wait_tiles<L, NST - 3>(nt - 2 - t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);  // the slot of tile t-1
+            frags(smem + nstage * SS, fo0, xf0, wf0);
+            mmas(xf1, wf1);
+            stage = nstage;
+        }
+        if (nt > 0) {  // last tile
+            frags(smem + stage * SS, fo1, xf1, wf1);
+            mmas(xf0, wf0);
+            mmas(xf1, wf1);
+        }
+    } else {
+        // fp8: one 32x32x64 MFMA per tile pair and k-tile.  Same ring protocol; the second half of tile t's fragments and
+        // the first half of tile t+1's are requested before the MFMAs of tile t issue.
+        short8_t xn[TM], wn[TN];
+        for (int t = 0; t + 1 < nt; ++t) {
+            frags(smem + stage * SS, fo1, xf1, wf1);
+            const int nstage = stage + 1 == NST ? 0 : stage + 1;
+            wait_tiles<L, NST - 3>(nt - 2 - t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);
+            frags(smem + nstage * SS, fo0, xn, wn);
+            mmas8(xf0, wf0, xf1, wf1);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) xf0[a] = xn[a];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) wf0[b] = wn[b];
+            stage = nstage;
+        }
+        if (nt > 0) {
+            frags(smem + stage * SS, fo1, xf1, wf1);
+            mmas8(xf0, wf0, xf1, wf1);
+        }
     }
 
     g2_finish<TM, TN, WTM, WTN, NTH>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
@@ -484,13 +536,13 @@ template <int NST> __global__ __launch_bounds__(256) void gemm2_tt_kernel(Args2 
     int64_t ca = m0 + chunk * 8, cb = n0 + chunk * 8;
     if (ca > g.M - 8) ca = g.M - 8;
     if (cb > g.N - 8) cb = g.N - 8;
-    const bf16_t* pa[IO];
-    const bf16_t* pb[IO];
+    const char* pa[IO];
+    const char* pb[IO];
 #pragma unroll
     for (int i = 0; i < IO; ++i) {
         const int64_t krow = (int64_t)kt0 * BK + (i * NW + wave) * 4 + kr;
-        pa[i] = sg.A + z * sg.sA + krow * sg.lda + ca;
-        pb[i] = sg.B + z * sg.sB + krow * sg.ldb + cb;
+        pa[i] = sg.A + z * sg.sA + krow * sg.lda + ca * 2;
+        pb[i] = sg.B + z * sg.sB + krow * sg.ldb + cb * 2;
     }
     const int64_t stepa = (int64_t)BK * sg.lda, stepb = (int64_t)BK * sg.ldb;
     auto issue = [&](int st) {
@@ -597,16 +649,16 @@ static Cfg2 cfg_dims(int c) {
 
 // tile, waves, ring depth (LDS = depth * (BM + BN) * 64 B): 128x128 / 4 deep = 64 KB (two blocks per CU), 128x64 and
 // 64x128 / 6 deep = 72 KB (two per CU), 256x128 / 4 deep = 96 KB and 128x128 / 6 deep = 96 KB (one per CU), 64x64 / 8
-template <bool CONV> static void launch_cfg(int c, const Args2& a, unsigned blocks, hipStream_t st) {
+template <bool CONV, int EB> static void launch_cfg(int c, const Args2& a, unsigned blocks, hipStream_t st) {
     switch (c) {
-        case CFG_128x64: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_256x128: hipLaunchKernelGGL((gemm2_kernel<256, 128, 4, 2, 4, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
-        case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 6, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x64: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, 6, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_256x128: hipLaunchKernelGGL((gemm2_kernel<256, 128, 4, 2, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_64x128: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 6, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 6, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
         case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
-            hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV>), dim3(blocks), dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV>), dim3(blocks), dim3(256), 0, st, a); break;
+            hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
 
@@ -634,12 +686,13 @@ struct Plan2Entry {
 };
 #include "gemm2_plans.inc"
 
-static void plan2(bool conv, int64_t M, int64_t N, int nkt, int64_t batch, int64_t ws_bytes, int* cfg_out, int* splits_out) {
+static void plan2(bool conv, bool fp8, int64_t M, int64_t N, int nkt, int64_t batch, int64_t ws_bytes, int* cfg_out,
+                  int* splits_out) {
     int fc = 0, fs = 0;
     g2_overrides(&fc, &fs);
     int c = fc;
     int64_t s = fs;
-    if (c == CFG_AUTO) {
+    if (c == CFG_AUTO && !fp8) {  // the table was measured with bf16 operands
         for (size_t i = 0; i < sizeof(g2_plans) / sizeof(g2_plans[0]); ++i) {
             const Plan2Entry& e = g2_plans[i];
             if (e.conv == (conv ? 1 : 0) && e.M == M && e.N == N && e.nkt == nkt && e.batch == batch) {
@@ -700,9 +753,9 @@ static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t 
     return 1;
 }
 
-static int finish_launch(Args2& a, bool conv, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
+static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
     int c, s;
-    plan2(conv, a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
+    plan2(conv, fp8, a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
     const Cfg2 d = cfg_dims(c);
     a.tiles_m = (int)cdiv64(a.M, d.bm);
     a.tiles_n = (int)cdiv64(a.N, d.bn);
@@ -712,8 +765,13 @@ static int finish_launch(Args2& a, bool conv, int64_t batch, void* ws, int64_t w
     const int64_t blocks = a.ntiles * s;
     if (blocks >= (1ll << 31)) return 0;
     a.vec = epi_vec_ok(a.ep, a.N, a.sC, a.sR, a.sBias, a.M);
-    if (conv) launch_cfg<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
-    else launch_cfg<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
+    if (fp8) {
+        if (conv) launch_cfg<true, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        else launch_cfg<false, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        return 3;
+    }
+    if (conv) launch_cfg<true, 2>(c, a, (unsigned)blocks, (hipStream_t)stream);
+    else launch_cfg<false, 2>(c, a, (unsigned)blocks, (hipStream_t)stream);
     return 1;
 }
 
@@ -725,8 +783,8 @@ static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
     if (p->batch1 > 1 && (p->sA1 % 8 || p->sB1 % 8)) return 0;
     if (p->K < 256 || p->M >= (1ll << 31) || p->N >= (1ll << 31) || !p->ws) return 0;
     Args2 a = {};
-    a.seg[0].A = (const bf16_t*)p->A; a.seg[0].B = (const bf16_t*)p->B;
-    a.seg[0].lda = p->lda; a.seg[0].ldb = p->ldb; a.seg[0].sA = p->sA1; a.seg[0].sB = p->sB1;
+    a.seg[0].A = (const char*)p->A; a.seg[0].B = (const char*)p->B;
+    a.seg[0].lda = p->lda * 2; a.seg[0].ldb = p->ldb * 2; a.seg[0].sA = p->sA1 * 2; a.seg[0].sB = p->sB1 * 2;
     a.seg[0].nkt = (int)(p->K / BK);
     a.nseg = 1;
     a.nkt = a.seg[0].nkt;
@@ -754,23 +812,29 @@ static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
     return 2;
 }
 
+// fp8 (e4m3) operands run ONLY here (the general kernel has no fp8 path): an ineligible fp8 problem is an error of the
+// caller, reported by gemm.hip.  EB = element bytes; a 16-byte chunk holds 16 / EB elements, a k-tile 64 / EB.
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
-    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->batch2 != 1) return 0;
-    if (p->transA && p->transB) return comat_option(COMAT_OPT_GEMM2_TT) ? try_gemm_tt(p, stream) : 0;
+    const bool fp8 = p->in_dtype == COMAT_FP8_E4M3;
+    if ((!g2_enabled() && !fp8) || (p->in_dtype != COMAT_BF16 && !fp8) || p->batch2 != 1) return 0;
+    if (p->transA && p->transB) return (!fp8 && comat_option(COMAT_OPT_GEMM2_TT)) ? try_gemm_tt(p, stream) : 0;
     if (p->transA || p->transB) return 0;
-    if (p->K % BK || p->lda % 8 || p->ldb % 8 || !al16(p->A) || !al16(p->B)) return 0;
-    if (p->batch1 > 1 && (p->sA1 % 8 || p->sB1 % 8)) return 0;
-    if (p->M < 48 || p->M >= (1ll << 31) || p->N >= (1ll << 31)) return 0;  // skinny problems: the 64x64 kernel + split-K
+    const int eb = fp8 ? 1 : 2, ch = 16 / eb, ke = RB / eb;
+    if (p->K % ke || p->lda % ch || p->ldb % ch || !al16(p->A) || !al16(p->B)) return 0;
+    if (p->batch1 > 1 && (p->sA1 % ch || p->sB1 % ch)) return 0;
+    if ((p->M < 48 && !fp8) || p->M >= (1ll << 31) || p->N >= (1ll << 31)) return 0;  // skinny: the 64x64 kernel + split-K
     Args2 a = {};
-    a.seg[0].A = (const bf16_t*)p->A; a.seg[0].B = (const bf16_t*)p->B;
-    a.seg[0].lda = p->lda; a.seg[0].ldb = p->ldb; a.seg[0].sA = p->sA1; a.seg[0].sB = p->sB1;
-    a.seg[0].nkt = (int)(p->K / BK);
+    a.seg[0].A = (const char*)p->A; a.seg[0].B = (const char*)p->B;
+    a.seg[0].lda = p->lda * eb; a.seg[0].ldb = p->ldb * eb; a.seg[0].sA = p->sA1 * eb; a.seg[0].sB = p->sB1 * eb;
+    a.seg[0].nkt = (int)(p->K / ke);
     a.nseg = 1;
     a.nkt = a.seg[0].nkt;
     a.M = p->M; a.N = p->N;
     a.sC = p->sC1; a.sR = p->sR1; a.sBias = 0;
+    a.scale_a = fp8 ? p->scale_a : nullptr;
+    a.scale_b = fp8 ? p->scale_b : nullptr;
     fill_epi(a, p);
-    return finish_launch(a, false, p->batch1, p->ws, p->ws_bytes, stream);
+    return finish_launch(a, false, fp8, p->batch1, p->ws, p->ws_bytes, stream);
 }
 
 int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream) {
@@ -782,8 +846,8 @@ int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segmen
     for (int s = 0; s < nseg; ++s) {
         if (segs[s].K % BK || segs[s].lda % 8 || segs[s].ldb % 8 || !al16(segs[s].A) || !al16(segs[s].B)) return 0;
         if (batch > 1 && (segs[s].sA % 8 || segs[s].sB % 8)) return 0;
-        a.seg[s].A = (const bf16_t*)segs[s].A; a.seg[s].B = (const bf16_t*)segs[s].B;
-        a.seg[s].lda = segs[s].lda; a.seg[s].ldb = segs[s].ldb; a.seg[s].sA = segs[s].sA; a.seg[s].sB = segs[s].sB;
+        a.seg[s].A = (const char*)segs[s].A; a.seg[s].B = (const char*)segs[s].B;
+        a.seg[s].lda = segs[s].lda * 2; a.seg[s].ldb = segs[s].ldb * 2; a.seg[s].sA = segs[s].sA * 2; a.seg[s].sB = segs[s].sB * 2;
         a.seg[s].nkt = (int)(segs[s].K / BK);
         nkt += a.seg[s].nkt;
     }
@@ -793,18 +857,23 @@ int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segmen
     a.M = p->M; a.N = p->N;
     a.sC = p->sC1; a.sR = p->sR1; a.sBias = p->bias ? p->N : 0;
     fill_epi(a, p);
-    return finish_launch(a, false, batch, p->ws, p->ws_bytes, stream);
+    return finish_launch(a, false, false, batch, p->ws, p->ws_bytes, stream);
 }
 
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
-    if (!g2_enabled() || p->in_dtype != COMAT_BF16 || p->mode != 0 || p->Cin % BK) return 0;
+    const bool fp8 = p->in_dtype == COMAT_FP8_E4M3;
+    const int eb = fp8 ? 1 : 2, ke = RB / eb;
+    if ((!g2_enabled() && !fp8) || (p->in_dtype != COMAT_BF16 && !fp8) || p->mode != 0 || p->Cin % ke) return 0;
     if (!al16(p->X) || !al16(p->W)) return 0;
     const int64_t M = (int64_t)p->B * p->Hout * p->Wout;
     const int64_t K = (int64_t)p->KH * p->KW * p->Cin;
-    if (M < 48 || M >= (1ll << 31)) return 0;
+    if ((M < 48 && !fp8) || M >= (1ll << 31)) return 0;
+    if ((int64_t)p->B * p->Hin * p->Win * p->Cin * eb >= (1ll << 31)) return 0;  // 32-bit byte offsets of the gather
     Args2 a = {};
-    a.seg[0].A = (const bf16_t*)p->X; a.seg[0].B = (const bf16_t*)p->W;
-    a.seg[0].lda = 0; a.seg[0].ldb = K; a.seg[0].nkt = (int)(K / BK);
+    a.seg[0].A = (const char*)p->X; a.seg[0].B = (const char*)p->W;
+    a.seg[0].lda = 0; a.seg[0].ldb = K * eb; a.seg[0].nkt = (int)(K / ke);
+    a.scale_a = fp8 ? p->scale_a : nullptr;
+    a.scale_b = fp8 ? p->scale_b : nullptr;
     a.nseg = 1;
     a.nkt = a.seg[0].nkt;
     a.Hin = p->Hin; a.Win = p->Win; a.Cin = p->Cin; a.Hout = p->Hout; a.Wout = p->Wout;
@@ -815,5 +884,5 @@ int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
     a.ep.ldc = p->Cout; a.ep.ldr = p->Cout; a.ep.rows_per_b2 = (int64_t)p->Hout * p->Wout;
     a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
-    return finish_launch(a, true, 1, p->ws, p->ws_bytes, stream);
+    return finish_launch(a, true, fp8, 1, p->ws, p->ws_bytes, stream);
 }

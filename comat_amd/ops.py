@@ -116,6 +116,49 @@ def reset_side_stream_state():
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# fp8 forward (BASELINE.json configs[4]: "fp8 MFMA UNet forward with bf16 backward")
+# ----------------------------------------------------------------------------------------------------------------
+# Inside `with fp8_forward(True)` the FORWARD product of every frozen Linear / conv that was tagged `allow_fp8` (the
+# generator UNet's block layers, comat_amd/unet.py) and whose contraction length per tap is a multiple of 64 runs on
+# the fp8 (OCP e4m3) MFMA: the activation is quantised per tensor on the fly (abs-max scale), the frozen weight once.
+# The LoRA branch, the attention products, norms and every BACKWARD product stay in the storage dtype and use the
+# unquantised saved activations and weights: gradients are those of the bf16 network evaluated at the fp8 forward's
+# activations (the usual straight-through treatment of the quantiser).
+_fp8_on = False
+
+
+class fp8_forward:
+    def __init__(self, flag=True):
+        self.flag = bool(flag)
+
+    def __enter__(self):
+        global _fp8_on
+        self.prev, _fp8_on = _fp8_on, self.flag
+        return self
+
+    def __exit__(self, *exc):
+        global _fp8_on
+        _fp8_on = self.prev
+        return False
+
+
+def fp8_eligible(holder, k_inner):
+    return bool(getattr(holder, "allow_fp8", False)) and k_inner % 64 == 0
+
+
+def _use_fp8(holder, k_inner):
+    return _fp8_on and fp8_eligible(holder, k_inner)
+
+
+def fp8_weight(holder):
+    """(e4m3 bytes, scale) of a frozen weight in its forward orientation, quantised once (frozen: never refreshed)"""
+    w8 = getattr(holder, "_w8", None)
+    if w8 is None:
+        w8 = holder._w8 = kernels().fp8_quantize(holder.w.contiguous())
+    return w8
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # parameter holders
 # ----------------------------------------------------------------------------------------------------------------
 class FrozenLinear:
@@ -536,8 +579,15 @@ class _Linear(Function):
         y = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
         if residual is not None:
             residual = _c(residual)
-        kernels().gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
-                       beta=1.0 if residual is not None else 0.0, act=act)
+        if _use_fp8(lin, Kd):
+            k = kernels()
+            x8, sx = k.fp8_quantize(x)
+            w8, sw = fp8_weight(lin)
+            k.gemm(x8, w8, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
+                   beta=1.0 if residual is not None else 0.0, act=act, scales=(sx, sw))
+        else:
+            kernels().gemm(x, lin.w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
+                           beta=1.0 if residual is not None else 0.0, act=act)
         ctx.lin = lin
         ctx.has_res = residual is not None
         ctx.shape = (M, N, Kd)
@@ -599,7 +649,24 @@ class _LoRAGroupLinear(Function):
             assert G == 1
             residual = _c(residual)
         sw, su = _uniform_stride([lin.w for lin in lins]), _uniform_stride(ucs)
-        if sw is not None and su is not None and residual is None and all(lin.bias is None for lin in lins):
+        use8 = [_use_fp8(lin, Kd) for lin in lins]
+        if any(use8):
+            # frozen part on the fp8 MFMA (x quantised once for the whole group), low-rank part added in the storage dtype
+            x8, sx = k.fp8_quantize(x)
+            ys = []
+            for i, lin in enumerate(lins):
+                N = lin.out_features
+                y = x.new_empty((M, N))
+                beta = 1.0 if residual is not None else 0.0
+                if use8[i]:
+                    w8, sw8 = fp8_weight(lin)
+                    k.gemm(x8, w8, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=beta, scales=(sx, sw8))
+                    k.gemm(h[:, i * r:(i + 1) * r], ucs[i], y, M, N, r, Gr, r, N, R=y, ldr=N, beta=1.0)
+                else:
+                    k.gemm_segments([(x, lin.w, Kd, Kd, Kd), (h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r)], y, M, N, N,
+                                    bias=lin.bias, R=residual, ldr=N, beta=beta)
+                ys.append(y)
+        elif sw is not None and su is not None and residual is None and all(lin.bias is None for lin in lins):
             # co-allocated frozen weights (frozen_linear_group) + adjacent up factors: ONE batched launch for the group
             N = lins[0].out_features
             ys = x.new_empty((G, M, N))
@@ -738,9 +805,17 @@ class _Conv(Function):
         y = x.new_empty((B * Ho * Wo, conv.cout))
         if residual is not None:
             residual = _c(residual)
-        kernels().conv2d(x, conv.w, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad,
-                         mode=0, ups=ups, bias=conv.bias, bias2=bias2, R=residual,
-                         beta=1.0 if residual is not None else 0.0)
+        if _use_fp8(conv, conv.cin):
+            k = kernels()
+            x8, sx = k.fp8_quantize(x)
+            w8, sw = fp8_weight(conv)
+            k.conv2d(x8, w8, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad, mode=0,
+                     ups=ups, bias=conv.bias, bias2=bias2, R=residual, beta=1.0 if residual is not None else 0.0,
+                     scales=(sx, sw))
+        else:
+            kernels().conv2d(x, conv.w, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad,
+                             mode=0, ups=ups, bias=conv.bias, bias2=bias2, R=residual,
+                             beta=1.0 if residual is not None else 0.0)
         ctx.conv, ctx.geo = conv, (B, H, W, Ho, Wo, ups)
         ctx.has_res = residual is not None
         return y

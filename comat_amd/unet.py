@@ -68,28 +68,41 @@ class LoRABank(ops.LoRAStore):
 class _Mods:
     """Weight containers built from a diffusers-named state dict."""
 
-    def __init__(self, sd, dtype, device):
+    NO_FP8 = ("time_emb", "add_embedding", "conv_in", "conv_out")  # embeddings and the first / last conv stay exact
+
+    def __init__(self, sd, dtype, device, fp8=False):
+        """fp8: False, True (every eligible block layer) or a tuple of name fragments (only layers whose state-dict name
+        contains one of them: per-category parity tests)"""
         self.sd, self.dtype, self.device = sd, dtype, device
+        self.fp8, self.made = fp8, []
+
+    def _tag(self, obj, name):
+        obj.allow_fp8 = (bool(self.fp8) and not any(s in name for s in self.NO_FP8)
+                         and (self.fp8 is True or any(s in name for s in self.fp8)))
+        self.made.append(obj)
+        return obj
 
     def lin(self, name):
-        return ops.FrozenLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device)
+        return self._tag(ops.FrozenLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device),
+                         name)
 
     def lin_group(self, names):
         """projections that read the same input: one co-allocated weight buffer when their shapes agree"""
         ws = [self.sd[n + ".weight"] for n in names]
         if len(names) > 1 and all(tuple(w.shape) == tuple(ws[0].shape) for w in ws):
-            return ops.frozen_linear_group(ws, [self.sd.get(n + ".bias") for n in names], self.dtype, self.device)
+            grp = ops.frozen_linear_group(ws, [self.sd.get(n + ".bias") for n in names], self.dtype, self.device)
+            return [self._tag(g, n) for g, n in zip(grp, names)]
         return [self.lin(n) for n in names]
 
     def conv(self, name, stride=1, pad=1):
-        return ops.FrozenConv(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device,
-                              stride=stride, pad=pad)
+        return self._tag(ops.FrozenConv(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device,
+                                        stride=stride, pad=pad), name)
 
     def conv1x1(self, name):
         """1x1 conv (weight [Co,Ci,1,1]) or nn.Linear (weight [Co,Ci]) — the same GEMM on channels-last tokens."""
         w = self.sd[name + ".weight"]
-        return ops.FrozenLinear(w.reshape(w.shape[0], w.shape[1]), self.sd.get(name + ".bias"), self.dtype,
-                                self.device)
+        return self._tag(ops.FrozenLinear(w.reshape(w.shape[0], w.shape[1]), self.sd.get(name + ".bias"), self.dtype,
+                                          self.device), name)
 
     def norm(self, name):
         f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -182,9 +195,15 @@ class CrossAttnBlock:
 
 
 class UNet:
-    def __init__(self, cfg: UNetConfig, sd: dict, dtype=torch.bfloat16, device="cuda", lora: LoRABank | None = None):
+    def __init__(self, cfg: UNetConfig, sd: dict, dtype=torch.bfloat16, device="cuda", lora: LoRABank | None = None,
+                 fp8_forward=False):
+        """fp8_forward: BASELINE.json configs[4] - the forward products of the frozen block layers (resnet convs,
+        down / upsamplers, proj_in / proj_out, attention projections, feed-forward) run on the fp8 MFMA with per-tensor
+        scales (ops.fp8_forward); embeddings, conv_in / conv_out, LoRA, attention and every backward product do not.
+        A tuple of name fragments restricts it to the layers whose state-dict name contains one of them."""
         self.cfg, self.dtype, self.device, self.lora = cfg, dtype, device, lora
-        m = _Mods(sd, dtype, device)
+        self.fp8 = bool(fp8_forward)
+        m = _Mods(sd, dtype, device, fp8=fp8_forward if isinstance(fp8_forward, tuple) else self.fp8)
         g = cfg.norm_groups
         self.t1, self.t2 = m.lin("time_embedding.linear_1"), m.lin("time_embedding.linear_2")
         if cfg.addition_embed:
@@ -211,6 +230,10 @@ class UNet:
         self.conv_out = m.conv("conv_out")
         self._temb_cache = {}
         self._te_cache = {}
+        if self.fp8:  # quantise the frozen weights now (once), not inside the first step or a graph capture
+            for o in m.made:
+                if ops.fp8_eligible(o, o.cin if isinstance(o, ops.FrozenConv) else o.in_features):
+                    ops.fp8_weight(o)
 
     def added_embedding(self, text_embeds, time_ids):
         """SDXL `text_time` conditioning (TrainableSDPipeline.py:772-784,807): add_embedding([pooled text |
@@ -258,6 +281,10 @@ class UNet:
         SDXL: added = (text_embeds [B, pooled], time_ids [B, 6]), or the precomputed `added_embedding(...)` tensor.
         kv_cache: a dict owned by the caller for ONE sampler invocation (LoRA factors and `ctx` must not change while
         it lives): the cross-attention key / value projections of `ctx` are computed once and shared by its calls."""
+        with ops.fp8_forward(self.fp8):
+            return self._forward(x, B, H, W, t, ctx, L, capture_places, added, kv_cache)
+
+    def _forward(self, x, B, H, W, t, ctx, L, capture_places, added, kv_cache):
         cfg = self.cfg
         temb_act = self._time_embedding(t, B, added)
         maps = {p: [] for p in capture_places}

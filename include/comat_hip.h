@@ -23,9 +23,10 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 2
+#define COMAT_ABI_VERSION 3
 
-enum { COMAT_F32 = 0, COMAT_BF16 = 1 };
+enum { COMAT_F32 = 0, COMAT_BF16 = 1,
+       COMAT_FP8_E4M3 = 2 /* OCP e4m3fn bytes; operand dtype of comat_gemm / comat_conv2d only (comat_fp8_quantize) */ };
 enum { COMAT_OK = 0, COMAT_EINVAL = -1, COMAT_ELAUNCH = -2, COMAT_EUNSUPPORTED = -3 };
 enum { COMAT_ACT_NONE = 0, COMAT_ACT_SILU = 1, COMAT_ACT_GELU = 2 };
 
@@ -37,7 +38,8 @@ const char* comat_last_error(void);
  * differ at most in floating-point summation order. */
 int comat_set_option(const char* name, int32_t value);
 /* Which kernel served the calling thread's last comat_gemm / comat_gemm_segments / comat_conv2d call: 0 the general
- * 64x64 kernel, 1 the LDS-DMA pipelined kernel, 2 its k-major (transA && transB) variant; -1 before the first call.
+ * 64x64 kernel, 1 the LDS-DMA pipelined kernel, 2 its k-major (transA && transB) variant, 3 its fp8 (e4m3, 32x32x64
+ * MFMA) variant; -1 before the first call.
  * bench.py and the tests use it to attribute time and to assert that a problem runs on the kernel the docs say. */
 int comat_last_gemm_kernel(void);
 
@@ -70,6 +72,11 @@ typedef struct {
     int32_t r_dtype;    /* dtype of R */
     void* ws;           /* optional caller-owned split-K workspace (NULL: never split), see below */
     int64_t ws_bytes;
+    /* in_dtype == COMAT_FP8_E4M3: device pointers to the per-tensor dequantisation scales of A and B (value = scale *
+     * fp8), NULL = 1.  The product is scaled by *scale_a * *scale_b before bias / activation / residual.  fp8 operands
+     * need transA == transB == 0, K % 64 == 0, lda/ldb % 16 == 0; anything else is COMAT_EINVAL (no silent fallback). */
+    const float* scale_a;
+    const float* scale_b;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 
@@ -121,6 +128,8 @@ typedef struct {
     int32_t in_dtype, out_dtype, r_dtype;
     void* ws;           /* optional caller-owned split-K workspace (layout: see comat_gemm) */
     int64_t ws_bytes;
+    const float* scale_a;  /* in_dtype == COMAT_FP8_E4M3 (mode 0, Cin % 64 == 0): per-tensor scales of X and W, as in */
+    const float* scale_b;  /* comat_gemm_params */
 } comat_conv_params;
 int comat_conv2d(const comat_conv_params* p, void* stream);
 
@@ -304,6 +313,18 @@ int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float l
                 float max_norm, void* stream);
 /* counters[0] += 1 if *gnorm_sq is finite (update applied), else counters[1] += 1 (update skipped). */
 int comat_adamw_tick(int32_t* counters, const float* gnorm_sq, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-tensor fp8 (OCP e4m3fn) quantisation: the operand format of the fp8-forward configuration (BASELINE.json
+ * configs[4]: "fp8 MFMA UNet forward with bf16 backward"; the reference itself trains in fp16 autocast,
+ * training_script.py:449-456 - fp8 is this project's MI355X target, restated on the CPU by oracle/fp8.py).
+ *   comat_fp8_scale:    *scale = max(max_i |x_i|, 2^-100) / 448      (one launch; ws: 8 bytes the caller zeroed once)
+ *   comat_fp8_quantize: y_i = e4m3fn(x_i * (1 / *scale)), round to nearest even, saturating; y: n bytes
+ * x: n elements of `dtype` (fp32 or bf16), 16-byte aligned.  Feed y and scale to comat_gemm / comat_conv2d with
+ * in_dtype = COMAT_FP8_E4M3.
+ * ---------------------------------------------------------------------------------------------------------- */
+int comat_fp8_scale(const void* x, int64_t n, int32_t dtype, float* scale, void* ws, void* stream);
+int comat_fp8_quantize(const void* x, int64_t n, int32_t dtype, const float* scale, void* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,13 @@ def _v(t, sizes, strides):
     return torch.as_strided(t, sizes, strides, t.storage_offset())
 
 
+def _f(t, scale=None):
+    """operand -> fp32 values; uint8 tensors hold fp8 e4m3 bytes (value = scale * fp8)"""
+    if t.dtype == torch.uint8:
+        return t.view(torch.float8_e4m3fn).float() * scale.float()
+    return t.float()
+
+
 def _act(x, act):
     if act == ACT_SILU:
         return F.silu(x)
@@ -34,11 +41,15 @@ class SimKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
              sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
-             beta=0.0, act=ACT_NONE):
+             beta=0.0, act=ACT_NONE, scales=None):
         b1, b2 = batch
+        assert (scales is not None) == (A.dtype == torch.uint8)
+        if scales is not None:
+            assert not transA and not transB and K % 64 == 0 and lda % 16 == 0 and ldb % 16 == 0 and b2 == 1
+        sa, sb = scales if scales is not None else (None, None)
         Av = _v(A, (b1, b2, M, K), (sA[0], sA[1], 1, lda) if transA else (sA[0], sA[1], lda, 1))
         Bv = _v(B, (b1, b2, N, K), (sB[0], sB[1], 1, ldb) if transB else (sB[0], sB[1], ldb, 1))
-        acc = alpha * (Av.float() @ Bv.float().transpose(-1, -2))
+        acc = alpha * (_f(Av, sa) @ _f(Bv, sb).transpose(-1, -2))
         if bias is not None:
             acc = acc + bias.float()
         if bias2 is not None:
@@ -69,9 +80,13 @@ class SimKernels:
             df[do:do + rows * cols].view(cols, rows)[c0:c1, r0:r1] = blk.t().to(dst.dtype)
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
-               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE):
-        x = _v(X, (B, Hin, Win, Cin), (Hin * Win * Cin, Win * Cin, Cin, 1)).float().permute(0, 3, 1, 2)
-        w = _v(W, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)).float().permute(0, 3, 1, 2)
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
+        assert (scales is not None) == (X.dtype == torch.uint8)
+        if scales is not None:
+            assert mode == 0 and Cin % 64 == 0
+        sa, sb = scales if scales is not None else (None, None)
+        x = _f(_v(X, (B, Hin, Win, Cin), (Hin * Win * Cin, Win * Cin, Cin, 1)), sa).permute(0, 3, 1, 2)
+        w = _f(_v(W, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)), sb).permute(0, 3, 1, 2)
         if mode == 0:
             if ups == 2:
                 x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -94,6 +109,20 @@ class SimKernels:
         if R is not None:
             acc = acc + beta * _v(R, (B * Hout * Wout, Cout), (Cout, 1)).float()
         _v(Y, (B * Hout * Wout, Cout), (Cout, 1)).copy_(acc.to(Y.dtype))
+
+    # ---- fp8 operands ---------------------------------------------------------------------------------------
+    def fp8_quantize(self, x, out=None, scale=None):
+        """include/comat_hip.h: scale = max(amax, 2^-100) / 448, bytes = e4m3fn(x * (1 / scale)) (RNE, saturating)"""
+        xf = x.float()
+        sc = torch.clamp(xf.abs().max(), min=2.0 ** -100) / 448.0
+        q = (xf * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        if scale is None:
+            scale = torch.empty(1, dtype=torch.float32)
+        scale.copy_(sc.reshape(1))
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.uint8)
+        out.copy_(q)
+        return out, scale
 
     # ---- normalisation -------------------------------------------------------------------------------------
     @staticmethod

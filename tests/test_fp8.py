@@ -1,0 +1,331 @@
+"""fp8 forward (BASELINE.json configs[4]: "fp8 MFMA UNet forward with bf16 backward"), first slice:
+  * the e4m3fn rounding rule of the oracle (oracle/fp8.py) against torch's float8_e4m3fn cast, value by value;
+  * comat_fp8_scale / comat_fp8_quantize bit for bit against the oracle;
+  * comat_gemm / comat_conv2d with COMAT_FP8_E4M3 operands (32x32x64 fp8 MFMA) against the oracle's dequantised products;
+  * at the real SDXL-1024^2 shapes (128^2 latent level): integer-valued operands, where fp8 and bf16 arithmetic are both
+    exact, must give bit-identical results on the fp8 and the bf16 kernel;
+  * a small SDXL-topology UNet with fp8 forward against the oracle's fp8 emulation: eps, input gradient, LoRA gradients.
+
+Stated fp8 tolerance: given THE SAME input bits the product and the oracle compute the same scale and the same e4m3
+bytes, so one operator agrees to the fp32 summation order of its products: 2e-5 relative L2 with fp32 storage (1e-4 for
+the raw GEMM/conv entry points), ~1e-2 with bf16 storage (the output rounding).  Across a whole network only a
+statistical statement holds (see test_unet_fp8_forward_against_oracle_emulation for why)."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from comat_amd import config, ops, weights
+from comat_amd.unet import LoRABank, UNet
+from helpers import rel_l2, tok
+from oracle import fp8 as OF
+from oracle import sd as O
+
+FP8_UNET = dataclasses.replace(config.TINY_SDXL_UNET, block_out_channels=(64, 128, 128), cross_attention_dim=64,
+                               heads_per_level=(2, 4, 4), transformer_layers=(1, 1, 2), norm_groups=8, lora_rank=8)
+
+
+def rnd(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def test_oracle_rounding_rule_matches_the_e4m3fn_format():
+    allb = torch.arange(256, dtype=torch.uint8)
+    vals = allb.view(torch.float8_e4m3fn).float()
+    finite = vals[torch.isfinite(vals)]
+    assert finite.numel() == 254 and finite.abs().max() == 448.0 and finite[finite > 0].min() == 2.0 ** -9
+    # every representable value is a fixed point; midpoints tie to even; everything in between goes to the nearer one
+    pos = torch.sort(finite[finite >= 0]).values
+    probes = [pos, -pos, (pos[:-1] + pos[1:]) / 2, -(pos[:-1] + pos[1:]) / 2]
+    g = torch.Generator().manual_seed(0)
+    probes.append((torch.rand(20000, generator=g) * 2 - 1) * 448)
+    probes.append((torch.rand(20000, generator=g) * 2 - 1) * 0.05)
+    probes.append(torch.tensor([460.0, -463.9, 1e-4, 0.00097656, 0.00097657, 0.0]))
+    x = torch.cat(probes)
+    want = x.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    got = torch.from_numpy(OF.e4m3fn_round(x.numpy()))
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n", [8, 1000, 4099, 320 * 4096 + 3])
+def test_quantize_matches_oracle_bit_for_bit(dev, dtype, n):
+    x = (rnd(n, seed=n) * 3.7).to(dtype)
+    x[n // 2] = 0.0
+    q_ref, s_ref = OF.quantize(x)
+    q, s = ops.kernels().fp8_quantize(x.to(dev).contiguous())
+    assert float(s.cpu()) == float(s_ref), (float(s.cpu()), float(s_ref))
+    assert torch.equal(q.cpu(), q_ref)
+    # values: the oracle's numpy rounding rule, applied to the scaled input, gives the same bytes' values
+    want = OF.e4m3fn_round((x.float() * (1.0 / s_ref)).numpy()) * float(s_ref)
+    assert np.array_equal(OF.dequantize(q.cpu(), s_ref).numpy(), want.astype(np.float32))
+
+
+def test_quantize_of_zeros_is_zero(dev):
+    q, s = ops.kernels().fp8_quantize(torch.zeros(777, device=dev))
+    assert float(s.cpu()) == float(torch.tensor(2.0 ** -100) / 448.0) and int(q.cpu().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (200, 96, 128), (1, 40, 192), (333, 320, 640), (2048, 1280, 320)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_fp8_gemm_matches_oracle(dev, shape, out_dtype):
+    M, N, K = shape
+    x, w = rnd(M, K, seed=1) * 2.0, rnd(N, K, seed=2) * 0.05
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4).to(out_dtype)
+    (xq, sx), (wq, sw) = OF.quantize(x), OF.quantize(w)
+    ref = OF.dequantize(xq, sx).double() @ OF.dequantize(wq, sw).double().t() + bias.double() + res.double()
+    k = ops.kernels()
+    x8, sxd = k.fp8_quantize(x.to(dev))
+    w8, swd = k.fp8_quantize(w.to(dev))
+    y = torch.empty(M, N, dtype=out_dtype, device=dev)
+    k.gemm(x8, w8, y, M, N, K, K, K, N, bias=bias.to(dev), R=res.to(dev), ldr=N, beta=1.0, scales=(sxd, swd))
+    lim = 1e-4 if out_dtype == torch.float32 else 6e-3  # bf16 output: one rounding of the result
+    assert rel_l2(y, ref) < lim, rel_l2(y, ref)
+    if dev.type == "cuda":
+        from comat_amd import _hip
+        assert _hip.last_gemm_kernel() == 3  # the fp8 MFMA kernel, not a fallback
+
+
+@pytest.mark.parametrize("geo", [(2, 8, 8, 64, 128, 3, 1, 1, 1), (1, 16, 16, 128, 64, 3, 2, 1, 1), (2, 8, 8, 64, 64, 3, 1, 1, 2),
+                                 (1, 12, 12, 192, 96, 1, 1, 0, 1)])
+def test_fp8_conv_matches_oracle(dev, geo):
+    B, H, W, Cin, Cout, ks, stride, pad, ups = geo
+    x = rnd(B, Cin, H, W, seed=5)
+    w = rnd(Cout, Cin, ks, ks, seed=6) * 0.05
+    bias = rnd(Cout, seed=7)
+    xq, wq = OF.fake_quant(x), OF.fake_quant(w)
+    xu = torch.nn.functional.interpolate(xq, scale_factor=2, mode="nearest") if ups == 2 else xq
+    ref = torch.nn.functional.conv2d(xu.double(), wq.double(), bias.double(), stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2:]
+    k = ops.kernels()
+    x8, sx = k.fp8_quantize(tok(x).to(dev))
+    w8, sw = k.fp8_quantize(w.permute(0, 2, 3, 1).contiguous().to(dev))
+    y = torch.empty(B * Ho * Wo, Cout, device=dev)
+    k.conv2d(x8, w8, y, B, H, W, Cin, Ho, Wo, Cout, ks, ks, stride, pad, mode=0, ups=ups, bias=bias.to(dev), scales=(sx, sw))
+    assert rel_l2(y, tok(ref)) < 1e-4, rel_l2(y, tok(ref))
+
+
+def test_fp8_ineligible_problems_fail_loudly(dev):
+    """no silent fallback: the fp8 path has no second kernel behind it (include/comat_hip.h)"""
+    k = ops.kernels()
+    x8, sx = k.fp8_quantize(torch.ones(32, 96, device=dev))
+    w8, sw = k.fp8_quantize(torch.ones(16, 96, device=dev))
+    y = torch.empty(32, 16, device=dev)
+    with pytest.raises((RuntimeError, AssertionError)):
+        k.gemm(x8, w8, y, 32, 16, 96, 96, 96, 16, scales=(sx, sw))  # K % 64 != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["conv128_320", "conv64_640", "geglu", "attn_out"])
+def test_full_shape_integer_operands_agree_bit_for_bit_with_the_bf16_kernel(hip, case):
+    """SDXL at 1024^2 (128^2 latents, CFG batch 2): integer-valued activations in [-8, 8] and weights in [-4, 4] are
+    exact in e4m3 AND in bf16, every product and every partial sum (< 2^24) is exact in fp32, so the fp8 MFMA path and the
+    bf16 MFMA path must return the same bits whatever their tiling and summation order."""
+    k = ops.kernels()
+    g = torch.Generator().manual_seed(11)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi + 1, s, generator=g).float()
+    one = torch.ones(1, device=hip)
+    to8 = lambda t: t.to(torch.float8_e4m3fn).view(torch.uint8).to(hip)  # exact: small integers are e4m3 values
+    if case.startswith("conv"):
+        B, H, C = (2, 128, 320) if case == "conv128_320" else (2, 64, 640)
+        x, w = ri(-8, 8, B * H * H, C), ri(-4, 4, C, 3, 3, C)
+        x8, w8 = to8(x), to8(w)
+        x, w = x.to(hip), w.to(hip)
+        y8, y16 = torch.empty(B * H * H, C, device=hip), torch.empty(B * H * H, C, device=hip)
+        k.conv2d(x8, w8, y8, B, H, H, C, H, H, C, 3, 3, 1, 1, scales=(one, one))
+        k.conv2d(x.bfloat16(), w.bfloat16(), y16, B, H, H, C, H, H, C, 3, 3, 1, 1)
+    else:
+        M, N, K = (2 * 128 * 128, 2560, 320) if case == "geglu" else (2 * 64 * 64, 640, 640)
+        x, w = ri(-8, 8, M, K), ri(-4, 4, N, K)
+        x8, w8 = to8(x), to8(w)
+        x, w = x.to(hip), w.to(hip)
+        y8, y16 = torch.empty(M, N, device=hip), torch.empty(M, N, device=hip)
+        k.gemm(x8, w8, y8, M, N, K, K, K, N, scales=(one, one))
+        k.gemm(x.bfloat16(), w.bfloat16(), y16, M, N, K, K, K, N)
+    torch.cuda.synchronize()
+    assert float(y16.abs().max()) > 100 and torch.equal(y8, y16)
+    # and one row against exact integer arithmetic on the host
+    if not case.startswith("conv"):
+        row = (x[7].cpu().double() @ w.cpu().double().t()).float()
+        assert torch.equal(y8[7].cpu(), row)
+
+
+def _fp8_world(dev, dtype=torch.float32):
+    ucfg = FP8_UNET
+    q = lambda d: {k_: v.to(dtype).float() for k_, v in d.items()}
+    usd = q(weights.make_unet_weights(ucfg, perturb_norms=True))
+    lsd = q({k_: (v * 5 if k_.endswith("up.weight") else v) for k_, v in weights.make_lora_weights(ucfg).items()})
+    ocfg = O.UNetConfig(**dataclasses.asdict(ucfg))
+    B, h, w, L = 2, 8, 8, 7
+    x = rnd(B, 4, h, w, seed=1)
+    ctx = rnd(B, L, ucfg.cross_attention_dim, seed=2)
+    added = (rnd(B, ucfg.pooled_dim, seed=3), torch.tensor([[64.0, 64, 0, 0, 64, 64]] * B))
+    gout = rnd(B, 4, h, w, seed=4)
+    return ucfg, ocfg, usd, lsd, (B, h, w, L), x, ctx, added, gout
+
+
+def _tagged(holder):
+    holder.allow_fp8 = True
+    return holder
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_linear_op_matches_oracle_on_identical_inputs(dev, dtype):
+    """ops.linear under fp8_forward against the oracle's `_lin` under its fp8 emulation, SAME input bits: same scale,
+    same bytes, so the outputs differ by summation order only; the backward is the unquantised product's."""
+    M, K, N = 96, 128, 192
+    q = lambda t: t.to(dtype).float()
+    x, W, b, res, g = q(rnd(M, K, seed=1)), q(rnd(N, K, seed=2) * 0.1), rnd(N, seed=3), q(rnd(M, N, seed=4)), q(rnd(M, N, seed=5))
+    xo = x.clone().requires_grad_(True)
+    with O.fp8_forward(True):
+        yo = O._lin({"blk.weight": W, "blk.bias": b}, "blk", xo) + res
+    (yo * g).sum().backward()
+    y_exact = torch.nn.functional.linear(x, W, b) + res
+    lin = _tagged(ops.FrozenLinear(W, b, dtype, dev))
+    xd = x.to(dev, dtype).requires_grad_(True)
+    with ops.fp8_forward(True):
+        y = ops.linear(xd, lin, residual=res.to(dev, dtype))
+    (y.float() * g.to(dev)).sum().backward()
+    lim = 2e-5 if dtype == torch.float32 else 8e-3
+    assert rel_l2(yo, y_exact) > 1e-2                       # the quantiser is on ...
+    assert rel_l2(y, yo) < lim, rel_l2(y, yo)               # ... and the product follows the oracle, not the exact product
+    assert rel_l2(xd.grad, xo.grad) < lim
+    with ops.fp8_forward(False):                            # outside the context the same holder is exact
+        assert rel_l2(ops.linear(xd.detach(), lin, residual=res.to(dev, dtype)), y_exact) < lim
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_lora_group_op_matches_oracle_on_identical_inputs(dev, dtype):
+    """q / k / v of one attention: frozen part on fp8 (x quantised once), LoRA part and all gradients unquantised"""
+    M, K, N, r = 80, 64, 128, 8
+    q = lambda t: t.to(dtype).float()
+    x, g = q(rnd(M, K, seed=1)), [q(rnd(M, N, seed=20 + i)) for i in range(3)]
+    names = ["a.to_q", "a.to_k", "a.to_v"]
+    sd = {n + ".weight": q(rnd(N, K, seed=30 + i) * 0.1) for i, n in enumerate(names)}
+    lora = {}
+    for i, n in enumerate(names):
+        lora[n + ".lora.down.weight"] = q(rnd(r, K, seed=40 + i) * 0.2)
+        lora[n + ".lora.up.weight"] = q(rnd(N, r, seed=50 + i) * 0.2)
+    lo = {k_: v.clone().requires_grad_(True) for k_, v in lora.items()}
+    xo = x.clone().requires_grad_(True)
+    with O.fp8_forward(True):
+        yo = [O._lin(sd, n, xo, lo) for n in names]
+    sum((a * b).sum() for a, b in zip(yo, g)).backward()
+    store = ops.LoRAStore([[(n + ".lora.down.weight", n + ".lora.up.weight", lora[n + ".lora.down.weight"],
+                             lora[n + ".lora.up.weight"]) for n in names]], dtype, dev)
+    lins = [_tagged(l) for l in ops.frozen_linear_group([sd[n + ".weight"] for n in names], [None] * 3, dtype, dev)]
+    xd = x.to(dev, dtype).requires_grad_(True)
+    with ops.fp8_forward(True):
+        ys = ops.lora_group_linear(xd, lins, store.groups[0])
+    sum((a.float() * b.to(dev)).sum() for a, b in zip(ys, g)).backward()
+    ops.join_side_streams()
+    lim = 2e-5 if dtype == torch.float32 else 1e-2
+    for a, b in zip(ys, yo):
+        assert rel_l2(a, b) < lim, rel_l2(a, b)
+    assert rel_l2(xd.grad, xo.grad) < lim
+    for n, p in store.params.items():
+        assert rel_l2(p.grad, lo[n].grad) < lim, (n, rel_l2(p.grad, lo[n].grad))
+
+
+@pytest.mark.parametrize("geo", [(2, 8, 64, 128, 1, 1), (1, 8, 128, 64, 2, 1), (2, 4, 64, 64, 1, 2)])
+def test_fp8_conv_op_matches_oracle_on_identical_inputs(dev, geo):
+    B, H, Cin, Cout, stride, ups = geo
+    x, W, b = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, 3, 3, seed=2) * 0.05, rnd(Cout, seed=3)
+    temb = rnd(B, Cout, seed=4)
+    xo = x.clone().requires_grad_(True)
+    xu = torch.nn.functional.interpolate(xo, scale_factor=2, mode="nearest") if ups == 2 else xo
+    with O.fp8_forward(True):
+        yo = O._conv({"blk.weight": W, "blk.bias": b}, "blk", xu, stride=stride) + temb[:, :, None, None]
+    g = rnd(*yo.shape, seed=5)
+    (yo * g).sum().backward()
+    conv = _tagged(ops.FrozenConv(W, b, torch.float32, dev, stride=stride, pad=1))
+    xd = tok(x).to(dev).requires_grad_(True)
+    with ops.fp8_forward(True):
+        y = ops.conv2d(xd, conv, B, H, H, ups=ups, bias2=temb.to(dev))
+    (y * tok(g).to(dev)).sum().backward()
+    assert rel_l2(y, tok(yo)) < 2e-5, rel_l2(y, tok(yo))
+    assert rel_l2(xd.grad, tok(xo.grad)) < 2e-5
+
+
+def test_unet_fp8_forward_against_oracle_emulation(dev):
+    """Whole UNet, every eligible layer on fp8.  Quantisers in series amplify ANY difference between two fp32
+    implementations: the first activation that lands on the other side of a rounding boundary (~1e-6 summation-order
+    noise is enough) changes its successors by ~1e-3, which then re-rounds per cent of the next quantiser's inputs, and
+    so on - after a few layers product and oracle carry independent quantisation noise.  Exact agreement is therefore a
+    per-operator property (the tests above: identical input bits -> identical bytes); at network level the checks are
+      (1) layers that see bit-identical inputs (the first quantised layers) produce the same scales to 1e-5,
+      (2) the same NUMBER of tensors is quantised in product and oracle (same sizes, upsampler inputs apart),
+      (3) the product's distance to the oracle emulation stays below the emulation's own distance to the exact network
+          (two draws of the same quantisation noise), and the product's distance to the exact network is that of the
+          oracle within a factor of two."""
+    ucfg, ocfg, usd, lsd, (B, h, w, L), x, ctx, added, gout = _fp8_world(dev)
+    o_scales, o_shapes = [], []
+    orig = OF.fake_quant
+
+    def spy(t):
+        qv, sc = OF.quantize(t)
+        if t.shape[0] == B:  # activations (weights are [out, in, ...]; no weight here has leading dim 2)
+            o_scales.append(float(sc))
+            o_shapes.append(t.numel())
+        return OF.dequantize(qv, sc)
+    OF.fake_quant = spy
+    try:
+        with torch.no_grad():
+            eo = O.unet_forward(usd, ocfg, x, 417, ctx, lsd, None, added, fp8=True)
+    finally:
+        OF.fake_quant = orig
+    with torch.no_grad():
+        e_exact = O.unet_forward(usd, ocfg, x, 417, ctx, lsd, None, added)
+    bank = LoRABank(ucfg, lsd, torch.float32, dev)
+    unet = UNet(ucfg, usd, torch.float32, dev, bank, fp8_forward=True)
+    k = ops.kernels()
+    p_scales, p_shapes = [], []
+    kq = k.fp8_quantize
+
+    def pspy(t, **kw):
+        r = kq(t, **kw)
+        p_scales.append(r[1])
+        p_shapes.append(t.numel())
+        return r
+    k.fp8_quantize = pspy
+    try:
+        with torch.no_grad():
+            e, _ = unet(tok(x).to(dev), B, h, w, 417, ctx.reshape(B * L, -1).to(dev).contiguous(), L,
+                        added=(added[0].to(dev), added[1].tolist()))
+    finally:
+        k.fp8_quantize = kq
+    p_scales = [float(t.cpu()) for t in p_scales]
+    # (2) the oracle quantises the shared input of a q/k/v (k/v) group once per projection, the product once per group
+    dedup = [(n_, s_) for i, (n_, s_) in enumerate(zip(o_shapes, o_scales))
+             if i == 0 or (n_, s_) != (o_shapes[i - 1], o_scales[i - 1])]
+    # (the element counts differ only where the product quantises the input of an upsampler conv BEFORE the fused 2x upsample)
+    assert len(dedup) == len(p_shapes) and sum(n_ for n_, _ in dedup) >= sum(p_shapes)
+    # (1) down_blocks.0.resnets.0.conv1 / conv2: inputs produced by unquantised layers only
+    assert abs(p_scales[0] - dedup[0][1]) < 1e-5 * dedup[0][1]
+    # (3)
+    cost_o, cost_p, mism = rel_l2(tok(eo), tok(e_exact)), rel_l2(e, tok(e_exact)), rel_l2(e, tok(eo))
+    print(f"fp8 UNet: oracle-vs-exact {cost_o:.3e}, product-vs-exact {cost_p:.3e}, product-vs-oracle {mism:.3e}")
+    assert cost_o > 1e-2 and 0.5 * cost_o < cost_p < 2.0 * cost_o and mism < 1.2 * cost_o
+
+
+def test_fp8_forward_touches_only_the_tagged_layers(sim):
+    """embeddings, conv_in / conv_out stay exact; a UNet built without the flag never quantises"""
+    ucfg, ocfg, usd, lsd, (B, h, w, L), x, ctx, added, gout = _fp8_world(sim)
+    calls = []
+    k = ops.kernels()
+    orig = k.fp8_quantize
+    k.fp8_quantize = lambda t, **kw: (calls.append(tuple(t.shape)), orig(t, **kw))[1]
+    unet = UNet(ucfg, usd, torch.float32, sim, LoRABank(ucfg, lsd, torch.float32, sim))
+    with torch.no_grad():
+        unet(tok(x), B, h, w, 417, ctx.reshape(B * L, -1).contiguous(), L, added=(added[0], added[1].tolist()))
+    assert calls == []
+    unet8 = UNet(ucfg, usd, torch.float32, sim, LoRABank(ucfg, lsd, torch.float32, sim), fp8_forward=True)
+    n_weights = len(calls)
+    assert n_weights > 20 and not getattr(unet8.conv_in, "allow_fp8") and not getattr(unet8.conv_out, "allow_fp8")
+    assert not unet8.t1.allow_fp8 and not unet8.a1.allow_fp8 and getattr(unet8.conv_in, "_w8", None) is None
+    with torch.no_grad():
+        unet8(tok(x), B, h, w, 417, ctx.reshape(B * L, -1).contiguous(), L, added=(added[0], added[1].tolist()))
+    acts = calls[n_weights:]
+    assert len(acts) > 20 and all(s[-1] % 64 == 0 for s in acts)  # activations only, contraction length % 64 == 0
+    k.fp8_quantize = orig

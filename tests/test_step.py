@@ -21,8 +21,13 @@ from oracle import step as OS
 
 DTYPES = [torch.float32, torch.bfloat16]
 # bf16 storage against the fp32 oracle on the SAME (bf16-representable) weights: the gradient error is the rounding of
-# every stored activation (2^-9 relative each) carried through ~100 layers and three denoise steps.
-BF16_GRAD_LIMIT = 0.12
+# every stored activation (2^-9 relative each) carried through ~100 layers and three denoise steps of a random-weight
+# toy network.  Limits = 2 x the largest error measured on an MI355X / on the ABI simulator
+# (profiles/r02_g_bf16_errors.txt: generator 7.0e-2 SD1.5 / 1.33e-1 SDXL, discriminator 2.2e-2, head 1.5e-3).
+BF16_GRAD_LIMIT = 0.14
+BF16_GRAD_LIMIT_SDXL = 0.27
+BF16_D_GRAD_LIMIT = 0.045
+BF16_HEAD_GRAD_LIMIT = 4e-3
 
 
 def report(name, dtype, dev, **vals):
@@ -116,9 +121,10 @@ def test_train_step_matches_oracle(dev, dtype, attrcon):
     hg = torch.cat([ref["head_grads"][0].reshape(-1), ref["head_grads"][1].reshape(-1)])
     report(f"tiny_step attrcon={int(attrcon)}", dtype, dev, g=rel_l2(bank.flat_grad, g_ref), d=rel_l2(dbank.flat_grad, d_ref),
            head=rel_l2(trainer.D.head_grad, hg))
+    lim_d = lim if dtype == torch.float32 else BF16_D_GRAD_LIMIT
     assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
-    assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
-    assert rel_l2(trainer.D.head_grad, hg) < lim * 3
+    assert rel_l2(dbank.flat_grad, d_ref) < lim_d, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
+    assert rel_l2(trainer.D.head_grad, hg) < (3e-3 if dtype == torch.float32 else BF16_HEAD_GRAD_LIMIT)
     # parameters after clip + AdamW.  The first Adam update is sign-like (lr * g / (|g| + eps)): elements whose
     # gradient is ~0 amplify summation-order differences, hence 3e-4 rather than the 1e-3-of-gradient bound / 10
     p_ref = torch.cat([W["lora"][n].detach().reshape(-1) for n in bank.names])
@@ -232,10 +238,11 @@ def test_train_step_sdxl_matches_oracle(dev, dtype):
         check(logs[key], ref[rk], dtype, key, factor=f)
     g_ref = torch.cat([ref["g_grads"][n].reshape(-1) for n in bank.names])
     d_ref = torch.cat([ref["d_grads"][n].reshape(-1) for n in dbank.names])
-    lim = 1e-3 if dtype == torch.float32 else BF16_GRAD_LIMIT
+    lim = 1e-3 if dtype == torch.float32 else BF16_GRAD_LIMIT_SDXL
+    lim_d = lim if dtype == torch.float32 else BF16_D_GRAD_LIMIT
     report("tiny_step sdxl", dtype, dev, g=rel_l2(bank.flat_grad, g_ref), d=rel_l2(dbank.flat_grad, d_ref))
     assert rel_l2(bank.flat_grad, g_ref) < lim, f"G LoRA grads rel-L2 {rel_l2(bank.flat_grad, g_ref):.3e}"
-    assert rel_l2(dbank.flat_grad, d_ref) < lim, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
+    assert rel_l2(dbank.flat_grad, d_ref) < lim_d, f"D LoRA grads rel-L2 {rel_l2(dbank.flat_grad, d_ref):.3e}"
 
 
 @pytest.mark.parametrize("attrcon", [False, True])

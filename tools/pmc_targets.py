@@ -14,6 +14,14 @@ dev = torch.device("cuda:0")
 T = torch.bfloat16
 N = int(os.environ.get("PMC_N", "5"))
 
+# calibration stream for the byte counters: out = 1.0 * x over 256 Mi bf16 elements = 512 MiB read + 512 MiB written
+# (larger than the 256 MiB Infinity Cache)
+CAL_N = 256 * 1024 * 1024
+Xc = torch.ones(CAL_N, device=dev, dtype=T)
+Yc = torch.empty_like(Xc)
+for _ in range(N):
+    K.axpby(1.0, Xc, 0.0, None, Yc, CAL_N)
+del Xc, Yc
 # conv 3x3, B=2, 64x64, 320 -> 320 (ResnetBlock2D at the top UNet level)
 X = torch.randn(2 * 64 * 64, 320, device=dev).to(T)
 W = torch.randn(320, 3, 3, 320, device=dev).to(T)

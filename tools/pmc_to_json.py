@@ -6,6 +6,7 @@ Per kernel: average duration, HBM-side bytes per launch (FETCH_SIZE is in KiB an
 stream at half its bytes: x 2 as MI355X_MICROARCH.md prescribes; WRITE_SIZE in KiB, uncorrected), MFMA busy share =
 SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), and the algorithmic bytes / FLOPs of the probe's launches."""
 import json
+import re
 import sqlite3
 import sys
 from collections import defaultdict
@@ -25,10 +26,13 @@ ALGO = [
 ]
 
 
-def main():
+CAL_BYTES = 256 * 1024 * 1024 * 2  # tools/pmc_targets.py: the axpby stream reads and writes this many bytes
+
+
+def load(dbs):
     ctr = defaultdict(dict)
     first = {}
-    for db in sys.argv[1:]:
+    for db in dbs:
         cur = sqlite3.connect(db).cursor()
         for k, gs, c, v, st, d, n in cur.execute("select kernel_name, grid_size, counter_name, avg(value), min(start), avg(duration), "
                                                  "count(*) from counters_collection group by kernel_name, grid_size, counter_name"):
@@ -36,9 +40,69 @@ def main():
             ctr[(k, gs)].setdefault("_us", d / 1e3)
             ctr[(k, gs)].setdefault("_n", n)
             first.setdefault((k, gs), st)
+    return ctr, first
+
+
+def family(name):
+    """'void (anonymous namespace)::gemm2_kernel<128, ...>(Args2)' -> 'gemm2_kernel'"""
+    n = name.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void\s+", "", n)
+    m = re.match(r"([A-Za-z_][\w:]*)", n)
+    base = m.group(1) if m else n[:40]
+    return base.split("::")[-1]
+
+
+def step_families(dbs, write_cal):
+    """whole-step counter passes (bench.py under --pmc, eager launches): per kernel family sums over every dispatch"""
+    fam = defaultdict(lambda: defaultdict(float))
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        for k, c, v, d, n in cur.execute("select kernel_name, counter_name, sum(value), sum(duration), count(*) from "
+                                         "counters_collection group by kernel_name, counter_name"):
+            f = fam[family(k)]
+            f[c] += v
+            f["_n_" + c] += n
+            f["_ns_" + c] += d
+    out = {}
+    for name, f in fam.items():
+        ent = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
+            if "_n_" + c in f:
+                ent["launches"] = int(f["_n_" + c])
+                ent["avg_us"] = round(f["_ns_" + c] / f["_n_" + c] / 1e3, 2)
+                ent["total_ms"] = round(f["_ns_" + c] / 1e6, 2)
+                break
+        if "FETCH_SIZE" in f:
+            ent["hbm_read_bytes_per_launch"] = int(f["FETCH_SIZE"] * 1024 * 2 / f["_n_FETCH_SIZE"])
+        if "WRITE_SIZE" in f:
+            ent["hbm_write_bytes_per_launch"] = int(f["WRITE_SIZE"] * 1024 * write_cal / f["_n_WRITE_SIZE"])
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in f and f.get("GRBM_GUI_ACTIVE"):
+            ent["mfma_busy_frac"] = round(f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * f["GRBM_GUI_ACTIVE"] / 8.0), 4)
+        out[name] = ent
+    return dict(sorted(out.items(), key=lambda kv: -kv[1].get("total_ms", 0.0))[:40])
+
+
+def main():
+    args = sys.argv[1:]
+    step_dbs = []
+    if "--step" in args:
+        i = args.index("--step")
+        args, step_dbs = args[:i], args[i + 1:]
+    ctr, first = load(args)
+    # byte-counter calibration on the known stream
+    fetch_cal, write_cal = None, 1.0
+    for (k, gs), c in ctr.items():
+        if "axpby_kernel" in k and gs >= CAL_BYTES // 64:
+            if c.get("FETCH_SIZE"):
+                fetch_cal = CAL_BYTES / (c["FETCH_SIZE"] * 1024)
+            if c.get("WRITE_SIZE"):
+                write_cal = CAL_BYTES / (c["WRITE_SIZE"] * 1024)
     groups = sorted((g for g in ctr if "anonymous" in g[0]), key=lambda g: first[g])
     seen = defaultdict(int)
-    out = {}
+    out = {"calibration": {"stream_bytes_each_way": CAL_BYTES, "true_over_FETCH_SIZE_KiB": fetch_cal,
+                           "true_over_WRITE_SIZE_KiB": write_cal,
+                           "applied": "reads: FETCH_SIZE x 1024 x 2 (MI355X_MICROARCH.md, HBM); writes: WRITE_SIZE x 1024 x "
+                                      "the measured write factor"}}
     for g in groups:
         k, gs = g
         c = ctr[g]
@@ -57,7 +121,7 @@ def main():
         if "FETCH_SIZE" in c:
             ent["hbm_read_bytes"] = int(c["FETCH_SIZE"] * 1024 * 2)
         if "WRITE_SIZE" in c:
-            ent["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
+            ent["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024 * write_cal)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
             # GRBM_GUI_ACTIVE comes summed over the 8 XCDs (1.3e6 "cycles" for a 67.6 us kernel in round 1 = 8 x 2.4 GHz x t)
             ent["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 4)
@@ -70,6 +134,17 @@ def main():
                 ent["hbm_GB_per_s"] = round(tot / us / 1e3, 1)
                 ent["traffic_over_algorithmic"] = round(tot / abytes, 2) if abytes else None
         out[f"{len(out):02d} {label or k[:60]}"] = ent
+    if step_dbs:
+        fams = step_families(step_dbs, write_cal)
+        out["step_families"] = fams
+        dom = fams.get("gemm2_kernel")
+        if dom and "hbm_read_bytes_per_launch" in dom and "hbm_write_bytes_per_launch" in dom:
+            out["bench_roofline"] = {
+                "kernel": "gemm2_kernel", "traffic_bytes_per_launch": dom["hbm_read_bytes_per_launch"] + dom["hbm_write_bytes_per_launch"],
+                "mfma_busy_frac": dom.get("mfma_busy_frac"), "launches_in_pass": dom["launches"],
+                "note": "HBM-side bytes per gemm2_kernel launch averaged over every launch of whole eager C2 steps under "
+                        "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate passes; "
+                        "tools/r2_call7.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE calibrated on a known stream"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
