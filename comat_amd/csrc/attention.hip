@@ -205,7 +205,11 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[G::TILE_BYTES + (TR ? G::TT_BYTES : G::TILE_BYTES)];
+    // LDS: [K tile | V tile (TR: its transposed image)], TWICE when it fits (DB): the next tile is written into the other
+    // buffer right after this tile's MFMAs, so a key tile costs ONE block barrier instead of two
+    constexpr int ONE = G::TILE_BYTES + (TR ? G::TT_BYTES : G::TILE_BYTES);
+    constexpr bool DB = 2 * ONE <= 65536;
+    __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Kt = smem;
     char* Vt = smem + G::TILE_BYTES;  // TR: the transposed image of the V tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -282,13 +286,19 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
 #pragma unroll
             for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], TR ? frag_km_t<T, DMAX>(Vt, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
         }
-        __syncthreads();
+        if (DB) {
+            // the other buffer was last read in iteration t-1, which every wave left through the barrier below
+            Kt = smem + ((t + 1) & 1) * ONE;
+            Vt = Kt + G::TILE_BYTES;
+        } else {
+            __syncthreads();
+        }
         if (more) {
             km.store(Kt);
             if (TR) vm.store_t(Vt);
             else vm.store(Vt);
-            __syncthreads();
         }
+        if (DB || more) __syncthreads();
     }
     if (q < a.Nq) {
         const float inv = 1.0f / l;
@@ -330,7 +340,9 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + (TR ? G::TT_BYTES : 0)];
+    constexpr int ONE = 2 * G::TILE_BYTES + (TR ? G::TT_BYTES : 0);
+    constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per key tile (see flash_fwd_kernel)
+    __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Kt = smem;
     char* Vt = smem + G::TILE_BYTES;
     char* KtT = smem + 2 * G::TILE_BYTES;  // TR: transposed image of the K tile (for dQ^T += K^T dS^T)
@@ -391,13 +403,19 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
 #pragma unroll
             for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], TR ? frag_km_t<T, DMAX>(KtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
         }
-        __syncthreads();
+        if (DB) {
+            Kt = smem + ((t + 1) & 1) * ONE;
+            Vt = Kt + G::TILE_BYTES;
+            KtT = Kt + 2 * G::TILE_BYTES;
+        } else {
+            __syncthreads();
+        }
         if (more) {
             km.store(Kt);
             if (TR) km.store_t(KtT);
             vm.store(Vt);
-            __syncthreads();
         }
+        if (DB || more) __syncthreads();
     }
     if (q < a.Nq) {
 #pragma unroll
@@ -415,7 +433,9 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    __shared__ __attribute__((aligned(16))) char smem[2 * G::TILE_BYTES + 256 + (TR ? 2 * G::TT_BYTES : 0)];
+    constexpr int ONE = 2 * G::TILE_BYTES + 256 + (TR ? 2 * G::TT_BYTES : 0);
+    constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per query tile (see flash_fwd_kernel)
+    __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Qt = smem;
     char* Gt = smem + G::TILE_BYTES;
     float* lse_s = (float*)(smem + 2 * G::TILE_BYTES);
@@ -503,7 +523,16 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
                 mma(dkT[t2], TR ? frag_km_t<T, DMAX>(QtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
             }
         }
-        __syncthreads();
+        if (DB) {
+            Qt = smem + ((t - tbeg + 1) & 1) * ONE;
+            Gt = Qt + G::TILE_BYTES;
+            lse_s = (float*)(Qt + 2 * G::TILE_BYTES);
+            D_s = lse_s + 32;
+            QtT = Qt + 2 * G::TILE_BYTES + 256;
+            GtT = QtT + G::TT_BYTES;
+        } else {
+            __syncthreads();
+        }
         if (more) {
             qm.store(Qt);
             gm.store(Gt);
@@ -512,8 +541,8 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
                 gm.store_t(GtT);
             }
             if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
-            __syncthreads();
         }
+        if (DB || more) __syncthreads();
     }
     if (key < a.Nk) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;

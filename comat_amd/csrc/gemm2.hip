@@ -191,19 +191,38 @@ __device__ __forceinline__ void g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        // slabs are added IN SLICE ORDER; the loads of slab s2 + 1 are in flight while slab s2 is added (a write-through
+        // slab comes back from memory, ~1.2 us per dependent round trip: 32 slices cost 38 us when read one after the
+        // other - profiles/r02_g_bench_shapes.txt, LoRA weight gradients)
+        f32x4_t cur[TM][TN][4], nxt[TM][TN][4] = {};
+        const int64_t base0 = (tile * QPT * NTH + tid) * 16, sstep = g.ntiles * QPT * NTH * 16;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cur[a][b][q] = io.load(base0 + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
         for (int s2 = 0; s2 < g.splits; ++s2) {
-            const int64_t src = (((int64_t)s2 * g.ntiles + tile) * QPT * NTH + tid) * 16;
+            if (s2 + 1 < g.splits) {
+                const int64_t src = base0 + (int64_t)(s2 + 1) * sstep;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) nxt[a][b][q] = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
+            }
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const f32x4_t v = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
-                        acc[a][b][4 * q] += v[0];
-                        acc[a][b][4 * q + 1] += v[1];
-                        acc[a][b][4 * q + 2] += v[2];
-                        acc[a][b][4 * q + 3] += v[3];
+                        acc[a][b][4 * q] += cur[a][b][q][0];
+                        acc[a][b][4 * q + 1] += cur[a][b][q][1];
+                        acc[a][b][4 * q + 2] += cur[a][b][q][2];
+                        acc[a][b][4 * q + 3] += cur[a][b][q][3];
+                        cur[a][b][q] = nxt[a][b][q];
                     }
         }
     }
@@ -794,11 +813,19 @@ static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
     a.tiles_m = (int)cdiv64(a.M, 128);
     a.tiles_n = (int)cdiv64(a.N, 128);
     a.ntiles = (int64_t)a.tiles_m * a.tiles_n * p->batch1;
-    // a handful of output tiles, thousands of tokens to contract: ~one block per CU, every slice >= 8 k-tiles
+    // a handful of output tiles, thousands of tokens to contract.  Launch time ~ (nkt / s) k-tiles of main loop at ~0.35 us
+    // each (a lone block per CU is DMA-latency bound) + s slabs for the last arriver at ~0.6 us each (pipelined sc1
+    // reads): minimal near s = sqrt(0.6 nkt) - 12 slices for 8192 tokens, not "one block per CU" (32 slices: 42 us
+    // measured, of which 38 us were the combine; profiles/r02_g_bench_shapes.txt)
     int fc = 0, fs = 0;
     g2_overrides(&fc, &fs);
-    int64_t s = fs > 0 ? fs : cdiv64(256, a.ntiles);
-    if (s > a.nkt / 8) s = a.nkt / 8;
+    int64_t s = fs;
+    if (s <= 0) {
+        s = 1;
+        while ((s + 1) * (s + 1) * 5 <= (int64_t)a.nkt * 3) ++s;  // floor(sqrt(0.6 nkt))
+        if (a.ntiles * s < 16) s = cdiv64(16, a.ntiles);           // very few tiles: keep at least 16 blocks busy
+    }
+    if (s > a.nkt / 4) s = a.nkt / 4;
     const int64_t slab_bytes = p->ws_bytes - COMAT_WS_COUNTER_BYTES;
     if (slab_bytes <= 0 || a.ntiles > WS_COUNTERS) s = 1;
     else if (s > slab_bytes / (a.ntiles * 128 * 128 * 4)) s = slab_bytes / (a.ntiles * 128 * 128 * 4);

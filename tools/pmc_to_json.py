@@ -92,7 +92,7 @@ def main():
     # byte-counter calibration on the known stream
     fetch_cal, write_cal = None, 1.0
     for (k, gs), c in ctr.items():
-        if "axpby_kernel" in k and gs >= CAL_BYTES // 64:
+        if "axpby_kernel" in k and max(c.get("FETCH_SIZE", 0), c.get("WRITE_SIZE", 0)) * 1024 > CAL_BYTES // 4:
             if c.get("FETCH_SIZE"):
                 fetch_cal = CAL_BYTES / (c["FETCH_SIZE"] * 1024)
             if c.get("WRITE_SIZE"):
