@@ -538,7 +538,8 @@ def main():
         rec = None
         if rank == 0:
             rec = CallRecorder(ops.kernels())
-            ops.set_side_stream_enabled(False)  # one stream: event pairs must not straddle kernels of another stream
+            ops.set_kernel_backend(rec)
+        ops.set_side_stream_enabled(False)  # one stream: event pairs must not straddle kernels of another stream
         trainer.serial_d, trainer.flat_d = True, False
         trainer.train_step(batch, **fixed)
         sync()

@@ -635,7 +635,10 @@ template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st)
     // (V; K in dQ; Q and dO in dK/dV) as transposed LDS images, so their MFMA fragments are two 8-byte reads instead of
     // eight 2-byte reads.  Options flash_trim / flash_tr = 0 (COMAT_FLASH_TRIM / COMAT_FLASH_TR) select the plain kernels.
     const int trim_v = comat_option(COMAT_OPT_FLASH_TRIM), tr_v = comat_option(COMAT_OPT_FLASH_TR);
-    if (tr_v == 1) return dispatch_tr<T, true>(a, bwd, trim_v == 1, st);
+    // flash_tr: 0 never, 2 always, 1 (default) by head dim: building the transposed image costs 8 scalar LDS writes per
+    // 16-byte chunk, which pays off for d <= 64 only (profiles/r02_h_mb_flash.txt: d = 80 backward 133 vs 144 us,
+    // d = 160 81 vs 92 us without it; d = 40 441 vs 474 us with it)
+    if (tr_v == 2 || (tr_v == 1 && a.d <= 64)) return dispatch_tr<T, true>(a, bwd, trim_v == 1, st);
     return dispatch_tr<T, false>(a, bwd, trim_v == 1, st);
 }
 

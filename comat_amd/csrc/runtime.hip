@@ -42,7 +42,8 @@ struct Opt {
 };
 Opt g_opts[COMAT_N_OPTIONS] = {
     {"flash_trim", "COMAT_FLASH_TRIM", 1, 0, false},      // skip all-zero head-dim MFMA steps of the fused attention
-    {"flash_tr", "COMAT_FLASH_TR", 1, 0, false},          // transposed LDS images for its k-major operand tiles
+    {"flash_tr", "COMAT_FLASH_TR", 1, 0, false},          // transposed LDS images for its k-major operand tiles: 0 never,
+                                                          // 1 for head dims <= 64 (where it pays), 2 always
     {"gemm2", "COMAT_GEMM2", 1, 0, false},                // LDS-DMA pipelined GEMM / conv kernel (gemm2.hip)
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count

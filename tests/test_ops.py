@@ -816,7 +816,7 @@ def test_flash_trim_is_bit_identical(hip, dtype, cfg, default_opts):
     q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
     g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
     res = []
-    for trim, tr in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    for trim, tr in ((0, 0), (1, 0), (0, 2), (1, 2), (1, 1)):  # tr: 0 never, 2 always, 1 by head dim (the default)
         _set_opts(flash_trim=trim, flash_tr=tr)
         qd, kd, vd = (dv(t, hip, dtype, grad=True) for t in (q, k_, v))
         o, _ = ops.attention(qd, kd, vd, B, Nq, Nk, H, d, need_probs=False)

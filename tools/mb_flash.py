@@ -45,7 +45,7 @@ def main():
         dq, dk, dv = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
         sc = d ** -0.5
         for trim in (0, 1):
-            for tr in (0, 1):
+            for tr in (0, 2):  # never / always (the default, 1, picks by head dim)
                 _hip.set_option("flash_trim", trim)
                 _hip.set_option("flash_tr", tr)
                 tf = timeit(lambda: k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, sc))
