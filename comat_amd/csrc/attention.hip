@@ -14,8 +14,7 @@
 //
 // Kernels (T = bf16 -> v_mfma_f32_32x32x16_bf16, T = fp32 -> exact v_mfma_f32_32x32x2_f32; DMAX = padded head dim):
 //   flash_fwd   : block = 4 waves x 32 queries, loops over 32-key tiles (K,V staged through LDS, register prefetch)
-//   flash_prep  : D[q] = sum_d dO[q,d] * O[q,d]
-//   flash_dq    : same geometry as forward; dQ^T += K^T dS^T
+//   flash_dq    : same geometry as forward; D[q] = sum_d dO[q,d] O[q,d] (stored for flash_dkdv), dQ^T += K^T dS^T
 //   flash_dkdv  : block = 4 waves x 32 keys, loops over 32-query tiles; dV^T += dO^T P, dK^T += Q^T dS
 #include "common.h"
 #include <stdlib.h>
@@ -313,28 +312,6 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     }
 }
 
-template <typename T> __global__ __launch_bounds__(NT) void flash_prep_kernel(FlashArgs a) {
-    // thread -> (b, q, h) with h fastest: a wave reads whole token rows of O / dO with 16-byte loads
-    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
-    const int64_t total = (int64_t)a.B * a.H * a.Nq;
-    if (idx >= total) return;
-    const int h = (int)(idx % a.H);
-    const int q = (int)((idx / a.H) % a.Nq);
-    const int b = (int)(idx / ((int64_t)a.H * a.Nq));
-    const T* o = (const T*)a.O + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
-    const T* g = (const T*)a.dO + ((int64_t)b * a.Nq + q) * a.ldo + h * a.d;
-    constexpr int EPV = 16 / (int)sizeof(T);
-    float acc = 0.f;
-    for (int c = 0; c < a.d; c += EPV) {
-        const uint4 ov = *(const uint4*)(o + c), gv = *(const uint4*)(g + c);
-        const T* oe = (const T*)&ov;
-        const T* ge = (const T*)&gv;
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) acc += ldf<T>(oe + e) * ldf<T>(ge + e);
-    }
-    a.Dbuf[((int64_t)b * a.H + h) * a.Nq + q] = acc;
-}
-
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
@@ -358,7 +335,27 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
     const float lse_q = (q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f) * LOG2E;  // log2 units
-    const float D_q = q < a.Nq ? a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] : 0.f;
+    // D[q] = sum_d dO[q, d] O[q, d]: the lane already holds its half of row q of dO; O comes in the same fragments.  Fixed
+    // order (chunks ascending, then the two halves), written for the dK/dV pass that follows on the stream: the separate
+    // "prep" launch of round 1 (260 launches per C2 step) is gone.
+    float D_q;
+    {
+        const T* Ob = (const T*)a.O + (int64_t)b * a.Nq * a.ldo + h * a.d;
+        F of[NK];
+        load_col_frags<T, DMAX, NK>(of, Ob, a.ldo, q, a.Nq, a.d, hh);
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            V16 gv, ov;
+            __builtin_memcpy(&gv, &gf[s], 16);
+            __builtin_memcpy(&ov, &of[s], 16);
+#pragma unroll
+            for (int e = 0; e < G::KC; ++e)
+                part += sizeof(T) == 2 ? bf16_to_f32(gv.h[e]) * bf16_to_f32(ov.h[e]) : gv.f[e] * ov.f[e];
+        }
+        D_q = half_sum(part);
+        if (q < a.Nq && hh == 0) a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] = D_q;
+    }
     const float c2 = a.scale * LOG2E;
     f32x16_t dqT[G::NT32];
 #pragma unroll
@@ -592,8 +589,6 @@ void launch_fwd(const FlashArgs& a, hipStream_t st) {
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_bwd(const FlashArgs& a, hipStream_t st) {
-    const int64_t total = (int64_t)a.B * a.H * a.Nq;
-    hipLaunchKernelGGL((flash_prep_kernel<T>), dim3((unsigned)cdiv64(total, NT)), dim3(NT), 0, st, a);
     hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
     hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
     if (a.qsplit > 1) {
