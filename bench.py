@@ -541,6 +541,16 @@ def main():
             ops.set_kernel_backend(rec)
         ops.set_side_stream_enabled(False)  # one stream: event pairs must not straddle kernels of another stream
         trainer.serial_d, trainer.flat_d = True, False
+        # Hold the GPU back while the host queues the step: an event pair then brackets a kernel the queue already holds,
+        # not the few microseconds the host needs to marshal the NEXT launch while the GPU sits idle (call 9: 25.0 us per
+        # launch with a starving queue against 20.6 us in the rocprofv3 trace of the same kernels).
+        if rank == 0 and hasattr(torch.cuda, "_sleep"):
+            sync()
+            t0s = time.time()
+            torch.cuda._sleep(20_000_000)
+            sync()
+            per_cycle = (time.time() - t0s) / 20_000_000
+            torch.cuda._sleep(int(0.25 / max(per_cycle, 1e-11)))
         trainer.train_step(batch, **fixed)
         sync()
         ops.set_side_stream_enabled(True)
