@@ -261,17 +261,26 @@ __device__ __forceinline__ void g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
 
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) as 32x32 MFMA tiles; NST-deep LDS ring.
 // CONV: implicit-GEMM gather.
-// EB: bytes per operand element (2 = bf16, 1 = fp8 e4m3); a k-tile is always 64 bytes of k.
-template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2>
+// EB: bytes per operand element (2 = bf16, 1 = fp8 e4m3).
+// KS: MFMA k-steps (of 32 bytes) per k-tile: 2 -> rows of 64 bytes (the host's k-tile unit, Args2::nkt), 4 -> rows of 128
+// bytes = two host k-tiles per barrier.  The k-loop of a problem with few rows is a latency chain (DMA wait, barrier,
+// LDS reads, MFMAs: ~0.11 us per 64-byte k-tile whatever the tile shape - 2 600 of the 4 000 launches of a C2 step);
+// doubling the tile halves the number of links.
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2, int KS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
-    constexpr int KE = RB / EB;  // k elements per k-tile
+    static_assert(KS == 2 || (KS == 4 && EB == 2), "128-byte k-tiles: bf16 only");
+    constexpr int RBK = 32 * KS;   // bytes per LDS row
+    constexpr int KSF = KS / 2;    // host k-tiles (64 bytes) per kernel k-tile
+    constexpr int KE = RBK / EB;   // k elements per k-tile
+    constexpr int LPR = RBK / 16;  // lanes (16-byte chunks) per row
+    constexpr int RPI = 64 / LPR;  // rows per DMA wave-instruction (1 KiB)
     constexpr int NW = WM * WN, NTH = NW * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int IA = BM / (16 * NW), IB = BN / (16 * NW);  // DMA instructions per wave per k-tile, per operand
-    static_assert(IA >= 1 && IB >= 1 && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile too small for the block");
+    constexpr int IA = BM / (RPI * NW), IB = BN / (RPI * NW);  // DMA instructions per wave per k-tile, per operand
+    static_assert(IA >= 1 && IB >= 1 && BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile too small for the block");
     static_assert(TM >= 1 && TN >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be whole MFMA tiles");
-    constexpr int L = IA + IB;          // DMA instructions per wave per k-tile
-    constexpr int SS = (BM + BN) * RB;  // bytes per ring stage: [A: BM rows][B: BN rows]
+    constexpr int L = IA + IB;           // DMA instructions per wave per k-tile
+    constexpr int SS = (BM + BN) * RBK;  // bytes per ring stage: [A: BM rows][B: BN rows]
     static_assert(NST >= 4 && (NST - 3) * L <= 63, "ring depth / vmcnt range");
     __shared__ __attribute__((aligned(1024))) char smem[NST * SS];  // the ONLY LDS object of the kernel
 
@@ -290,17 +299,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     const int tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
     const int64_t z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int per = (g.nkt + g.splits - 1) / g.splits;
+    const int nkt_all = g.nkt / KSF;  // k-tiles of THIS kernel's size (the host guarantees divisibility)
+    const int per = (nkt_all + g.splits - 1) / g.splits;
     int kt0 = sp * per;
-    if (kt0 > g.nkt) kt0 = g.nkt;
-    const int kt1 = kt0 + per < g.nkt ? kt0 + per : g.nkt;
+    if (kt0 > nkt_all) kt0 = nkt_all;
+    const int kt1 = kt0 + per < nkt_all ? kt0 + per : nkt_all;
     const int nt = __builtin_amdgcn_readfirstlane(kt1 - kt0);
 
-    // ---- DMA source state.  Wave-instruction i of an operand covers rows (i * NW + wave) * 16 .. + 16 of its tile,
-    // lane -> (row = lane / 4, slot = lane % 4) of the lane-linear 1 KiB it writes; the lane fetches chunk
-    // slot ^ ((row >> 2) & 3) of that row (the LDS swizzle, applied on the source side) ----
-    const int drow = lane >> 2;
-    const int csrc = (lane & 3) ^ ((drow >> 2) & 3);
+    // ---- DMA source state.  Wave-instruction i of an operand covers rows (i * NW + wave) * RPI .. + RPI of its tile,
+    // lane -> (row = lane / LPR, slot = lane % LPR) of the lane-linear 1 KiB it writes; the lane fetches chunk
+    // slot ^ swz(row) of that row (the LDS swizzle, applied on the source side).  swz: 64-byte rows (row >> 2) & 3,
+    // 128-byte rows (row >> 1) & 7 - either way the 16 rows one ds_read_b128 phase touches hit 64 distinct banks ----
+    auto swz = [](int row) { return KS == 2 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+    const int drow = lane / LPR;
+    const int csrc = (lane % LPR) ^ swz(drow);
     const char* pb[IB];     // running source pointers, B operand
     int64_t brow_[IB];      // clamped global row of the lane's B chunk
     const char* pa[IA];     // GEMM: running source pointers, A operand
@@ -312,14 +324,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-        int64_t gr = n0 + (i * NW + wave) * 16 + drow;
+        int64_t gr = n0 + (i * NW + wave) * RPI + drow;
         brow_[i] = gr < g.N ? gr : g.N - 1;  // columns >= N are never stored: any valid row will do
     }
     if (CONV) {
         const int hw = g.Hout * g.Wout;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int64_t gm = m0 + (i * NW + wave) * 16 + drow;
+            const int64_t gm = m0 + (i * NW + wave) * RPI + drow;
             rv[i] = gm < g.M;
             const int64_t gmc = rv[i] ? gm : 0;
             const int b = (int)(gmc / hw), rem = (int)(gmc - (int64_t)b * hw);
@@ -334,26 +346,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
         ky = tap / g.KW;
         kx = tap - ky * g.KW;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) pb[i] = g.seg[0].B + brow_[i] * g.seg[0].ldb + (int64_t)kt0 * RB + csrc * 16;
+        for (int i = 0; i < IB; ++i) pb[i] = g.seg[0].B + brow_[i] * g.seg[0].ldb + (int64_t)kt0 * RBK + csrc * 16;
     } else {
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int64_t gr = m0 + (i * NW + wave) * 16 + drow;
+            const int64_t gr = m0 + (i * NW + wave) * RPI + drow;
             arow_[i] = gr < g.M ? gr : g.M - 1;
         }
         // locate k-tile kt0 in the segment list
         int t0 = kt0;
         seg = 0;
-        while (seg + 1 < g.nseg && t0 >= g.seg[seg].nkt) {
-            t0 -= g.seg[seg].nkt;
+        while (seg + 1 < g.nseg && t0 >= g.seg[seg].nkt / KSF) {
+            t0 -= g.seg[seg].nkt / KSF;
             ++seg;
         }
-        seg_left = g.seg[seg].nkt - t0;
+        seg_left = g.seg[seg].nkt / KSF - t0;
         const Seg2 sg = g.seg[seg];
 #pragma unroll
-        for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + (int64_t)t0 * RB + csrc * 16;
+        for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + (int64_t)t0 * RBK + csrc * 16;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + (int64_t)t0 * RB + csrc * 16;
+        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + (int64_t)t0 * RBK + csrc * 16;
     }
 
     // issue the DMA of the next k-tile of this block's range into ring stage `st`
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
             if (seg_left == 0) {  // next segment (uniform branch)
                 ++seg;
                 const Seg2 sg = g.seg[seg];
-                seg_left = sg.nkt;
+                seg_left = sg.nkt / KSF;
 #pragma unroll
                 for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + csrc * 16;
 #pragma unroll
@@ -395,13 +407,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 dma16(pa[i], sbase + i * NW * 1024);
-                pa[i] += RB;
+                pa[i] += RBK;
             }
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            dma16(pb[i], sbase + BM * RB + i * NW * 1024);
-            pb[i] += RB;
+            dma16(pb[i], sbase + BM * RBK + i * NW * 1024);
+            pb[i] += RBK;
         }
     };
 
@@ -413,10 +425,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-    // fragment addressing: lane (r, h), k-step s reads 16 bytes at row r, slot (2 s + h) ^ ((r >> 2) & 3)
-    const int sw = (r >> 2) & 3;
-    const int fo0 = r * RB + ((0 + h) ^ sw) * 16, fo1 = r * RB + ((2 + h) ^ sw) * 16;
-    const int a_base = wr * WTM * RB, b_base = BM * RB + wc * WTN * RB;
+    // fragment addressing: lane (r, h), k-step s reads 16 bytes at row r, slot (2 s + h) ^ swz(r)
+    const int sw = swz(r);
+    auto fofs = [&](int s2) { return r * RBK + (((2 * s2 + h) ^ sw) * 16); };
+    const int fo0 = fofs(0), fo1 = fofs(1);
+    const int a_base = wr * WTM * RBK, b_base = BM * RBK + wc * WTN * RBK;
 
     // ---- pipeline.  DMA runs NST-1 k-tiles ahead of the MFMAs; ONE barrier per k-tile, in the MIDDLE of a tile's MFMA
     // work: the fragments of k-step 1 are requested from LDS before the MFMAs of k-step 0 issue, the fragments of the
@@ -427,9 +440,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     // were all consumed by MFMAs before any wave reached this barrier. ----
     auto frags = [&](const char* st, int fo, short8_t (&xf)[TM], short8_t (&wf)[TN]) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a) xf[a] = *(const short8_t*)(st + a_base + a * 32 * RB + fo);
+        for (int a = 0; a < TM; ++a) xf[a] = *(const short8_t*)(st + a_base + a * 32 * RBK + fo);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) wf[b] = *(const short8_t*)(st + b_base + b * 32 * RB + fo);
+        for (int b = 0; b < TN; ++b) wf[b] = *(const short8_t*)(st + b_base + b * 32 * RBK + fo);
     };
     auto mmas = [&](const short8_t (&xf)[TM], const short8_t (&wf)[TN]) {
 #pragma unroll
@@ -454,7 +467,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
         frags(smem, fo0, xf0, wf0);
     }
     int stage = 0;  // ring slot of tile t
-    if constexpr (EB == 2) {
+    if constexpr (EB == 2 && KS == 4) {
+        // four k-steps per tile: fragments of step s + 1 are requested before the MFMAs of step s issue; the barrier (and
+        // the DMA issue behind it) sits before the MFMAs of the LAST step, with the next tile's step 0 already requested
+        for (int t = 0; t + 1 < nt; ++t) {
+            const char* cur = smem + stage * SS;
+            frags(cur, fo1, xf1, wf1);
+            mmas(xf0, wf0);
+            frags(cur, fofs(2), xf0, wf0);
+            mmas(xf1, wf1);
+            frags(cur, fofs(3), xf1, wf1);
+            mmas(xf0, wf0);
+            const int nstage = stage + 1 == NST ? 0 : stage + 1;
+            wait_tiles<L, NST - 3>(nt - 2 - t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);
+            frags(smem + nstage * SS, fo0, xf0, wf0);
+            mmas(xf1, wf1);
+            stage = nstage;
+        }
+        if (nt > 0) {
+            const char* cur = smem + stage * SS;
+            frags(cur, fo1, xf1, wf1);
+            mmas(xf0, wf0);
+            frags(cur, fofs(2), xf0, wf0);
+            mmas(xf1, wf1);
+            frags(cur, fofs(3), xf1, wf1);
+            mmas(xf0, wf0);
+            mmas(xf1, wf1);
+        }
+    } else if constexpr (EB == 2) {
         for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
             frags(smem + stage * SS, fo1, xf1, wf1);
             mmas(xf0, wf0);
@@ -650,7 +693,9 @@ template <int NST> __global__ __launch_bounds__(256) void gemm2_tt_kernel(Args2 
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
-       CFG_128x128_W8 = 7 };
+       CFG_128x128_W8 = 7,
+       // 128-byte k-tiles (KS = 4): half as many barrier / wait / issue rounds along k, for latency-bound problems
+       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11, CFG_LAST = 11 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -662,7 +707,20 @@ static Cfg2 cfg_dims(int c) {
         case CFG_64x128: return {64, 128, 256};
         case CFG_64x64: return {64, 64, 256};
         case CFG_128x128_W8: return {128, 128, 512};
+        case CFG_64x64_K4: return {64, 64, 256};
+        case CFG_128x64_K4: return {128, 64, 256};
+        case CFG_64x128_K4: return {64, 128, 256};
         default: return {128, 128, 256};
+    }
+}
+static bool cfg_is_k4(int c) { return c >= CFG_64x64_K4 && c <= CFG_128x128_K4; }
+static int cfg_k2_twin(int c) {  // the same block shape with 64-byte k-tiles
+    switch (c) {
+        case CFG_64x64_K4: return CFG_64x64;
+        case CFG_128x64_K4: return CFG_128x64;
+        case CFG_64x128_K4: return CFG_64x128;
+        case CFG_128x128_K4: return CFG_128x128;
+        default: return c;
     }
 }
 
@@ -678,6 +736,15 @@ template <bool CONV, int EB> static void launch_cfg(int c, const Args2& a, unsig
         case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
             hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
+    }
+}
+// 128-byte k-tiles, bf16: ring of 4 stages = the same bytes of k in flight as 8 stages of 64-byte tiles
+template <bool CONV> static void launch_cfg_k4(int c, const Args2& a, unsigned blocks, hipStream_t st) {
+    switch (c) {
+        case CFG_64x64_K4: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_128x64_K4: hipLaunchKernelGGL((gemm2_kernel<128, 64, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
+        case CFG_64x128_K4: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
 
@@ -775,6 +842,16 @@ static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t 
 static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
     int c, s;
     plan2(conv, fp8, a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
+    if (cfg_is_k4(c)) {  // 128-byte k-tiles: bf16, every segment a whole number of them, conv taps uniform per tile
+        bool ok = !fp8 && (!conv || a.Cin % 64 == 0);
+        for (int i = 0; i < a.nseg; ++i) ok = ok && a.seg[i].nkt % 2 == 0;
+        if (!ok) c = cfg_k2_twin(c);
+        else {  // split counts are slices of 128-byte tiles here: no empty slices
+            const int64_t n2 = a.nkt / 2;
+            if (s > n2) s = (int)(n2 > 0 ? n2 : 1);
+            s = (int)cdiv64(n2, cdiv64(n2, s));
+        }
+    }
     const Cfg2 d = cfg_dims(c);
     a.tiles_m = (int)cdiv64(a.M, d.bm);
     a.tiles_n = (int)cdiv64(a.N, d.bn);
@@ -788,6 +865,11 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
         if (conv) launch_cfg<true, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
         else launch_cfg<false, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
         return 3;
+    }
+    if (cfg_is_k4(c)) {
+        if (conv) launch_cfg_k4<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        else launch_cfg_k4<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        return 1;
     }
     if (conv) launch_cfg<true, 2>(c, a, (unsigned)blocks, (hipStream_t)stream);
     else launch_cfg<false, 2>(c, a, (unsigned)blocks, (hipStream_t)stream);

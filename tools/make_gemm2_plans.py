@@ -18,15 +18,16 @@ for path in sys.argv[1:]:
         s, us, k = min(ok)
         cfg = int(k.split(":")[0])
         old = rows.get(key)
-        if old is None or r["calls"] > old[3]:
-            rows[key] = (cfg, s, us, r["calls"], r["us"].get("general", 0.0))
-out = ["// gemm2_plans.inc - measured plans of the pipelined GEMM / conv kernel for the problems of the SD1.5 (C2) step:",
+        if old is None or r["calls"] >= old[3] or path != old[5]:  # later files (newer measurements) win
+            rows[key] = (cfg, s, us, max(r["calls"], old[3] if old else 0), r["us"].get("general", 0.0), path)
+out = ["// gemm2_plans.inc - measured plans of the pipelined GEMM / conv kernel for the problems of the SD1.5 (C2) and SDXL (C4) steps:",
        "// tools/tune_gemm2.py on an MI355X -> tools/make_gemm2_plans.py.  {conv, M, N, k-tiles, batch, tile code, slices}",
-       "// tile codes: 1 128x128, 2 128x64, 3 256x128, 4 64x128, 6 64x64, 7 128x128 with 8 waves.  Trailing comment: us per launch with this plan,",
+       "// tile codes: 1 128x128, 2 128x64, 3 256x128, 4 64x128, 6 64x64, 7 128x128 with 8 waves; 8..11 = 64x64, 128x64, 64x128, 128x128 with",
+       "// 128-byte k-tiles.  Trailing comment: us per launch with this plan,",
        "// with the general 64x64 kernel, calls per step.",
        "static const Plan2Entry g2_plans[] = {"]
 for key in sorted(rows, key=lambda k: (-rows[k][3] * rows[k][2])):
-    cfg, s, us, calls, gen = rows[key]
+    cfg, s, us, calls, gen, _ = rows[key]
     out.append(f"    {{{key[0]}, {key[1]}, {key[2]}, {key[3]}, {key[4]}, {cfg}, {s}}},  // {us:.1f} us (general {gen:.1f}), {calls} calls")
 out.append("};")
 open("comat_amd/csrc/gemm2_plans.inc", "w").write("\n".join(out) + "\n")
