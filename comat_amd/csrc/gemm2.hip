@@ -311,8 +311,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     // slot ^ swz(row) of that row (the LDS swizzle, applied on the source side).  swz: 64-byte rows (row >> 2) & 3,
     // 128-byte rows (row >> 1) & 7 - either way the 16 rows one ds_read_b128 phase touches hit 64 distinct banks ----
     auto swz = [](int row) { return KS == 2 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+    // (the swizzle is a function of the row INSIDE the tile: instruction i of wave w holds rows (i NW + w) RPI + drow, and
+    // NW RPI is a multiple of the swizzle's 16-row period)
+    static_assert((NW * RPI) % 16 == 0, "swizzle period");
     const int drow = lane / LPR;
-    const int csrc = (lane % LPR) ^ swz(drow);
+    const int csrc = (lane % LPR) ^ swz(wave * RPI + drow);
     const char* pb[IB];     // running source pointers, B operand
     int64_t brow_[IB];      // clamped global row of the lane's B chunk
     const char* pa[IA];     // GEMM: running source pointers, A operand
