@@ -14,10 +14,10 @@ from collections import defaultdict
 # (kernel-name fragment, occurrence among the groups with that fragment in launch order) -> label, algorithmic FLOP and
 # bytes of one launch in tools/pmc_targets.py
 ALGO = [
-    (("gemm2_kernel", "true, 2>"), 0, "conv 3x3 B=2 64x64 320->320", 2.0 * 8192 * 320 * 2880, 8192 * 320 * 2 * 2 + 320 * 2880 * 2),
-    (("gemm2_kernel", "true, 2>"), 1, "conv 3x3 B=1 128x128 512->512 (VAE)", 2.0 * 16384 * 512 * 4608, 16384 * 512 * 2 * 2 + 512 * 4608 * 2),
+    (("gemm2_kernel", "true, 2, "), 0, "conv 3x3 B=2 64x64 320->320", 2.0 * 8192 * 320 * 2880, 8192 * 320 * 2 * 2 + 320 * 2880 * 2),
+    (("gemm2_kernel", "true, 2, "), 1, "conv 3x3 B=1 128x128 512->512 (VAE)", 2.0 * 16384 * 512 * 4608, 16384 * 512 * 2 * 2 + 512 * 4608 * 2),
     (("gemm2_tt_kernel",), 0, "LoRA weight gradient 320x128 over 8192 tokens", 2.0 * 320 * 128 * 8192, 8192 * (320 + 128) * 2 + 320 * 128 * 8),
-    (("gemm2_kernel", "false, 2>"), 0, "GEGLU projection 8192x2560x320", 2.0 * 8192 * 2560 * 320, (8192 * 320 + 2560 * 320 + 8192 * 2560) * 2),
+    (("gemm2_kernel", "false, 2, "), 0, "GEGLU projection 8192x2560x320", 2.0 * 8192 * 2560 * 320, (8192 * 320 + 2560 * 320 + 8192 * 2560) * 2),
     (("flash_fwd_kernel",), 0, "fused attention fwd 2x8 heads, 4096^2, d=40", 4.0 * 16 * 4096 * 4096 * 40, 4 * 2 * 4096 * 320 * 2),
     (("flash_dkdv_kernel",), 0, "fused attention bwd dK/dV", 6.0 * 16 * 4096 * 4096 * 40, 6 * 2 * 4096 * 320 * 2),
     (("flash_dq_kernel",), 0, "fused attention bwd dQ", 4.0 * 16 * 4096 * 4096 * 40, 5 * 2 * 4096 * 320 * 2),
