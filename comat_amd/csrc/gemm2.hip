@@ -1,4 +1,5 @@
-// gemm2.hip — LDS-DMA pipelined bf16 MFMA GEMM / K-segmented GEMM / implicit-GEMM conv2d for gfx950 (CDNA4).
+// gemm2.hip — LDS-DMA pipelined MFMA GEMM / K-segmented GEMM / implicit-GEMM conv2d for gfx950 (CDNA4): bf16 operands, an
+// fp8 (e4m3) variant of the same kernel, and a k-major x k-major variant for the LoRA weight gradients.
 //
 // The k-contiguous bf16 contractions carry ~all FLOPs of the CoMat step (every frozen Linear / 1x1 conv, the LoRA
 // "frozen + low-rank" K-segmented products, every 3x3 conv of the UNets and the VAE).  The general kernel of gemm.hip
@@ -7,11 +8,12 @@
 // LDS-bound at ~10 % of the matrix peak (profiles/r01_pmc_conv_gemm_attnmap.txt).  This kernel is built around what
 // bounds it instead:
 //   * operands go global -> LDS by DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR round trip, no
-//     ds_write), 4-deep LDS ring, ONE s_barrier per k-tile, counted s_waitcnt vmcnt(N) so that two k-tiles stay in
-//     flight across every barrier (cdna_hip_programming.md section 5: "pipelining across barriers");
+//     ds_write), NST-deep LDS ring (4..8 stages), ONE s_barrier per k-tile, counted s_waitcnt vmcnt(N) so that NST-3
+//     k-tiles stay in flight across every barrier (cdna_hip_programming.md section 5: "pipelining across barriers");
 //   * each wave owns 2x2 (or 2x1) MFMA tiles of 32x32: 4 fragment reads feed 4 MFMAs (half the LDS read traffic per
 //     FLOP), accumulators stay in registers for the whole k-loop;
-//   * LDS image = rows of 64 bytes (32 bf16 of k), 16-byte chunk c of row r stored at slot c ^ ((r >> 2) & 3): the four
+//   * LDS image = rows of 64 bytes (32 bf16 of k; 128-byte rows with their own swizzle in the KS = 4 shapes), 16-byte
+//     chunk c of row r stored at slot c ^ ((r >> 2) & 3): the four
 //     16-lane groups of a ds_read_b128 then touch all 64 banks exactly once (conflict-free without padding, which the
 //     lane-linear DMA destination would not allow).  The swizzle is applied on the SOURCE address of the DMA and on the
 //     fragment read (both sides, rule 21 of the guide);
