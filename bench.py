@@ -465,17 +465,19 @@ def main():
     # The eager step is host-bound (~17 k launches at ~10 us of host time each): when the launch topology is static
     # (C2: every denoise step is trained, no attribute-concentration masks) and this is a single-process run, the
     # whole step is captured once into a hipGraph (comat_amd.step.GraphedStep) and the timed steps are replays with
-    # fresh inputs.  COMAT_STEP_GRAPH=0 times eager launches.  Capture happens here, before warm-up and timing.
+    # fresh inputs (with more than one rank the graph holds forward + backward; the RCCL all-reduces and the optimizer
+    # launches follow eagerly).  COMAT_STEP_GRAPH=0 times eager launches.  Capture happens here, before warm-up and timing.
     stepper, graph_note = None, "eager launches"
     mode = os.environ.get("COMAT_STEP_GRAPH", "auto")  # auto | 1 (graph) | 0 (eager)
-    if (not args.selftest and world == 1 and not scfg.attrcon and mode != "0" and "training_steps" in fixed):
+    if (not args.selftest and not scfg.attrcon and mode != "0" and "training_steps" in fixed):
         from comat_amd.step import GraphedStep
         cand = GraphedStep(trainer)
         try:
             cand(batch, **fixed)  # eager step + capture
             cand(batch, **fixed)  # first replay
             sync()
-            stepper, graph_note = cand, "whole step replayed from one hipGraph"
+            stepper, graph_note = cand, ("whole step replayed from one hipGraph" if not cand.split() else
+                                         "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")
         except Exception as e:  # noqa: BLE001 - stay measurable: fall back to eager launches, loudly
             print(f"[bench] step-graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             graph_note = f"eager launches (graph capture failed: {type(e).__name__})"

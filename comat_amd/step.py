@@ -234,6 +234,18 @@ class CoMatTrainer:
             logs["D_loss"] = self._d_step(out, batch)
         return logs
 
+    def _forward_backward_joined(self, batch, fixed):
+        """_forward_backward with every stream it forked joined again: the capturable part of a data-parallel step (the
+        gradient exchange and the optimizer follow outside the graph, see GraphedStep)."""
+        logs = self._forward_backward(batch, fixed)
+        if self.device.type == "cuda":
+            ops.join_side_streams()
+            if self._d_pending:
+                torch.cuda.current_stream(self.device).wait_stream(self._d_stream)
+                self._d_pending = False
+                self._d_keep = None
+        return logs
+
     def _apply_updates(self):
         """all-reduce(mean) of the flat gradient buffers (RCCL, async) + clip + AdamW for G and D.  The G all-reduce is
         launched as soon as the G backward is queued, i.e. before the concurrently running D step is joined: on
@@ -283,8 +295,10 @@ class GraphedStep:
     Streams inside the capture: the LoRA weight gradients of the G backward fork onto a side stream, the D step forks onto
     its own stream (its weight gradients stay on that stream: a fork from a forked stream crashes hipStreamEndCapture on
     ROCm 7.2 - located stage by stage in profiles/r02_c_stepgraph_stages.txt); both rejoin before the optimizer.
-    Not captured (the eager path runs instead): attribute-concentration steps (their masks are resized on the host),
-    data-parallel runs (the RCCL all-reduce stays outside graphs until it can be tested on a multi-GPU node).
+    Data-parallel runs (and COMAT_GRAPH_SPLIT=1): the graph ends where the streams have rejoined after the backward passes;
+    the RCCL all-reduces and the two clip + AdamW updates (a dozen launches) follow eagerly, exactly as in the eager step -
+    no collective is ever captured.
+    Not captured (the eager path runs instead): attribute-concentration steps (their masks are resized on the host).
     Results are bit-identical to eager steps (`tests/test_step.py::test_graphed_step_matches_eager`)."""
 
     BATCH_KEYS = ("prompt_embeds", "negative_prompt_embeds", "gan_null_embeds", "latents", "real_latents",
@@ -298,9 +312,14 @@ class GraphedStep:
         self.pool = None
 
     def supported(self, batch):
-        from .dist import world_size
-        return (self.tr.device.type == "cuda" and not self.tr.cfg.attrcon and world_size() == 1
+        return (self.tr.device.type == "cuda" and not self.tr.cfg.attrcon
                 and batch.get("noises") is not None and batch.get("latents") is not None)
+
+    @staticmethod
+    def split():
+        """graph = forward + backward only; exchange + optimizer eager (always so with more than one rank)"""
+        from .dist import world_size
+        return world_size() > 1 or os.environ.get("COMAT_GRAPH_SPLIT") == "1"
 
     def _stage(self, batch):
         """copy the batch into the fixed-address buffers (allocating them at the first call / on a shape change)"""
@@ -340,7 +359,8 @@ class GraphedStep:
             tr.blip.static_tables = None
             real_tab = tr.blip.tables(res, res, crop)
             tr.blip.static_tables = st
-        key = tuple(training_steps)
+        split = self.split()
+        key = (tuple(training_steps), split)
         ent = self.graphs.get(key)
         # D step inside the capture: forked onto its own stream (it overlaps the G backward chain: 187 -> 168 ms per C2 step
         # on MI355X) with its weight gradients kept on that stream - a fork from a forked stream (nested) crashes
@@ -363,7 +383,10 @@ class GraphedStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
-                out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+                if split:
+                    out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
+                else:
+                    out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
             if self.pool is None:
                 self.pool = g.pool()
             self.graphs[key] = (g, out)
@@ -373,5 +396,8 @@ class GraphedStep:
         tr.blip.static_tables.load(real_tab)
         g.replay()
         out = dict(out)
+        if split:
+            tr._apply_updates()
+            out["grad_norm_sq"] = tr.opt.gnorm_sq
         out["training_steps"], out["crop"] = list(training_steps), crop
         return out

@@ -290,13 +290,17 @@ def test_graphed_step_wrapper_runs_eager_without_a_gpu(sim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_graphed_step_matches_eager(hip, dtype):
+def test_graphed_step_matches_eager(hip, dtype, split, monkeypatch):
     """The whole optimisation step replayed from ONE hipGraph (G fwd/bwd, D fwd/bwd on its stream, side-stream weight
     gradients, clip + AdamW with the device-side step count) against eager steps: different noises, latents, prompts and
     crops per step (graph inputs), two different trained-step lists (two graphs sharing one memory pool) — parameters of
-    G and D, the optimizer moments and the logged losses stay bit-identical over 6 steps."""
+    G and D, the optimizer moments and the logged losses stay bit-identical over 6 steps.  split: the form data-parallel
+    runs use - the graph ends after the backward passes, gradient exchange and optimizer launches follow eagerly."""
     from comat_amd.step import GraphedStep
+    if split:
+        monkeypatch.setenv("COMAT_GRAPH_SPLIT", "1")
     cfg, batch, W, tr_e = make_world(dtype, hip, False)
     cfg, _, _, tr_g = make_world(dtype, hip, False)
     gs = GraphedStep(tr_g)
