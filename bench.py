@@ -472,20 +472,35 @@ def main():
     if (not args.selftest and not scfg.attrcon and mode != "0" and "training_steps" in fixed):
         from comat_amd.step import GraphedStep
         cand = GraphedStep(trainer)
+
+        def agree(value, op):
+            """the same decision on every rank (each step holds two all-reduces: ranks that took different branches
+            would leave the collectives of the timed region unmatched)"""
+            if world == 1:
+                return value
+            t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=op)
+            return float(t)
+
+        ok, err = 1, ""
         try:
-            cand(batch, **fixed)  # eager step + capture
+            cand(batch, **fixed)  # one eager step (with its all-reduces), then the capture (no collective inside)
+        except Exception as e:  # noqa: BLE001 - stay measurable: fall back to eager launches, loudly
+            ok, err = 0, type(e).__name__
+            print(f"[bench] step-graph capture failed ({err}: {e}); timing eager launches", file=sys.stderr)
+        ok = agree(ok, torch.distributed.ReduceOp.MIN) if world > 1 else ok
+        if ok:
             cand(batch, **fixed)  # first replay
             sync()
             stepper, graph_note = cand, ("whole step replayed from one hipGraph" if not cand.split() else
                                          "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")
-        except Exception as e:  # noqa: BLE001 - stay measurable: fall back to eager launches, loudly
-            print(f"[bench] step-graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            graph_note = f"eager launches (graph capture failed: {type(e).__name__})"
+        else:
+            graph_note = f"eager launches (graph capture failed on some rank{': ' + err if err else ''})"
             trainer.blip.static_tables = None
             sync()
         if stepper is not None and mode == "auto":
             # eager launches pay ~10 us of host time per kernel, graph replay pays the capture-safe stream topology (no
-            # nested forks): take whichever is faster on this box (3 steps each)
+            # nested forks): take whichever is faster on this box (3 steps each; the slowest rank decides for all)
             def probe(fn):
                 fn()
                 sync()
@@ -497,6 +512,9 @@ def main():
             trainer.serial_d, trainer.flat_d = False, False
             t_eager = probe(lambda: trainer.train_step(batch, **fixed))
             t_graph = probe(lambda: stepper(batch, **fixed))
+            if world > 1:
+                t_eager = agree(t_eager, torch.distributed.ReduceOp.MAX)
+                t_graph = agree(t_graph, torch.distributed.ReduceOp.MAX)
             if t_eager < t_graph:
                 stepper, graph_note = None, f"eager launches (probe: eager {t_eager * 1e3:.0f} ms < graph {t_graph * 1e3:.0f} ms)"
             else:

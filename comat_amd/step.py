@@ -382,7 +382,10 @@ class GraphedStep:
                 tr.D.bank.mark_updated()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool):
+            # more than one rank: RCCL's watchdog thread polls events while we capture - only THIS thread's calls may
+            # invalidate the capture ("thread_local"; the default "global" mode would abort it)
+            mode = {"capture_error_mode": "thread_local"} if split else {}
+            with torch.cuda.graph(g, pool=self.pool, **mode):
                 if split:
                     out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
                 else:
