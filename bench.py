@@ -469,7 +469,10 @@ def main():
     # launches follow eagerly).  COMAT_STEP_GRAPH=0 times eager launches.  Capture happens here, before warm-up and timing.
     stepper, graph_note = None, "eager launches"
     mode = os.environ.get("COMAT_STEP_GRAPH", "auto")  # auto | 1 (graph) | 0 (eager)
-    if (not args.selftest and not scfg.attrcon and mode != "0" and "training_steps" in fixed):
+    # more than one rank: the split graph (forward + backward captured, exchange + optimizer eager) is validated on one GPU
+    # only (COMAT_GRAPH_SPLIT=1); until it has run on a multi-GPU node it is opt-in there (COMAT_STEP_GRAPH=1)
+    if (not args.selftest and not scfg.attrcon and mode != "0" and "training_steps" in fixed
+            and (world == 1 or mode == "1")):
         from comat_amd.step import GraphedStep
         cand = GraphedStep(trainer)
 
