@@ -328,14 +328,63 @@ __global__ void gn_reduce_finalize_kernel(const double* __restrict__ ws, int nbl
 // grid-stride kernel that re-derives group index, statistics, gamma and beta per ELEMENT (an integer division and five
 // dependent loads per 2 bytes of data) ran at ~1 TB/s on MI355X (round 1); here the inner loop is one 16-byte load per operand, 8 FMAs and
 // one 16-byte store.  Same arithmetic, same operation order per element.
-template <typename T, int MODE>
+// FIN (option norm_fused = 2): no reduce / finalize launch between the statistics pass and this kernel - every block
+// combines the (<= 64) per-block partial slabs of its sample's groups itself, in a fixed order (8 lanes per group take
+// slabs sub, sub + 8, ...; then a fixed butterfly), before it touches the data.  Block 0 of a sample stores mean / rstd
+// for the backward pass.
+struct GnFin {
+    const double* part;  // the workspace of the statistics pass (slab 1 + k at part + (1 + k) * B * G * 2)
+    float* stats_out;    // MODE 0: [B, G, 2]
+    int nblk;
+    double count;
+    float eps;
+};
+
+template <typename T, int MODE, bool FIN = false>
 __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ stats, const double* __restrict__ ws,
                                                         T* __restrict__ out, int HW, int C, int G, int silu,
-                                                        int rows_per_block, const T* __restrict__ add) {
+                                                        int rows_per_block, const T* __restrict__ add, GnFin fin) {
     constexpr int EPV = 16 / sizeof(T);
     const int b = blockIdx.y;
+    __shared__ float sm_a[FIN ? 64 : 1], sm_b[FIN ? 64 : 1];
+    if (FIN) {
+        constexpr int SUB = 8;
+        const int g2 = threadIdx.x / SUB, sub = threadIdx.x % SUB;
+        if (g2 < G) {  // G is a multiple of 8 and <= 32 here (host): whole waves take this branch
+            const int64_t n = (int64_t)gridDim.y * G * 2;
+            const int64_t i = (int64_t)b * G + g2;
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = sub; k < fin.nblk; k += SUB) {
+                s1 += fin.part[(int64_t)(1 + k) * n + 2 * i];
+                s2 += fin.part[(int64_t)(1 + k) * n + 2 * i + 1];
+            }
+#pragma unroll
+            for (int o = 1; o < SUB; o <<= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if (sub == 0) {
+                if (MODE == 0) {
+                    const double mean = s1 / fin.count;
+                    double var = s2 / fin.count - mean * mean;
+                    if (var < 0) var = 0;
+                    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)fin.eps));
+                    sm_a[g2] = m;
+                    sm_b[g2] = r;
+                    if (blockIdx.x == 0) {
+                        fin.stats_out[2 * i] = m;
+                        fin.stats_out[2 * i + 1] = r;
+                    }
+                } else {
+                    sm_a[g2] = (float)s1;
+                    sm_b[g2] = (float)s2;
+                }
+            }
+        }
+        __syncthreads();
+    }
     const int VPR = C / EPV;
     const int R = VPR >= NT ? 1 : NT / VPR;
     const int cpg = C / G;
@@ -353,14 +402,20 @@ __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x,
         float gm[EPV], bt[EPV], mu[EPV], rs[EPV], s1[EPV], s2[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-            const int64_t sg = (int64_t)b * G + (c0 + e) / cpg;
+            const int grp = (c0 + e) / cpg;
+            const int64_t sg = (int64_t)b * G + grp;
             gm[e] = gamma[c0 + e];
             bt[e] = beta[c0 + e];
-            mu[e] = stats[2 * sg];
-            rs[e] = stats[2 * sg + 1];
+            if (FIN && MODE == 0) {
+                mu[e] = sm_a[grp];
+                rs[e] = sm_b[grp];
+            } else {
+                mu[e] = stats[2 * sg];
+                rs[e] = stats[2 * sg + 1];
+            }
             if (MODE == 1) {
-                s1[e] = (float)ws[2 * sg];
-                s2[e] = (float)ws[2 * sg + 1];
+                s1[e] = FIN ? sm_a[grp] : (float)ws[2 * sg];
+                s2[e] = FIN ? sm_b[grp] : (float)ws[2 * sg + 1];
             }
         }
         for (int r = r0 + rsub; r < r1; r += R) {
@@ -412,45 +467,63 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
 
 // workspace: [GN_TICKETS uint32 ticket counters (zeroed once by the caller, re-armed by the kernels) | doubles]
 constexpr int GN_TICKETS = 1024;
-static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) != 0 && B <= GN_TICKETS; }
+static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) == 1 && B <= GN_TICKETS; }
+// norm_fused = 2: the apply kernel finalises (gn_vapply2_kernel<.., FIN>); needs whole waves of 8-lane groups
+static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_FUSED) == 2 && G % 8 == 0 && G <= 32; }
 
 template <typename T>
 static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
                        int64_t HW, int C, int G, float eps, int silu, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
-    const int rpb = gn_rows_per_block(B, HW, C, EPV);
+    const bool fin = gn_fin_in_apply(G);
+    int rpb = gn_rows_per_block(B, HW, C, EPV);
+    if (fin && rpb < cdiv64(HW, 64)) rpb = (int)cdiv64(HW, 64);  // at most 64 partial slabs per sample
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
-    const bool fused = gn_two_launch(B);
+    const bool fused = !fin && gn_two_launch(B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                        (const float*)nullptr, ws, (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, stats,
                        (double)HW * (C / G), eps);
-    if (!fused)
+    if (!fused && !fin)
         hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(B * G), dim3(64), 0, st, (const double*)ws, (int)sg.x, B * G,
                            stats, (double)HW * (C / G), eps);
     const int arpb = gn_apply_rows_per_block(B, HW, C, EPV);
-    hipLaunchKernelGGL((gn_vapply2_kernel<T, 0>), dim3((unsigned)cdiv64(HW, arpb), (unsigned)B), dim3(NT), 0, st, (const T*)x,
-                       (const T*)nullptr, gamma, beta, (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G,
-                       silu, arpb, (const T*)nullptr);
+    const dim3 ag((unsigned)cdiv64(HW, arpb), (unsigned)B);
+    const GnFin f = {ws, stats, (int)sg.x, (double)HW * (C / G), eps};
+    if (fin)
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
+                           (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
+                           f);
+    else
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, false>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
+                           (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
+                           f);
 }
 
 template <typename T>
 static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                        double* ws_all, int B, int64_t HW, int C, int G, int silu, const void* add, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
-    const int rpb = gn_rows_per_block(B, HW, C, EPV);
+    const bool fin = gn_fin_in_apply(G);
+    int rpb = gn_rows_per_block(B, HW, C, EPV);
+    if (fin && rpb < cdiv64(HW, 64)) rpb = (int)cdiv64(HW, 64);
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
-    const bool fused = gn_two_launch(B);
+    const bool fused = !fin && gn_two_launch(B);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
                        (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, (float*)nullptr, 0.0, 0.0f);
-    if (!fused) hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
+    if (!fused && !fin) hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
     const int arpb = gn_apply_rows_per_block(B, HW, C, EPV);
-    hipLaunchKernelGGL((gn_vapply2_kernel<T, 1>), dim3((unsigned)cdiv64(HW, arpb), (unsigned)B), dim3(NT), 0, st, (const T*)x,
-                       (const T*)dy, gamma, beta, stats, (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb,
-                       (const T*)add);
+    const dim3 ag((unsigned)cdiv64(HW, arpb), (unsigned)B);
+    const GnFin f = {ws, nullptr, (int)sg.x, 0.0, 0.0f};
+    if (fin)
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 1, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
+                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f);
+    else
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 1, false>), ag, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
+                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f);
 }
 
 static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int64_t HW) {

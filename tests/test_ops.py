@@ -26,6 +26,11 @@ def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
     return x.to(dtype).float()  # value representable in `dtype`, held in fp32
 
 
+def rel_l2(got, ref):
+    got, ref = got.detach().double().cpu().reshape(-1), ref.detach().double().cpu().reshape(-1)
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
 def check(got, ref, dtype, what="", factor=1.0):
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
@@ -150,6 +155,37 @@ def test_groupnorm(dev, dtype, silu, shape):
     y.backward(dv(gy, dev, dtype))
     check(y, yr, dtype, "gn fwd")
     check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, "gn bwd", factor=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4096, 320, 32), (2, 64, 1280, 32), (1, 16384, 128, 32), (2, 50, 32, 8), (1, 130, 320, 32)])
+def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
+    """option norm_fused: 1 = the last-arriving statistics block finalises, 2 = the prologue of the apply kernel does (no
+    reduce launch in either).  Same statistics up to the fp64 summation order of the per-block partials: outputs and
+    gradients agree with the three-launch form to fp32 rounding, and with the torch reference as in test_groupnorm."""
+    B_, HW, C, G = shape
+    x = rnd(B_, HW, C, dtype=dtype, seed=1) * 2 + 0.7
+    gamma, beta = rnd(C, seed=2) * 0.5 + 1, rnd(C, seed=3) * 0.3
+    gy = rnd(B_ * HW, C, dtype=dtype, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr.permute(0, 2, 1), G, gamma, beta, eps=1e-5).permute(0, 2, 1)).reshape(B_ * HW, C)
+    gy2 = rnd(B_ * HW, C, dtype=dtype, seed=5)  # cotangent of the bypass branch: the `add` operand of the backward kernel
+    (yr * gy).sum().backward()
+    xr.grad += gy2.reshape(B_, HW, C)
+    res = []
+    for mode in (0, 1, 2):
+        _set_opts(norm_fused=mode)
+        xd = dv(x.reshape(B_ * HW, C), hip, dtype, grad=True)
+        y, xa = ops.group_norm_fork(xd, dv(gamma, hip), dv(beta, hip), B_, HW, G=G, eps=1e-5, silu=True)
+        ((y.float() * dv(gy, hip).float()).sum() + (xa.float() * dv(gy2, hip).float()).sum()).backward()
+        res.append((y.detach().float(), xd.grad.float()))
+        check(y, yr, dtype, f"gn fwd (norm_fused={mode})")
+        check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, f"gn bwd (norm_fused={mode})", factor=2)
+    lim = 2e-6 if dtype == torch.float32 else 1e-2  # bf16: an output may flip by one ulp
+    for mode in (1, 2):
+        for a, b_, name in zip(res[0], res[mode], ("y", "dx")):
+            assert rel_l2(b_, a) < lim, f"norm_fused={mode}: {name} differs from the three-launch form by {rel_l2(b_, a):.2e}"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
