@@ -58,7 +58,8 @@ def step_tflop(total_step, K, gan, sdxl=False, res=512):
     return f
 
 
-MFMA_CALLS = ("gemm", "gemm_segments", "conv2d", "flash_attn_fwd", "flash_attn_bwd")
+MFMA_CALLS = ("gemm", "gemm_segments", "conv2d", "flash_attn_fwd", "flash_attn_bwd", "gemm_tt_grouped")
+NOT_LAUNCHES = ("tt_group_ok", "gemm_workspace_bytes")  # helpers of the backend that enqueue nothing
 
 
 class CallRecorder:
@@ -84,6 +85,8 @@ class CallRecorder:
         fn = getattr(self.inner, name)
         if not callable(fn):
             return fn
+        if name in NOT_LAUNCHES:
+            return fn
         if name not in MFMA_CALLS:
             def counted(*a, **kw):
                 self.other[name] = self.other.get(name, 0) + 1
@@ -105,7 +108,7 @@ class CallRecorder:
                 self.nulls.append((n0, n1))
             if rec is None:
                 from comat_amd import _hip
-                kid = _hip.last_gemm_kernel() if name in ("gemm", "gemm_segments", "conv2d") else -1
+                kid = _hip.last_gemm_kernel() if name in ("gemm", "gemm_segments", "conv2d", "gemm_tt_grouped") else -1
                 self.calls[sig] = [name, a, kw, self._flops(name, a, kw), 1, kid, self._bytes(name, a, kw)]
             else:
                 rec[4] += 1
@@ -119,6 +122,11 @@ class CallRecorder:
 
     @classmethod
     def _sig(cls, name, a, kw):
+        if name == "gemm_tt_grouped":  # a group of k-major weight-gradient problems: shapes with their multiplicities
+            shapes = {}
+            for p in a[0]:
+                shapes[p[3:6]] = shapes.get(p[3:6], 0) + 1
+            return f"tt_grouped n={len(a[0])} " + " ".join(f"{m}x{n}x{k}*{c}" for (m, n, k), c in sorted(shapes.items()))
         if name == "gemm":
             return (f"gemm M={a[3]} N={a[4]} K={a[5]} ld={a[6]},{a[7]},{a[8]} tA={int(kw.get('transA', False))} "
                     f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={a[2].dtype} "
@@ -135,6 +143,8 @@ class CallRecorder:
 
     @staticmethod
     def _flops(name, a, kw):
+        if name == "gemm_tt_grouped":
+            return sum(2.0 * p[3] * p[4] * p[5] for p in a[0])
         if name == "gemm":
             M, N, K = a[3], a[4], a[5]
             b = kw.get("batch", (1, 1))
@@ -153,6 +163,8 @@ class CallRecorder:
     def _bytes(name, a, kw):
         """algorithmic HBM bytes of one launch: every operand read once, the output written once"""
         sz = lambda t: t.element_size()
+        if name == "gemm_tt_grouped":  # both operands once, the fp32 output read + written
+            return sum((p[3] + p[4]) * p[5] * 2 + 2 * p[3] * p[4] * 4 for p in a[0])
         if name == "gemm":
             M, N, K = a[3], a[4], a[5]
             b = kw.get("batch", (1, 1))

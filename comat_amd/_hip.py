@@ -56,12 +56,18 @@ class ConvParams(C.Structure):
     ]
 
 
+class TTProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("M", C.c_int64), ("N", C.c_int64),
+                ("K", C.c_int64), ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64)]
+
+
 _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> argtypes (restype is int unless noted); mirrors include/comat_hip.h one to one.
 SIGNATURES = {
     "comat_gemm": [C.POINTER(GemmParams), _vp],
     "comat_gemm_segments": [C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, _vp],
+    "comat_gemm_tt_grouped": [C.POINTER(TTProblem), _i32, _i32, _vp, _i64, _vp],
     "comat_conv2d": [C.POINTER(ConvParams), _vp],
     "comat_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp],
     "comat_groupnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i32, _vp],
@@ -126,14 +132,15 @@ def load_library(path: str | None = None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, C.c_int)
-    if lib.comat_abi_version() != 3:
+    if lib.comat_abi_version() != 4:
         raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
 
 GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_kernel (LDS-DMA pipelined)",
-                     2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)"}
+                     2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)",
+                     4: "gemm2_tt_group_kernel (grouped k-major products)"}
 
 
 def last_gemm_kernel() -> int:
@@ -263,6 +270,25 @@ class HipKernels:
         ws = self._workspace(Cout.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_gemm_segments(C.byref(p), arr, n, _stream()), "comat_gemm_segments")
+
+    @staticmethod
+    def tt_group_ok(A, B, Cacc, M, N, K, lda, ldb, ldc):
+        """what comat_gemm_tt_grouped takes (include/comat_hip.h); anything else goes through gemm()"""
+        return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and Cacc.dtype == torch.float32
+                and M >= 8 and N >= 8 and K >= 1 and M % 8 == 0 and N % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0
+                and ldc % 4 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0 and Cacc.data_ptr() % 16 == 0)
+
+    def gemm_tt_grouped(self, problems):
+        """C_p[M, N] (fp32) += A_p^T B_p for independent problems [(A [K, M] ld lda, B [K, N] ld ldb, C, M, N, K, lda, ldb,
+        ldc)] in as few launches as possible (<= 48 problems each); the C_p must not overlap."""
+        n = len(problems)
+        arr = (TTProblem * n)()
+        for i, (A, B, Cacc, M, N, K, lda, ldb, ldc) in enumerate(problems):
+            assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and Cacc.dtype == torch.float32
+            e = arr[i]
+            e.A, e.B, e.C, e.M, e.N, e.K, e.lda, e.ldb, e.ldc = _ptr(A), _ptr(B), _ptr(Cacc), M, N, K, lda, ldb, ldc
+        ws = self._workspace(problems[0][0].device)
+        _check(_lib.comat_gemm_tt_grouped(arr, n, BF16, ws.data_ptr(), self.WS_BYTES, _stream()), "comat_gemm_tt_grouped")
 
     def transpose_cast_tiles(self, src, dst, tiles):
         assert src.dtype == torch.float32 and tiles.dtype == torch.int64 and tiles.shape[1] == 6

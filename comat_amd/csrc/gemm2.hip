@@ -695,6 +695,259 @@ template <int NST> __global__ __launch_bounds__(256) void gemm2_tt_kernel(Args2 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GROUPED k-major products: up to TT_MAXP independent problems  C_p[M_p, N_p] += A_p^T B_p  (fp32 accumulate in place)
+// in ONE launch.  The LoRA weight gradients of a step are ~720 such problems (320 x 128 outputs over 8 192 tokens and
+// the like), each far too small to fill the chip and each paying the serial split-K combine of its own launch
+// (profiles/r02_h_mb_tt.txt: 24 us per launch, 30 TFLOP/s).  They depend on nothing but saved activations and nobody
+// reads them before the optimizer, so the host queues them (comat_amd/ops.py: TTQueue) and hands them over in groups:
+// the launch then has thousands of workgroups, the split-K combines of different tiles overlap, and the per-launch
+// latencies are paid once per group.
+// The problem table travels in the KERNEL ARGUMENTS (72 bytes per problem, < 4 KiB in all): no device-side table to
+// upload, and a captured hipGraph node carries it by value.
+// Same tile machinery as gemm2_tt_kernel (128 x 128 tile, 4 waves, DMA ring, ds_read_b64_tr_b16 fragments); new here:
+// any K >= 1 (k-rows beyond K are DMA'd from the zero page, so the 77-token text projections join the group), and a
+// per-problem split count chosen by the host for the GROUP (long slices when the group fills the chip anyway).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TT_MAXP = 48;
+
+struct TTProb {
+    const char* A;
+    const char* B;
+    float* C;
+    int M, N, K;
+    int lda, ldb;  // bytes
+    int ldc;       // elements
+    int tiles_n, tiles, splits;
+    int tile0, slab0;  // first ticket counter / first 64 KiB slab of this problem in the workspace
+};
+static_assert(sizeof(TTProb) == 72, "TTProb layout");
+
+struct TTGroupArgs {
+    TTProb prob[TT_MAXP];
+    int blk0[TT_MAXP + 1];  // first work item of every problem (blk0[nprob] = number of work items)
+    int nprob;
+    float* ws;
+};
+static_assert(sizeof(TTGroupArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
+template <int NST> __global__ __launch_bounds__(256, 2) void gemm2_tt_group_kernel(TTGroupArgs g) {
+    constexpr int BM = 128, BN = 128, NW = 4, NTH = 256, WTM = 64, WTN = 64, TM = 2, TN = 2;
+    constexpr int RBT = 256, OPB = BK * RBT, SS = 2 * OPB, IO = BK / (4 * NW), L = 2 * IO;
+    static_assert(IO == 2 && (NST - 3) * L <= 63, "k-major tile geometry");
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // work item -> problem (binary search over the kernel-argument table: scalar loads only)
+    const int lin = __builtin_amdgcn_readfirstlane((int)xcd_chunk_map(blockIdx.x, gridDim.x));
+    int lo = 0, hi = g.nprob;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (lin >= g.blk0[mid]) lo = mid;
+        else hi = mid;
+    }
+    const TTProb& P = g.prob[lo];
+    const int local = lin - g.blk0[lo];
+    // tile-fastest: neighbouring work items (same XCD chunk) contract the same k-slice of one shared operand
+    const int tile = __builtin_amdgcn_readfirstlane(local % P.tiles);
+    const int sp = __builtin_amdgcn_readfirstlane(local / P.tiles);
+    const int tn = tile % P.tiles_n, tm = tile / P.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int K = P.K, M = P.M, N = P.N, splits = P.splits;
+    const int nkt = (K + BK - 1) / BK;
+    const int per = (nkt + splits - 1) / splits;
+    int kt0 = sp * per;
+    if (kt0 > nkt) kt0 = nkt;
+    const int kt1 = kt0 + per < nkt ? kt0 + per : nkt;
+    const int nt = __builtin_amdgcn_readfirstlane(kt1 - kt0);
+
+    const int kr = lane >> 4, chunk = (lane & 15) ^ (4 * kr);
+    int64_t ca = m0 + chunk * 8, cb = n0 + chunk * 8;
+    if (ca > M - 8) ca = M - 8;
+    if (cb > N - 8) cb = N - 8;
+    const char* abase = P.A + ca * 2;
+    const char* bbase = P.B + cb * 2;
+    const int64_t lda = P.lda, ldb = P.ldb;
+    const char* zsrc = (const char*)g_zero_page + (lane & 15) * 16;
+    int krow0 = kt0 * BK + wave * 4 + kr;  // k-row of DMA instruction 0 of the next tile to issue (instruction i: + 16 i)
+    const char* pa[IO];
+    const char* pb[IO];
+#pragma unroll
+    for (int i = 0; i < IO; ++i) {
+        pa[i] = abase + (int64_t)(krow0 + i * NW * 4) * lda;
+        pb[i] = bbase + (int64_t)(krow0 + i * NW * 4) * ldb;
+    }
+    const int64_t stepa = (int64_t)BK * lda, stepb = (int64_t)BK * ldb;
+    auto issue = [&](int st) {
+        char* sbase = smem + st * SS + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < IO; ++i) {
+            dma16(krow0 + i * NW * 4 < K ? (const void*)pa[i] : (const void*)zsrc, sbase + i * NW * 1024);
+            pa[i] += stepa;
+        }
+#pragma unroll
+        for (int i = 0; i < IO; ++i) {
+            dma16(krow0 + i * NW * 4 < K ? (const void*)pb[i] : (const void*)zsrc, sbase + OPB + i * NW * 1024);
+            pb[i] += stepb;
+        }
+        krow0 += BK;
+    };
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+
+    const int kq = (lane & 15) >> 2;
+    const int colb = ((wr * WTM + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const int colb_b = ((wc * WTN + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+    const unsigned rowoff = (unsigned)((8 * h + kq) * RBT);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned fa[TM], fb[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) fa[a] = rowoff + (unsigned)((colb + a * 64) ^ (64 * kq));
+#pragma unroll
+    for (int b = 0; b < TN; ++b) fb[b] = (unsigned)OPB + rowoff + (unsigned)((colb_b + b * 64) ^ (64 * kq));
+
+#pragma unroll
+    for (int u = 0; u < NST - 1; ++u)
+        if (u < nt) issue(u);
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        wait_tiles<L, NST - 2>(nt - 1 - t);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);
+        const unsigned sb = smem_base + (unsigned)(stage * SS);
+        TTFrag xa[2][TM], xb[2][TN];
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %8, %16 offset:4096\n\tds_read_b64_tr_b16 %9, %16 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %10, %17 offset:4096\n\tds_read_b64_tr_b16 %11, %17 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %12, %18 offset:4096\n\tds_read_b64_tr_b16 %13, %18 offset:5120\n\t"
+            "ds_read_b64_tr_b16 %14, %19 offset:4096\n\tds_read_b64_tr_b16 %15, %19 offset:5120\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(xa[0][0].lo), "=&v"(xa[0][0].hi), "=&v"(xa[0][1].lo), "=&v"(xa[0][1].hi), "=&v"(xb[0][0].lo),
+              "=&v"(xb[0][0].hi), "=&v"(xb[0][1].lo), "=&v"(xb[0][1].hi), "=&v"(xa[1][0].lo), "=&v"(xa[1][0].hi),
+              "=&v"(xa[1][1].lo), "=&v"(xa[1][1].hi), "=&v"(xb[1][0].lo), "=&v"(xb[1][0].hi), "=&v"(xb[1][1].lo),
+              "=&v"(xb[1][1].hi)
+            : "v"(sb + fa[0]), "v"(sb + fa[1]), "v"(sb + fb[0]), "v"(sb + fb[1])
+            : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    short8_t xf, wf;
+                    __builtin_memcpy(&xf, &xa[s2][a], 16);
+                    __builtin_memcpy(&wf, &xb[s2][b], 16);
+                    mma_t(acc[a][b], wf, xf);
+                }
+        stage = stage + 1 == NST ? 0 : stage + 1;
+    }
+
+    // split-K combine of this problem's tile (same protocol as g2_finish; slabs of 64 KiB = one 128 x 128 fp32 tile)
+    if (splits > 1) {
+        constexpr int QPT = TM * TN * 4;
+        const SlabIO io(g.ws + WS_COUNTERS);
+        const int64_t sstep = (int64_t)P.tiles * QPT * NTH * 16;
+        const int64_t base0 = ((int64_t)(P.slab0 + tile) * QPT * NTH + tid) * 16;
+        const int64_t mine = base0 + (int64_t)sp * sstep;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    io.store(mine + (int64_t)((a * TN + b) * 4 + q) * NTH * 16, v);
+                }
+        if (!splitk_ticket_is_last((unsigned*)g.ws + P.tile0 + tile, splits, (unsigned*)smem)) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        f32x4_t cur[TM][TN][4], nxt[TM][TN][4] = {};
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cur[a][b][q] = io.load(base0 + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
+        for (int s2 = 0; s2 < splits; ++s2) {
+            if (s2 + 1 < splits) {
+                const int64_t src = base0 + (int64_t)(s2 + 1) * sstep;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) nxt[a][b][q] = io.load(src + (int64_t)((a * TN + b) * 4 + q) * NTH * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[a][b][4 * q] += cur[a][b][q][0];
+                        acc[a][b][4 * q + 1] += cur[a][b][q][1];
+                        acc[a][b][4 * q + 2] += cur[a][b][q][2];
+                        acc[a][b][4 * q + 3] += cur[a][b][q][3];
+                        cur[a][b][q] = nxt[a][b][q];
+                    }
+        }
+    }
+
+    // epilogue: C += acc (fp32, 2 x 16-byte read-modify-write per 8 columns; layout as in g2_finish)
+    float* Cp = P.C;
+    const int64_t ldc = P.ldc;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int64_t m = m0 + wr * WTM + a * 32 + r;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                half_swap(v[j], v[4 + j]);
+                half_swap(v[8 + j], v[12 + j]);
+            }
+            const int64_t nb = n0 + wc * WTN + b * 32 + 8 * h;
+            if (m < M) {
+#pragma unroll
+                for (int e8 = 0; e8 < 2; ++e8) {
+                    const int64_t n = nb + 16 * e8;
+                    if (n < N) {
+                        float* pc = Cp + m * ldc + n;
+                        float4 c0 = *(const float4*)pc, c1 = *(const float4*)(pc + 4);
+                        const float* w = v + 8 * e8;
+                        c0.x += w[0]; c0.y += w[1]; c0.z += w[2]; c0.w += w[3];
+                        c1.x += w[4]; c1.y += w[5]; c1.z += w[6]; c1.w += w[7];
+                        *(float4*)pc = c0;
+                        *(float4*)(pc + 4) = c1;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
@@ -999,4 +1252,94 @@ int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
     a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
     return finish_launch(a, true, fp8, 1, p->ws, p->ws_bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grouped k-major products (include/comat_hip.h: comat_gemm_tt_grouped)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int comat_gemm_tt_grouped(const comat_tt_problem* probs, int32_t nprob, int32_t in_dtype, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    COMAT_REQUIRE(probs != nullptr && nprob >= 1, "comat_gemm_tt_grouped: no problems");
+    COMAT_REQUIRE(in_dtype == COMAT_BF16, "comat_gemm_tt_grouped: bf16 operands only (fp32 parity mode uses comat_gemm)");
+    for (int i = 0; i < nprob; ++i) {
+        const comat_tt_problem& q = probs[i];
+        COMAT_REQUIRE(q.A && q.B && q.C, "comat_gemm_tt_grouped: null operand in problem %d", i);
+        COMAT_REQUIRE(q.M >= 8 && q.N >= 8 && q.K >= 1 && q.M % 8 == 0 && q.N % 8 == 0 && q.M < (1 << 24) && q.N < (1 << 24) &&
+                          q.K < (1 << 30),
+                      "comat_gemm_tt_grouped: problem %d: M, N must be multiples of 8, K >= 1", i);
+        COMAT_REQUIRE(q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc % 4 == 0 && q.lda >= q.M && q.ldb >= q.N && q.ldc >= q.N &&
+                          q.lda < (1 << 29) && q.ldb < (1 << 29) && q.ldc < (1ll << 31),
+                      "comat_gemm_tt_grouped: problem %d: leading dimensions must keep rows 16-byte aligned", i);
+        COMAT_REQUIRE(al16(q.A) && al16(q.B) && al16(q.C), "comat_gemm_tt_grouped: problem %d: operands must be 16-byte aligned", i);
+    }
+    const int64_t slab_cap = ws ? (ws_bytes - COMAT_WS_COUNTER_BYTES) / (128 * 128 * 4) : 0;
+    int i0 = 0;
+    while (i0 < nprob) {
+        TTGroupArgs a = {};
+        int n = 0;
+        int64_t tiles_total = 0;
+        int nkt[TT_MAXP];
+        int64_t spl[TT_MAXP];
+        while (i0 + n < nprob && n < TT_MAXP) {
+            const comat_tt_problem& q = probs[i0 + n];
+            const int64_t t = cdiv64(q.M, 128) * cdiv64(q.N, 128);
+            if (n > 0 && tiles_total + t > WS_COUNTERS) break;
+            COMAT_REQUIRE(t <= WS_COUNTERS, "comat_gemm_tt_grouped: problem %d has too many output tiles", i0 + n);
+            TTProb& P = a.prob[n];
+            P.A = (const char*)q.A; P.B = (const char*)q.B; P.C = (float*)q.C;
+            P.M = (int)q.M; P.N = (int)q.N; P.K = (int)q.K;
+            P.lda = (int)(q.lda * 2); P.ldb = (int)(q.ldb * 2); P.ldc = (int)q.ldc;
+            P.tiles_n = (int)cdiv64(q.N, 128);
+            P.tiles = (int)t;
+            nkt[n] = (int)cdiv64(q.K, BK);
+            tiles_total += t;
+            ++n;
+        }
+        // split counts for the GROUP: slices of ~32 k-tiles (1 024 tokens); a group that would not fill the chip
+        // (256 CUs x 2 resident blocks, a few rounds) cuts finer, never below 4 k-tiles per slice
+        int64_t items = 0;
+        for (int p = 0; p < n; ++p) {
+            spl[p] = slab_cap > 0 ? cdiv64(nkt[p], 32) : 1;
+            if (spl[p] > 32) spl[p] = 32;
+            items += a.prob[p].tiles * spl[p];
+        }
+        if (slab_cap > 0 && items < 768) {
+            const int64_t f = cdiv64(768, items);
+            for (int p = 0; p < n; ++p) {
+                int64_t s = spl[p] * f, lim = nkt[p] / 4 > 1 ? nkt[p] / 4 : 1;
+                if (s > lim) s = lim;
+                if (s > 32) s = 32;
+                spl[p] = s > spl[p] ? s : spl[p];
+            }
+        }
+        for (;;) {  // the slabs of the group must fit the workspace
+            int64_t slabs = 0;
+            for (int p = 0; p < n; ++p) {
+                const int64_t per = cdiv64(nkt[p], spl[p]);
+                spl[p] = cdiv64(nkt[p], per);  // no empty slices
+                if (spl[p] > 1) slabs += a.prob[p].tiles * spl[p];
+            }
+            if (slabs <= slab_cap) break;
+            for (int p = 0; p < n; ++p) spl[p] = (spl[p] + 1) / 2;
+        }
+        int64_t blk = 0, tile0 = 0, slab0 = 0;
+        for (int p = 0; p < n; ++p) {
+            TTProb& P = a.prob[p];
+            P.splits = (int)spl[p];
+            P.tile0 = (int)tile0;
+            P.slab0 = (int)slab0;
+            a.blk0[p] = (int)blk;
+            blk += (int64_t)P.tiles * P.splits;
+            tile0 += P.tiles;
+            if (P.splits > 1) slab0 += (int64_t)P.tiles * P.splits;
+        }
+        COMAT_REQUIRE(blk < (1ll << 31), "comat_gemm_tt_grouped: too many work items");
+        a.blk0[n] = (int)blk;
+        a.nprob = n;
+        a.ws = (float*)ws;
+        hipLaunchKernelGGL((gemm2_tt_group_kernel<4>), dim3((unsigned)blk), dim3(256), 0, (hipStream_t)stream, a);
+        i0 += n;
+    }
+    comat_note_gemm_kernel(4);
+    return comat_check_launch("comat_gemm_tt_grouped");
 }

@@ -91,6 +91,7 @@ def join_side_streams():
     a stream that is not part of the capture would be an illegal cross-capture dependency."""
     global _join_queued
     _join_queued = False
+    flush_weight_grads()
     for dev, st in _side_dirty:
         torch.cuda.current_stream(dev).wait_stream(st)
     _side_dirty.clear()
@@ -109,10 +110,96 @@ def reset_side_stream_state():
     middle of a backward skips its end-of-backward callback; the latch would stay set and no later backward would ever
     join the side streams again) and drop the latch."""
     global _join_queued
-    if _side_dirty:
+    if _side_dirty or any(q.items for q in _ttq.values()):
         join_side_streams()
     _join_queued = False
     _side_keep.clear()
+
+
+# ---- deferred, grouped LoRA weight gradients -----------------------------------------------------------------------
+# dU = g^T h and dD = u^T x of every LoRA projection are k-major products over the token axis with a handful of output
+# tiles each (~720 per SD1.5 step).  Nothing reads them before the optimizer, so a backward pass QUEUES them here and
+# hands them to comat_gemm_tt_grouped in groups of <= TT_GROUP problems: one launch fills the chip where 48 small ones
+# each paid their own split-K combine (DESIGN.md section 4.4).  A group is flushed when it is full, when a new problem
+# accumulates into an output the group already holds (the same factor at another denoise step: the two must stay in
+# stream order), and at the end of the backward pass (join_side_streams).  Grouping is a pure function of the call
+# sequence, so results stay bit-reproducible run to run, eager or replayed from a graph.
+TT_GROUP = 48
+_ttq = {}  # (device, issuing stream) -> _TTQueue
+_tt_grouping = os.environ.get("COMAT_TT_GROUPED", "1") != "0"
+
+
+def set_tt_grouping(flag: bool):
+    """tests / A-B runs: False issues every weight gradient as its own comat_gemm launch (the round-2 path)"""
+    global _tt_grouping
+    flush_weight_grads()
+    _tt_grouping = bool(flag)
+
+
+class _TTQueue:
+    def __init__(self, dev, issuing, side):
+        self.dev, self.issuing, self.side = dev, issuing, side
+        self.items, self.outs, self.keep = [], set(), []
+
+    def add(self, prob, keep):
+        cptr = prob[2].data_ptr()
+        if len(self.items) >= TT_GROUP or cptr in self.outs:
+            self.flush()
+        self.items.append(prob)
+        self.outs.add(cptr)
+        self.keep.append(keep)
+
+    def flush(self):
+        if not self.items:
+            return
+        items, keep = self.items, self.keep
+        self.items, self.outs, self.keep = [], set(), []
+        if self.side is None:
+            with torch.cuda.stream(self.issuing):
+                kernels().gemm_tt_grouped(items)
+        else:
+            self.side.wait_stream(self.issuing)  # every operand queued so far has been produced on the issuing stream
+            with torch.cuda.stream(self.side):
+                kernels().gemm_tt_grouped(items)
+            if not any(st is self.side for _, st in _side_dirty):
+                _side_dirty.append((self.dev, self.side))
+            _side_keep.append(keep)  # operands stay alive until join_side_streams()
+
+
+class _HostQueue(_TTQueue):
+    """CPU tensors (tests with the ABI simulator): same grouping logic, no streams"""
+
+    def flush(self):
+        if self.items:
+            items = self.items
+            self.items, self.outs, self.keep = [], set(), []
+            kernels().gemm_tt_grouped(items)
+
+
+def _tt_enqueue(dev, problems, keep):
+    """queue weight-gradient problems [(A, B, C, M, N, K, lda, ldb, ldc)] of the backward pass running on the current
+    stream; `keep` = tensors that own the operands"""
+    if dev.type != "cuda":
+        q = _ttq.get((dev, 0))
+        if q is None:
+            q = _ttq[(dev, 0)] = _HostQueue(dev, None, None)
+    else:
+        cur = torch.cuda.current_stream(dev)
+        key = (dev, cur.cuda_stream)
+        q = _ttq.get(key)
+        if q is None:
+            q = _ttq[key] = _TTQueue(dev, cur, None)
+        if not q.items:
+            q.side = _side_stream(dev)  # decided per group: side streams may be suspended for a forked D step
+    for pr in problems:
+        q.add(pr, keep)
+    _queue_join()
+
+
+def flush_weight_grads():
+    """launch every queued weight-gradient group (idempotent)"""
+    for q in list(_ttq.values()):
+        q.flush()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -716,22 +803,34 @@ class _LoRAGroupLinear(Function):
         want_down = ctx.needs_input_grad[4]
         want_ups = ctx.needs_input_grad[5:]
 
-        def weight_grads():
-            if batched and all(want_ups):  # dU_i [N, r] += g_i^T h_i for all i
+        # LoRA weight gradients: dU_i [N, r] += g_i^T h_i,  d[D_1; ..; D_G] [G*r, K] += u^T x
+        probs = []
+        for i, lin in enumerate(lins):
+            if want_ups[i]:
+                probs.append((gs[i], h[:, i * r:(i + 1) * r], grp.ups[i].grad, lin.out_features, r, M,
+                              lin.out_features, Gr, r))
+        if want_down:
+            probs.append((u, x, grp.down_cat.grad, Gr, Kd, M, Gr, Kd, Kd))
+        if probs and _tt_grouping and all(k.tt_group_ok(*pr) for pr in probs):
+            _tt_enqueue(x.device, probs, (gs, h, u, x))
+            probs = []
+
+        def weight_grads():  # what the grouped kernel does not take (fp32 parity mode, odd shapes): one launch each
+            if batched and all(want_ups):
                 gu = grp.ups[0].grad
                 k.gemm(gs[0], h, gu, N0, r, M, N0, Gr, r, transA=True, transB=True, R=gu, ldr=r, beta=1.0,
                        batch=(G, 1), sA=(sg, 0), sB=(r, 0), sC=(sgu, 0), sR=(sgu, 0))
             else:
                 for i, lin in enumerate(lins):
-                    if want_ups[i]:  # dU_i [N, r] += g_i^T h_i
+                    if want_ups[i]:
                         N, gu = lin.out_features, grp.ups[i].grad
                         k.gemm(gs[i], h[:, i * r:(i + 1) * r], gu, N, r, M, N, Gr, r, transA=True, transB=True,
                                R=gu, ldr=r, beta=1.0)
-            if want_down:  # d[D_1; ..; D_G] [G*r, K] += u^T x
+            if want_down:
                 gd = grp.down_cat.grad
                 k.gemm(u, x, gd, Gr, Kd, M, Gr, Kd, Kd, transA=True, transB=True, R=gd, ldr=Kd, beta=1.0)
 
-        if want_down or any(want_ups):
+        if probs:
             side = _side_stream(x.device)
             if side is None:
                 weight_grads()

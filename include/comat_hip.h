@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 3
+#define COMAT_ABI_VERSION 4
 
 enum { COMAT_F32 = 0, COMAT_BF16 = 1,
        COMAT_FP8_E4M3 = 2 /* OCP e4m3fn bytes; operand dtype of comat_gemm / comat_conv2d only (comat_fp8_quantize) */ };
@@ -39,7 +39,7 @@ const char* comat_last_error(void);
 int comat_set_option(const char* name, int32_t value);
 /* Which kernel served the calling thread's last comat_gemm / comat_gemm_segments / comat_conv2d call: 0 the general
  * 64x64 kernel, 1 the LDS-DMA pipelined kernel, 2 its k-major (transA && transB) variant, 3 its fp8 (e4m3, 32x32x64
- * MFMA) variant; -1 before the first call.
+ * MFMA) variant, 4 the grouped k-major kernel (comat_gemm_tt_grouped); -1 before the first call.
  * bench.py and the tests use it to attribute time and to assert that a problem runs on the kernel the docs say. */
 int comat_last_gemm_kernel(void);
 
@@ -106,6 +106,26 @@ typedef struct {
     int64_t sA, sB;   /* element stride of A_s / B_s between batch items (p->batch1 items; 0 = shared operand) */
 } comat_gemm_segment;
 int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int32_t nseg, void* stream);
+
+/* Grouped k-major products:  C_p[M_p, N_p] += A_p^T B_p  for nprob INDEPENDENT problems, fp32 accumulation in place.
+ *   A_p is stored [K_p, M_p] (lda = element stride between k-rows), B_p is stored [K_p, N_p], both bf16; C_p is fp32
+ *   row-major with leading dimension ldc.  M_p, N_p multiples of 8 (>= 8); any K_p >= 1; lda, ldb multiples of 8, ldc of 4;
+ *   operands 16-byte aligned.  The C_p of one call must not overlap each other (the problems run concurrently); two calls
+ *   on one stream are ordered.  A violated requirement is COMAT_EINVAL before anything is launched.
+ * These are the LoRA weight gradients of a backward pass - dU = g^T h and dD = u^T x contract over the token axis of two
+ * row-major token matrices - which the reference leaves to autograd's addmm, one small launch per factor
+ * (training_utils/pipeline.py:84-115: LoRALinearLayer on to_q / to_k / to_v / to_out.0 of every Attention; ~720 factors
+ * gradients per SD1.5 step).  Nothing reads them before the optimizer, so the caller queues them and hands them over in
+ * groups: one launch per <= 48 problems fills the chip, and the split-K combines (in-launch, fixed slice order:
+ * bit-reproducible for a given grouping) overlap across problems.  `ws` as for comat_gemm (zeroed ticket counters at its
+ * head); without a workspace no problem is split. */
+typedef struct {
+    const void* A; const void* B; void* C;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+} comat_tt_problem;
+int comat_gemm_tt_grouped(const comat_tt_problem* probs, int32_t nprob, int32_t in_dtype, void* ws, int64_t ws_bytes,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * conv2d as implicit GEMM on channels-last tensors.

@@ -39,12 +39,12 @@ def oracle_cfgs(ucfg=config.TINY_UNET, vcfg=config.TINY_VAE):
     return O.UNetConfig(**dataclasses.asdict(ucfg)), O.VAEConfig(**dataclasses.asdict(vcfg))
 
 
-def tiny_weights(dtype):
+def tiny_weights(dtype, ucfg=config.TINY_UNET):
     """Tiny-config weights rounded to `dtype` (so oracle and kernels see identical values)."""
     q = lambda d: {k: v.to(dtype).float() for k, v in d.items()}
-    usd = q(weights.make_unet_weights(config.TINY_UNET, perturb_norms=True))
+    usd = q(weights.make_unet_weights(ucfg, perturb_norms=True))
     vsd = q(weights.make_vae_weights(config.TINY_VAE, perturb_norms=True))
-    lsd = q(weights.make_lora_weights(config.TINY_UNET))
+    lsd = q(weights.make_lora_weights(ucfg))
     # make LoRA up factors big enough that their gradients are well conditioned in the tiny model
     lsd = {k: (v * 5 if k.endswith("up.weight") else v).to(dtype).float() for k, v in lsd.items()}
     return usd, vsd, lsd

@@ -72,6 +72,20 @@ class SimKernels:
             acc = acc + beta * _v(R, (batch, M, N), (sR, ldr, 1)).float()
         _v(Cout, (batch, M, N), (sC, ldc, 1)).copy_(acc.to(Cout.dtype))
 
+    @staticmethod
+    def tt_group_ok(A, B, Cacc, M, N, K, lda, ldb, ldc):
+        return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and Cacc.dtype == torch.float32
+                and M >= 8 and N >= 8 and K >= 1 and M % 8 == 0 and N % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0
+                and ldc % 4 == 0)
+
+    def gemm_tt_grouped(self, problems):
+        ptrs = [p[2].data_ptr() for p in problems]
+        assert len(set(ptrs)) == len(ptrs), "comat_gemm_tt_grouped: the outputs of one call must not overlap"
+        for A, B, Cacc, M, N, K, lda, ldb, ldc in problems:
+            assert self.tt_group_ok(A, B, Cacc, M, N, K, lda, ldb, ldc)
+            Cv = _v(Cacc, (M, N), (ldc, 1))
+            Cv.add_(_v(A, (M, K), (1, lda)).float() @ _v(B, (K, N), (ldb, 1)).float())
+
     def transpose_cast_tiles(self, src, dst, tiles):
         sf, df = src.reshape(-1), dst.reshape(-1)
         for so, do, rows, cols, r0, c0 in tiles.tolist():

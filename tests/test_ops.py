@@ -320,6 +320,75 @@ def test_gemm_segments(dev, dtype, shape):
     check(out, ref, dtype, "gemm_segments batched")
 
 
+def test_gemm_tt_grouped(dev):
+    """comat_gemm_tt_grouped: C_p += A_p^T B_p for many independent k-major problems in a few launches (the LoRA weight
+    gradients, training_utils/pipeline.py:84-115) against fp32 matmuls of the same bf16 operands: ragged tiles, K that is
+    no multiple of the k-tile (zero-page rows), K < one k-tile, strided operands, more problems than one launch holds."""
+    dtype = torch.bfloat16
+    k = ops.kernels()
+    shapes = [(128, 320, 2048), (8, 8, 1), (136, 264, 77), (384, 64, 154), (64, 1280, 512), (320, 128, 4100), (16, 24, 31)]
+    shapes += [(8 * (1 + i % 5), 8 * (1 + i % 3), 33 + 17 * i) for i in range(60)]
+    probs, refs = [], []
+    for i, (M, N, K) in enumerate(shapes):
+        lda, ldb, ldc = M + (8 if i % 3 == 1 else 0), N + (16 if i % 4 == 2 else 0), N + (4 if i % 2 else 0)
+        A = rnd(K, lda, dtype=dtype, seed=100 + i, scale=0.5)
+        B = rnd(K, ldb, dtype=dtype, seed=300 + i, scale=0.5)
+        C0 = rnd(M, ldc, seed=500 + i)
+        Cd = dv(C0, dev)
+        probs.append((dv(A, dev, dtype), dv(B, dev, dtype), Cd, M, N, K, lda, ldb, ldc))
+        ref = C0.clone()
+        ref[:, :N] += A[:, :M].t() @ B[:, :N]
+        refs.append(ref)
+        assert k.tt_group_ok(*probs[-1])
+    k.gemm_tt_grouped(probs)
+    for i, (pr, ref) in enumerate(zip(probs, refs)):
+        check(pr[2], ref, torch.float32, f"tt_grouped problem {i} {shapes[i]}")  # padding columns untouched as well
+    k.gemm_tt_grouped(probs[:3])  # accumulates
+    for i in range(3):
+        M, N, K = shapes[i]
+        ref = refs[i].clone()
+        ref[:, :N] += probs[i][0].float().cpu()[:, :M].t() @ probs[i][1].float().cpu()[:, :N]
+        check(probs[i][2], ref, torch.float32, f"tt_grouped second call {i}")
+    if dev.type == "cuda":
+        from comat_amd import _hip
+        assert _hip.last_gemm_kernel() == 4
+        # bit-reproducible: the same call on the same inputs gives the same bits
+        outs = []
+        for _ in range(2):
+            Cs = [torch.zeros_like(pr[2]) for pr in probs]
+            k.gemm_tt_grouped([(pr[0], pr[1], c) + tuple(pr[3:]) for pr, c in zip(probs, Cs)])
+            outs.append(torch.cat([c.reshape(-1) for c in Cs]))
+        assert torch.equal(outs[0], outs[1])
+
+
+def test_weight_gradient_queue(dev):
+    """ops' deferred weight-gradient queue: problems are handed over in groups; a problem whose output is already in the
+    pending group starts a new group (the two launches stay in stream order), everything is launched by the join."""
+    dtype = torch.bfloat16
+    M, N, K = 16, 8, 40
+    A = [dv(rnd(K, M, dtype=dtype, seed=i), dev, dtype) for i in range(3)]
+    B = [dv(rnd(K, N, dtype=dtype, seed=10 + i), dev, dtype) for i in range(3)]
+    C1, C2 = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev)
+    ops.flush_weight_grads()
+    calls = []
+    real = ops.kernels().gemm_tt_grouped
+    ops.kernels().gemm_tt_grouped = lambda probs: (calls.append(len(probs)), real(probs))[1]
+    try:
+        # enqueue outside of a backward pass: bypass the autograd callback and join by hand
+        orig, ops._queue_join = ops._queue_join, lambda: None
+        ops._tt_enqueue(dev, [(A[0], B[0], C1, M, N, K, M, N, N), (A[1], B[1], C2, M, N, K, M, N, N)], (A, B))
+        ops._tt_enqueue(dev, [(A[2], B[2], C1, M, N, K, M, N, N)], (A, B))  # same output: flushes the first two
+        assert calls == [2]
+        ops.join_side_streams()
+        assert calls == [2, 1]
+    finally:
+        ops._queue_join = orig
+        ops.kernels().gemm_tt_grouped = real
+    f = lambda t: t.float().cpu()
+    check(C1, f(A[0]).t() @ f(B[0]) + f(A[2]).t() @ f(B[2]), torch.float32, "queue C1")
+    check(C2, f(A[1]).t() @ f(B[1]), torch.float32, "queue C2")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast_tiles(dev, dtype):
     src = rnd(5000, seed=1)
