@@ -59,7 +59,7 @@ def step_tflop(total_step, K, gan, sdxl=False, res=512):
 
 
 MFMA_CALLS = ("gemm", "gemm_segments", "conv2d", "flash_attn_fwd", "flash_attn_bwd", "gemm_tt_grouped")
-NOT_LAUNCHES = ("tt_group_ok", "gemm_workspace_bytes")  # helpers of the backend that enqueue nothing
+NOT_LAUNCHES = ("tt_group_ok", "gemm_workspace_bytes", "prepare_stream")  # helpers of the backend that enqueue nothing
 
 
 class CallRecorder:
@@ -437,6 +437,61 @@ def attn_map_probe():
                                "(two launches: per-head partial sums, then the head mean)"}}
 
 
+def secondary_c3(trainer, batch, rank, sync, steps=3):
+    """The reference's own recipe (scripts/sd15.sh:4-14 = BASELINE config C3: 50 denoise steps, 5 sampled ones with
+    gradient, concept matching + GAN + attribute concentration on 2 of them) timed in the same run on the SAME models:
+    45 no-grad UNet forwards replayed from per-timestep graphs + the step segments.  A few seconds; N = 1 only."""
+    import numpy as np
+    from comat_amd.segments import SegmentedStep
+    from comat_amd.step import CoMatTrainer, StepConfig
+    scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True)
+    tr = CoMatTrainer(trainer.pipe, trainer.bank, trainer.blip, trainer.D, scfg, seed=rank)
+    n_graphs = tr.pipe.prepare_graphs(1, 512, 512, 77, scfg.total_step)
+    dev = trainer.device
+    b = dict(batch)
+    b["noises"] = [torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(100 + i)).to(dev) for i in range(50)]
+    m = np.zeros((2, 512, 512), dtype=bool)
+    m[0, 60:250, 40:230] = True
+    m[1, 280:480, 260:500] = True
+    b["masks"], b["attributes"] = [m], [[[2, 3], [6, 7]]]
+    fixed = dict(crop=(1, 1, 510, 510))
+    st = SegmentedStep(tr)
+    for kw in precapture_plan(scfg, fixed):
+        st(b, **kw)
+    st(b, **fixed)
+    sync()
+    t0, host = time.time(), 0.0
+    for _ in range(steps):
+        h0 = time.perf_counter()
+        st(b, **fixed)
+        host += time.perf_counter() - h0
+    sync()
+    ms = (time.time() - t0) / steps * 1e3
+    total = step_tflop(50, 5, True)
+    return {"workload": "C3: SD1.5 512x512 bs=1, N=50 denoise steps (K=5 sampled with grad), concept-matching + GAN + attribute "
+                        "concentration (2 steps), clip+AdamW for G and D - scripts/sd15.sh of the reference",
+            "ms_per_step": round(ms, 1), "images_per_sec": round(1e3 / ms, 3), "steps": steps,
+            "host_enqueue_ms_per_step": round(host / steps * 1e3, 1),
+            "launch_mode": f"{n_graphs} no-grad UNet graphs + step segments ({st.stats()['segments']} segment graphs)",
+            "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS}
+
+
+def precapture_plan(scfg, fixed):
+    """Keyword sets for a few REAL optimisation steps that make a SegmentedStep visit every (slot, variant) once before
+    the timed region: with attribute concentration each trained-call slot has two variants (maps captured or not) and
+    the reference draws the capturing steps at random (training_script.py:589-590)."""
+    if not scfg.attrcon:
+        return []
+    from comat_amd.step import sample_training_steps
+    import random
+    ts = fixed.get("training_steps") or sample_training_steps(scfg.total_step, scfg.K, random.Random(0))
+    plans = [[ts[0], ts[1]], [ts[2], ts[3]]] if len(ts) >= 4 else [[t] for t in ts]
+    if len(ts) >= 5:
+        plans.append([ts[4]])
+    base = {k: v for k, v in fixed.items() if k != "training_steps"}
+    return [dict(base, training_steps=list(ts), attrcon_steps=p) for p in plans]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,66 +529,94 @@ def main():
 
     last_logs = {}
 
-    # The eager step is host-bound (~17 k launches at ~10 us of host time each): when the launch topology is static
-    # (C2: every denoise step is trained, no attribute-concentration masks) and this is a single-process run, the
-    # whole step is captured once into a hipGraph (comat_amd.step.GraphedStep) and the timed steps are replays with
-    # fresh inputs (with more than one rank the graph holds forward + backward; the RCCL all-reduces and the optimizer
-    # launches follow eagerly).  COMAT_STEP_GRAPH=0 times eager launches.  Capture happens here, before warm-up and timing.
+    # Launch modes (COMAT_STEP_MODE = auto | segments | graph | eager; COMAT_STEP_GRAPH=1/0 still selects graph / eager):
+    #   eager    - ~17 k launches per step at ~10 us of host time each: host-bound.
+    #   graph    - the WHOLE step captured once into a hipGraph (comat_amd.step.GraphedStep): needs a static launch topology
+    #              (C2: every denoise step trained, no attribute concentration) and, with more than one rank, ends before the
+    #              gradient exchange (exchange + optimizer follow eagerly).
+    #   segments - the trained UNet calls, the head and the discriminator step replayed from per-piece graphs behind the eager
+    #              sampler loop / loss assembly / exchange / optimizer (comat_amd.segments.SegmentedStep): ANY configuration,
+    #              ANY number of ranks, the same path on 1 and on 8 GPUs (no collective is ever captured).
+    #   auto     - segments everywhere; on one GPU with a static topology the whole-step graph is probed against it (3 steps
+    #              each) and the faster one is timed.  Every decision is agreed across ranks, so collectives stay matched.
     stepper, graph_note = None, "eager launches"
-    mode = os.environ.get("COMAT_STEP_GRAPH", "auto")  # auto | 1 (graph) | 0 (eager)
-    # more than one rank: the split graph (forward + backward captured, exchange + optimizer eager) is validated on one GPU
-    # only (COMAT_GRAPH_SPLIT=1); until it has run on a multi-GPU node it is opt-in there (COMAT_STEP_GRAPH=1)
-    if (not args.selftest and not scfg.attrcon and mode != "0" and "training_steps" in fixed
-            and (world == 1 or mode == "1")):
-        from comat_amd.step import GraphedStep
-        cand = GraphedStep(trainer)
+    mode = os.environ.get("COMAT_STEP_MODE") or {"1": "graph", "0": "eager"}.get(os.environ.get("COMAT_STEP_GRAPH", ""), "auto")
+    probe_ms = {}
 
-        def agree(value, op):
-            """the same decision on every rank (each step holds two all-reduces: ranks that took different branches
-            would leave the collectives of the timed region unmatched)"""
-            if world == 1:
-                return value
-            t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=op)
-            return float(t)
+    def agree(value, op):
+        """the same decision on every rank (each step holds two all-reduces: ranks that took different branches would
+        leave the collectives of the timed region unmatched)"""
+        if world == 1:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=op)
+        return float(t)
 
-        ok, err = 1, ""
+    def try_stepper(make, label):
+        """build a stepper and run its first (capturing) steps; on any failure fall back - loudly - to eager launches"""
+        ok, err, cand = 1, "", None
         try:
-            cand(batch, **fixed)  # one eager step (with its all-reduces), then the capture (no collective inside)
-        except Exception as e:  # noqa: BLE001 - stay measurable: fall back to eager launches, loudly
-            ok, err = 0, type(e).__name__
-            print(f"[bench] step-graph capture failed ({err}: {e}); timing eager launches", file=sys.stderr)
+            cand = make()
+        except Exception as e:  # noqa: BLE001 - stay measurable
+            ok, err = 0, f"{type(e).__name__}: {e}"
+            print(f"[bench] {label} failed ({err}); falling back", file=sys.stderr)
         ok = agree(ok, torch.distributed.ReduceOp.MIN) if world > 1 else ok
-        if ok:
-            cand(batch, **fixed)  # first replay
-            sync()
-            stepper, graph_note = cand, ("whole step replayed from one hipGraph" if not cand.split() else
-                                         "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")
-        else:
-            graph_note = f"eager launches (graph capture failed on some rank{': ' + err if err else ''})"
+        if not ok:
             trainer.blip.static_tables = None
+            trainer.pipe.trained_runner = trainer.head_runner = trainer.d_runner = None
             sync()
-        if stepper is not None and mode == "auto":
-            # eager launches pay ~10 us of host time per kernel, graph replay pays the capture-safe stream topology (no
-            # nested forks): take whichever is faster on this box (3 steps each; the slowest rank decides for all)
-            def probe(fn):
-                fn()
-                sync()
-                t0 = time.time()
-                for _ in range(3):
-                    fn()
-                sync()
-                return (time.time() - t0) / 3
-            trainer.serial_d, trainer.flat_d = False, False
-            t_eager = probe(lambda: trainer.train_step(batch, **fixed))
-            t_graph = probe(lambda: stepper(batch, **fixed))
-            if world > 1:
-                t_eager = agree(t_eager, torch.distributed.ReduceOp.MAX)
-                t_graph = agree(t_graph, torch.distributed.ReduceOp.MAX)
-            if t_eager < t_graph:
-                stepper, graph_note = None, f"eager launches (probe: eager {t_eager * 1e3:.0f} ms < graph {t_graph * 1e3:.0f} ms)"
-            else:
-                graph_note += f" (probe: graph {t_graph * 1e3:.0f} ms <= eager {t_eager * 1e3:.0f} ms)"
+        return (cand if ok else None), err
+
+    def probe(fn, n=3):
+        fn()
+        sync()
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        sync()
+        t = (time.time() - t0) / n
+        return agree(t, torch.distributed.ReduceOp.MAX) if world > 1 else t
+
+    static_topology = not scfg.attrcon and "training_steps" in fixed
+    seg_stepper = graph_stepper = None
+    if not args.selftest and mode in ("auto", "segments"):
+        from comat_amd.segments import SegmentedStep
+
+        def make_segments():
+            st = SegmentedStep(trainer)
+            for kw in precapture_plan(scfg, fixed):  # real optimisation steps that visit every (slot, variant) once
+                st(batch, **kw)
+            st(batch, **fixed)
+            sync()
+            return st
+        seg_stepper, err = try_stepper(make_segments, "segment capture")
+        if seg_stepper is not None:
+            stepper, graph_note = seg_stepper, "segments: trained UNet calls, head and D step replayed from hipGraphs"
+        else:
+            graph_note = f"eager launches (segment capture failed: {err})"
+    if not args.selftest and static_topology and (mode == "graph" or (mode == "auto" and world == 1)):
+        from comat_amd.step import GraphedStep
+
+        def make_graph():
+            st = GraphedStep(trainer)
+            st(batch, **fixed)  # one eager step (with its all-reduces), then the capture (no collective inside)
+            st(batch, **fixed)  # first replay
+            sync()
+            return st
+        graph_stepper, err = try_stepper(make_graph, "step-graph capture")
+        if graph_stepper is not None and mode == "graph":
+            stepper, graph_note = graph_stepper, ("whole step replayed from one hipGraph" if not graph_stepper.split() else
+                                                  "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")
+    if not args.selftest and mode == "auto" and seg_stepper is not None and graph_stepper is not None:
+        probe_ms["segments"] = probe(lambda: seg_stepper(batch, **fixed)) * 1e3
+        probe_ms["graph"] = probe(lambda: graph_stepper(batch, **fixed)) * 1e3
+        if probe_ms["graph"] < probe_ms["segments"]:
+            stepper, graph_note = graph_stepper, "whole step replayed from one hipGraph"
+        graph_note += f" (probe: segments {probe_ms['segments']:.0f} ms, whole-step graph {probe_ms['graph']:.0f} ms)"
+    eager_ms = None
+    if not args.selftest and world == 1 and static_topology and os.environ.get("COMAT_PROBE_EAGER", "1") != "0":
+        # the same step launched eagerly, for reference (what a run without any graph costs on this box)
+        eager_ms = probe(lambda: trainer.train_step(batch, **fixed)) * 1e3
 
     def run_step():
         if stepper is not None:
@@ -642,6 +725,13 @@ def main():
     attn_map = None
     if rank == 0 and not args.no_kernel_timing and not args.selftest:
         attn_map = attn_map_probe()
+    secondary = None
+    if (rank == 0 and world == 1 and args.config == "c2" and not args.selftest and not args.no_kernel_timing
+            and os.environ.get("COMAT_SECONDARY", "1") != "0"):
+        try:
+            secondary = {"c3": secondary_c3(trainer, batch, rank, sync)}
+        except Exception as e:  # noqa: BLE001 - the headline number must not depend on the secondary one
+            secondary = {"c3": {"error": f"{type(e).__name__}: {e}"}}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)
@@ -665,8 +755,10 @@ def main():
                                    ", clip+AdamW for G and D",
                        "parallelism": f"dp{world}", "build_s": round(t_build, 1),
                        "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 1), "launch_mode": graph_note,
+                       "probe_ms_per_step": {k: round(v, 1) for k, v in probe_ms.items()} or None,
+                       "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 1),
                        "per_rank_ms_per_step": per_rank_ms, "allreduce_ms_per_step": allreduce_ms},
-            "roofline": roofline, "cpu_baseline": cpu, "attn_map": attn_map,
+            "roofline": roofline, "cpu_baseline": cpu, "attn_map": attn_map, "secondary": secondary,
         }
         print(json.dumps(out))
 

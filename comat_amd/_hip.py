@@ -204,13 +204,33 @@ class HipKernels:
         load_library()
         self._ws = {}
 
+    @staticmethod
+    def _no_capture(what):
+        """Workspaces carry ticket counters that must be zero before their FIRST use and are re-armed by the kernels.  A
+        workspace created while its stream is capturing would be zeroed by a node of THAT graph only: a second graph
+        captured later on the same stream, replayed first, would run on uninitialised counters.  So creation during a
+        capture is an error: `prepare_stream()` creates them eagerly (ops.prepare_capture_stream does it for the package's
+        capture stream and its side stream)."""
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"{what} of a capturing stream must exist before the capture begins: call "
+                               "HipKernels.prepare_stream() on that stream first (comat_amd.ops.prepare_capture_stream)")
+
     def _workspace(self, dev):
         key = (dev, _stream())  # one slab workspace per stream: kernels on different streams may overlap
         ws = self._ws.get(key)
         if ws is None:
+            self._no_capture("the split-K workspace")
             ws = self._ws[key] = torch.empty(self.WS_BYTES // 4, dtype=torch.float32, device=dev)
             ws[: WS_COUNTER_BYTES // 4].zero_()  # the ABI asks for zeroed ticket counters before the first use
         return ws
+
+    def prepare_stream(self, dev, gn_groups=64):
+        """create (and zero) every per-stream workspace of the CURRENT stream now, outside any capture"""
+        self._no_capture("workspaces")
+        self._workspace(dev)
+        self._gn_workspace(dev, gn_groups, 1)
+        self._fp8_workspace(dev)
+        self._scratch(dev, 1 << 20)
 
     def gemm_workspace_bytes(self, M, N, K, batch=1, dtype=torch.bfloat16):
         return int(_lib.comat_gemm_workspace_bytes(M, N, K, batch, BF16 if dtype == torch.bfloat16 else F32))
@@ -323,10 +343,7 @@ class HipKernels:
         value = scale * fp8.  Two launches (abs-max -> scale, then the bytes)."""
         assert x.is_contiguous()
         n = x.numel()
-        key = ("fp8", x.device, _stream())
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = self._ws[key] = torch.zeros(2, dtype=torch.int32, device=x.device)  # ticket + running max, re-armed
+        ws = self._fp8_workspace(x.device)
         if scale is None:
             scale = torch.empty(1, dtype=torch.float32, device=x.device)
         if out is None:
@@ -334,6 +351,14 @@ class HipKernels:
         _check(_lib.comat_fp8_scale(_ptr(x), n, dt(x), _ptr(scale), _ptr(ws), _stream()), "comat_fp8_scale")
         _check(_lib.comat_fp8_quantize(_ptr(x), n, dt(x), _ptr(scale), _ptr(out), _stream()), "comat_fp8_quantize")
         return out, scale
+
+    def _fp8_workspace(self, dev):
+        key = ("fp8", dev, _stream())
+        ws = self._ws.get(key)
+        if ws is None:
+            self._no_capture("the fp8 scale workspace")
+            ws = self._ws[key] = torch.zeros(2, dtype=torch.int32, device=dev)  # ticket + running max, re-armed
+        return ws
 
     # ---- normalisation -------------------------------------------------------------------------------------
     def _gn_workspace(self, dev, B, G):
@@ -343,6 +368,7 @@ class HipKernels:
         key = ("gn", dev, _stream())
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            self._no_capture("the GroupNorm workspace")
             ws = self._ws[key] = torch.zeros(max(need, 1 << 18), dtype=torch.float64, device=dev)
         return ws
 
@@ -446,6 +472,9 @@ class HipKernels:
         key = ("scratch", dev, _stream())
         t = self._ws.get(key)
         if t is None or t.numel() < n:
+            # (no counters in here: a scratch buffer allocated during a capture is merely graph-private memory, but one
+            # that OUTLIVES the graph's pool bookkeeping - keep it out of captures as well)
+            self._no_capture("the reduction scratch buffer")
             t = self._ws[key] = torch.empty(max(n, 16384), dtype=torch.float32, device=dev)
         return t
 

@@ -106,17 +106,39 @@ class Blip:
         self.norm_shift = (-torch.tensor(CLIP_MEAN) / std).to(device)
         self._tables = {}
         self.static_tables = None
+        self._static_key = None
 
     # ---- image preprocessing -----------------------------------------------------------------------------------
-    def tables(self, H, W, crop):
-        if self.static_tables is not None:  # a captured step graph reads fixed-address tables (step.GraphedStep)
-            return self.static_tables
-        key = (H, W, crop)
+    def _crop_tables(self, H, W, crop):
+        key = (H, W, tuple(crop))
         if key not in self._tables:
             fwd, bwd = resize_tables(H, W, crop, (self.cfg.image_size, self.cfg.image_size), "bicubic")
             self._tables[key] = ops.ResampleTables(fwd, bwd, H, W, self.cfg.image_size, self.cfg.image_size,
                                                    self.device)
         return self._tables[key]
+
+    def tables(self, H, W, crop):
+        """the crop + resize operator of (H, W, crop).  Once fixed-address tables are installed (captured graphs of the
+        step read them: step.GraphedStep, segments.SegmentedStep) every caller gets THOSE, loaded with the operator it
+        asked for - so an eager call after a captured one can never preprocess with a stale crop.  Inside a capture the
+        tables are handed out as they are (the replaying code loads them before each replay)."""
+        st = self.static_tables
+        if st is None:
+            return self._crop_tables(H, W, crop)
+        if (H, W) != (st.Hin, st.Win):
+            raise ValueError(f"static resampling tables were installed for {st.Hin}x{st.Win} images, got {H}x{W}")
+        capturing = torch.device(self.device).type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if not capturing and self._static_key != (H, W, tuple(crop)):
+            st.load(self._crop_tables(H, W, crop))
+            self._static_key = (H, W, tuple(crop))
+        return st
+
+    def install_static_tables(self, H, W, crop):
+        """fixed-address tables (with spare taps for any other crop of the same size), loaded with `crop`'s operator"""
+        if self.static_tables is None:
+            self.static_tables = self._crop_tables(H, W, crop).static_copy()
+            self._static_key = (H, W, tuple(crop))
+        return self.tables(H, W, crop)
 
     def preprocess(self, img_tokens, B, H, W, crop=None):
         """crop (y0, x0, h, w) + Resize(bicubic, antialias) + Normalize in one kernel; -> [B*S*S, 3]."""

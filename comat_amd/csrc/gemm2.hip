@@ -1277,14 +1277,20 @@ extern "C" int comat_gemm_tt_grouped(const comat_tt_problem* probs, int32_t npro
     while (i0 < nprob) {
         TTGroupArgs a = {};
         int n = 0;
-        int64_t tiles_total = 0;
+        int64_t tiles_total = 0, slabs_total = 0;
         int nkt[TT_MAXP];
         int64_t spl[TT_MAXP];
         while (i0 + n < nprob && n < TT_MAXP) {
             const comat_tt_problem& q = probs[i0 + n];
             const int64_t t = cdiv64(q.M, 128) * cdiv64(q.N, 128);
-            if (n > 0 && tiles_total + t > WS_COUNTERS) break;
-            COMAT_REQUIRE(t <= WS_COUNTERS, "comat_gemm_tt_grouped: problem %d has too many output tiles", i0 + n);
+            int64_t sq = slab_cap > 0 ? cdiv64(cdiv64(q.K, BK), 32) : 1;
+            if (sq > 32) sq = 32;
+            const int64_t need = sq > 1 ? t * sq : 0;  // slabs of this problem (upper bound)
+            if (n > 0 && (tiles_total + t > WS_COUNTERS || slabs_total + need > slab_cap)) break;
+            COMAT_REQUIRE(t <= WS_COUNTERS && need <= slab_cap,
+                          "comat_gemm_tt_grouped: problem %d does not fit the workspace (%lld tiles, %lld slabs of 64 KiB)", i0 + n,
+                          (long long)t, (long long)need);
+            slabs_total += need;
             TTProb& P = a.prob[n];
             P.A = (const char*)q.A; P.B = (const char*)q.B; P.C = (float*)q.C;
             P.M = (int)q.M; P.N = (int)q.N; P.K = (int)q.K;
@@ -1295,32 +1301,14 @@ extern "C" int comat_gemm_tt_grouped(const comat_tt_problem* probs, int32_t npro
             tiles_total += t;
             ++n;
         }
-        // split counts for the GROUP: slices of ~32 k-tiles (1 024 tokens); a group that would not fill the chip
-        // (256 CUs x 2 resident blocks, a few rounds) cuts finer, never below 4 k-tiles per slice
-        int64_t items = 0;
+        // split count = a function of the PROBLEM alone (slices of ~32 k-tiles = 1 024 tokens, at most 32): the
+        // summation order of a weight gradient must not depend on which other problems happen to share its launch
+        // (eager steps, replayed segments and whole-step graphs group differently and still agree bit for bit)
         for (int p = 0; p < n; ++p) {
-            spl[p] = slab_cap > 0 ? cdiv64(nkt[p], 32) : 1;
-            if (spl[p] > 32) spl[p] = 32;
-            items += a.prob[p].tiles * spl[p];
-        }
-        if (slab_cap > 0 && items < 768) {
-            const int64_t f = cdiv64(768, items);
-            for (int p = 0; p < n; ++p) {
-                int64_t s = spl[p] * f, lim = nkt[p] / 4 > 1 ? nkt[p] / 4 : 1;
-                if (s > lim) s = lim;
-                if (s > 32) s = 32;
-                spl[p] = s > spl[p] ? s : spl[p];
-            }
-        }
-        for (;;) {  // the slabs of the group must fit the workspace
-            int64_t slabs = 0;
-            for (int p = 0; p < n; ++p) {
-                const int64_t per = cdiv64(nkt[p], spl[p]);
-                spl[p] = cdiv64(nkt[p], per);  // no empty slices
-                if (spl[p] > 1) slabs += a.prob[p].tiles * spl[p];
-            }
-            if (slabs <= slab_cap) break;
-            for (int p = 0; p < n; ++p) spl[p] = (spl[p] + 1) / 2;
+            int64_t sp = slab_cap > 0 ? cdiv64(nkt[p], 32) : 1;
+            if (sp > 32) sp = 32;
+            const int64_t per = cdiv64(nkt[p], sp);
+            spl[p] = cdiv64(nkt[p], per);  // no empty slices
         }
         int64_t blk = 0, tile0 = 0, slab0 = 0;
         for (int p = 0; p < n; ++p) {

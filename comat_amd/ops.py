@@ -66,6 +66,43 @@ def _side_stream(dev):
     return st
 
 
+# ---- the stream hipGraphs of this package are captured on ---------------------------------------------------------------
+_capture = {}
+
+
+def capture_stream(dev):
+    """ONE capture stream per device for every hipGraph the package records for replay on the main stream (step graph,
+    step segments, no-grad UNet forwards).  Kernels pick their workspaces by stream, so these graphs share one set of
+    workspaces - legal because they are only ever replayed on one stream, one after the other - and that set is created
+    and zeroed HERE, eagerly, together with the set of the stream's side stream: a workspace first touched inside a
+    capture would be zeroed by a node of that one graph only (see _hip.HipKernels._no_capture)."""
+    dev = torch.device(dev)
+    st = _capture.get(dev)
+    if st is None:
+        st = _capture[dev] = torch.cuda.Stream(device=dev)
+        prepare_capture_stream(dev, st)
+    return st
+
+
+def prepare_capture_stream(dev, st):
+    """create the per-stream workspaces of `st` and of the side stream forked from it, outside any capture"""
+    k = kernels()
+    if not hasattr(k, "prepare_stream"):
+        return
+    global _side_suspended
+    with torch.cuda.stream(st):
+        k.prepare_stream(dev)
+        saved, _side_suspended = _side_suspended, 0
+        try:
+            side = _side_stream(torch.device(dev))
+        finally:
+            _side_suspended = saved
+        if side is not None:
+            with torch.cuda.stream(side):
+                k.prepare_stream(dev)
+    torch.cuda.synchronize(dev)
+
+
 class no_side_streams:
     """Context: LoRA weight gradients of backward passes started inside it run on their issuing stream.  Used for the
     D step when it is itself forked onto its own stream inside a hipGraph capture: a fork from a forked stream (nested)

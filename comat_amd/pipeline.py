@@ -21,7 +21,7 @@ import torch
 from . import ops
 import os
 
-from .unet import GraphedUNetForward, UNet, VAEDecoder, regroup_maps
+from .unet import GraphedUNetForward, UNet, VAEDecoder, _capturing, regroup_maps
 
 
 class DDPMScheduler:
@@ -78,6 +78,12 @@ class TrainableSDPipeline:
         use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
                       and (not unet.cfg.addition_embed or os.environ.get("COMAT_SDXL_GRAPHS", "1") != "0"))
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
+        # hook of segments.SegmentedStep: runs a TRAINED UNet call (slot = its rank among the trained steps) from a pair
+        # of replayable graphs instead of eager launches; None = eager
+        self.trained_runner = None
+        # the text key / value projections are shared by the denoise steps of one sampler call (UNet.__call__); replayed
+        # segments recompute them per call, and so does the eager path when asked to match them bit for bit
+        self.share_text_kv = True
 
     def prepare_graphs(self, batch_size, height, width, L, num_inference_steps):
         """Capture the no-grad UNet forward graph of every timestep up front (before training starts), so that no
@@ -135,7 +141,10 @@ class TrainableSDPipeline:
         tmin = min(training_timesteps) if training_timesteps else 0
         places = sorted({s.split("_")[0] for s in train_layer_ls})
         self.attn_dict = {}
-        kv_cache = {}  # text key / value projections shared by the denoise steps of this call (see UNet.__call__)
+        # text key / value projections shared by the denoise steps of this call (see UNet.__call__)
+        kv_cache = {} if (self.share_text_kv and self.trained_runner is None) else None
+        wanted = {(s_.split("_")[0], int(s_.split("_")[1])) for s_ in train_layer_ls}
+        slot_of = {i: j for j, i in enumerate(sorted(set(training_timesteps)))}
         for i, t in enumerate(timesteps):
             train = i in training_timesteps
             with torch.set_grad_enabled(len(training_timesteps) == 0 or i > tmin):
@@ -150,6 +159,8 @@ class TrainableSDPipeline:
                 if (not train and self.graphed is not None and graph_ok
                         and not torch.cuda.is_current_stream_capturing()):
                     eps2, maps = self.graphed(xin, 2 * bs, h, w, int(t), ctx, L, added=added), {}
+                elif train and self.trained_runner is not None and not _capturing(dev):
+                    eps2, maps = self.trained_runner(slot_of[i], xin, 2 * bs, h, w, int(t), ctx, L, cap, added, wanted)
                 else:
                     eps2, maps = self.unet(xin, 2 * bs, h, w, int(t), ctx, L, capture_places=cap, added=added,
                                            kv_cache=kv_cache)
@@ -170,10 +181,9 @@ class TrainableSDPipeline:
                 lat = ops.cfg_ddpm_step(lat, eps2, z, guidance_scale, cx, ce, sigma)
         if output_type == "latent":  # TrainableSDPipeline.py:224-225: the final latents, no decode
             return ops.tokens_to_nchw(lat, bs, h, w)
-        z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), T)
-        img, H, W = self.vae(z0, bs, h, w)
-        if not (self.is_sdxl and return_latents):  # SDXL + return_latents returns the raw decode (:838-840)
-            img = ops.affine(img, 0.5, 0.5)
+        if output_type == "latent_tokens":  # the same as channels-last tokens [bs*h*w, 4] fp32 (decode_tokens follows)
+            return lat
+        img, H, W = self.decode_tokens(lat, bs, h, w, return_latents)
         if output_type == "tokens":
             out = (img, H, W)
         else:
@@ -181,6 +191,16 @@ class TrainableSDPipeline:
         if return_latents:
             return out, (lat if output_type == "tokens" else ops.tokens_to_nchw(lat, bs, h, w))
         return out
+
+
+    def decode_tokens(self, lat, bs, h, w, return_latents=False):
+        """`vae.decode(latents / scaling_factor)` (+ `/2 + 0.5`, TrainableSDPipeline.py:219-223) on channels-last latent
+        tokens -> (image tokens [bs*H*W, 3], H, W)"""
+        z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), self.dtype)
+        img, H, W = self.vae(z0, bs, h, w)
+        if not (self.is_sdxl and return_latents):  # SDXL + return_latents returns the raw decode (:838-840)
+            img = ops.affine(img, 0.5, 0.5)
+        return img, H, W
 
 
 class TrainableSDXLPipeline(TrainableSDPipeline):

@@ -1,0 +1,301 @@
+"""Step segments: the heavy, fixed-topology pieces of one CoMat optimisation step as replayable hipGraphs.
+
+A whole-step graph (step.GraphedStep) needs a static launch topology: it serves config C2 (every denoise step trained, no
+attribute concentration) on one GPU and nothing else.  The configurations the reference actually trains
+(`scripts/sd15.sh`, `scripts/sdxl.sh`: 50 denoise steps of which 5 sampled ones carry gradient,
+`training_script.py:563-566`; attribute concentration on 2 steps drawn from those, `:589-590`) change WHICH steps are
+trained and WHERE the attention maps are captured from one optimisation step to the next, and launched eagerly they are
+host-bound (~10 us of Python per launch x 17 k launches).  What does not change is the topology of the pieces:
+
+  U   one trained UNet call (`unet(latent_model_input, t, encoder_hidden_states=...)` with gradient,
+      TrainableSDPipeline.py:138-150; with or without captured cross-attention maps,
+      AttrConcenTrainableSDPipeline.py:239-279) - forward graph + backward graph per (slot, variant); the timestep
+      enters as a device tensor (its sinusoid), so ONE pair serves every timestep;
+  H   the head: VAE decode -> crop + BLIP caption reward -> generator-side discriminator loss
+      (TrainableSDPipeline.py:219-223, training_script.py:606-623) - forward + backward graph;
+  D   the discriminator step (forward + backward on [fake.detach(); real], training_script.py:683-690) - one graph,
+      captured on and replayed on the discriminator's own stream (it overlaps the generator's backward);
+  the N-K no-grad UNet forwards keep their per-timestep graphs (unet.GraphedUNetForward).
+
+Each U / H piece is a `GraphedSegment`: a `torch.autograd.Function` whose forward copies its inputs into fixed-address
+buffers and replays the forward graph, and whose backward copies the incoming gradients and replays the backward graph
+(LoRA weight gradients accumulate into the flat gradient buffer as a side effect of that replay, exactly as they do in
+the eager backward).  The sampler loop, the loss assembly, the gradient exchange and the optimizer stay the eager code of
+step.CoMatTrainer / pipeline.TrainableSDPipeline - a few hundred launches instead of 17 k - so ONE code path serves
+every configuration and any number of ranks: no collective is ever captured, and a data-parallel run replays exactly
+what a single GPU replays.
+
+First use of a segment runs it eagerly (a real part of that step: it also fills every host-side memo) and captures it
+right afterwards; from the second use on it is replayed.  Replays are bit-identical to the eager launches
+(tests/test_segments.py).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def _copy_into(dst, src):
+    """dst <- src (fixed-address buffer); float tensors through the library's copy kernel, the rest through torch"""
+    if dst.data_ptr() == src.data_ptr():
+        return
+    with torch.no_grad():
+        if dst.dtype in (torch.float32, torch.bfloat16) and src.dtype in (torch.float32, torch.bfloat16) \
+                and src.is_contiguous() and src.device == dst.device:
+            ops.kernels().unary(ops.UN_COPY, src, dst, dst.numel())
+        else:
+            dst.copy_(src, non_blocking=True)
+
+
+def _capture_kwargs():
+    # more than one rank: RCCL's watchdog thread polls events while we capture - only THIS thread's calls may invalidate
+    # the capture ("thread_local"; the default "global" mode would abort it)
+    import torch.distributed as dist
+    return {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
+
+
+class GraphedSegment:
+    """fn(*tensors) -> tuple of tensors, captured as a forward hipGraph and (if any output requires grad) a backward
+    hipGraph.  `stream`: the stream the graphs are captured on (it selects the kernels' workspaces: graphs that may be
+    replayed CONCURRENTLY must be captured on different streams) - default: the package's capture stream.
+    `pool`: memory pool shared with other segments that are never live at the same time (the two variants of one slot)."""
+
+    def __init__(self, fn, name, stream=None, pool=None):
+        self.fn, self.name, self.stream, self.pool = fn, name, stream, pool
+        self.fg = self.bg = None
+        self.replays = 0
+
+    @property
+    def captured(self):
+        return self.fg is not None
+
+    def capture(self, inputs):
+        dev = inputs[0].device
+        st = self.stream or ops.capture_stream(dev)
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        # fixed-address inputs live OUTSIDE the graph pool (they survive pool reuse by a sibling segment)
+        self.si = [torch.empty_like(x).requires_grad_(x.requires_grad) for x in inputs]
+        for s, x in zip(self.si, inputs):
+            _copy_into(s, x.detach())
+        kw = _capture_kwargs()
+        self.fg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fg, pool=self.pool, stream=st, **kw):
+            outs = self.fn(*self.si)
+        outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
+        self.out_req = [bool(o.requires_grad) for o in outs]
+        self.sgo = [torch.zeros_like(o) if r else None for o, r in zip(outs, self.out_req)]
+        self.sgi = [None] * len(self.si)
+        if any(self.out_req):
+            self.bg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bg, pool=self.pool, stream=st, **kw):
+                torch.autograd.backward([o for o, r in zip(outs, self.out_req) if r],
+                                        [g for g in self.sgo if g is not None])
+            self.sgi = [x.grad for x in self.si]
+            for x in self.si:
+                x.grad = None
+        # keep the outputs' storage, drop the recorded autograd graph: the saved activations stay where the graphs
+        # expect them, but the pool may hand their addresses to a sibling capture (never live at the same time)
+        self.outs = [o.detach() for o in outs]
+        del outs
+
+    def __call__(self, *inputs):
+        return _Replay.apply(self, *inputs)
+
+
+class _Replay(Function):
+    @staticmethod
+    def forward(ctx, seg, *inputs):
+        for s, x in zip(seg.si, inputs):
+            _copy_into(s, x)
+        seg.fg.replay()
+        seg.replays += 1
+        ctx.seg = seg
+        outs = tuple(o.detach() for o in seg.outs)
+        ctx.mark_non_differentiable(*[o for o, r in zip(outs, seg.out_req) if not r])
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gos):
+        seg = ctx.seg
+        for sg, g in zip(seg.sgo, gos):
+            if sg is None:
+                continue
+            if g is None:
+                sg.zero_()
+            else:
+                _copy_into(sg, g if g.is_contiguous() else g.contiguous())
+        seg.bg.replay()
+        return (None,) + tuple(None if gi is None else gi.detach() for gi in seg.sgi)
+
+
+class SegmentedStep:
+    """`trainer.train_step` with the UNet calls, the head and the discriminator step replayed from segment graphs.
+
+        stepper = SegmentedStep(trainer);  logs = stepper(batch, training_steps=..., crop=..., attrcon_steps=...)
+
+    Same call convention and same results (bit for bit) as CoMatTrainer.train_step; any configuration, any number of
+    ranks.  Without a GPU it simply runs the eager step."""
+
+    FLOAT_KEYS = ("prompt_embeds", "negative_prompt_embeds", "gan_null_embeds", "latents", "real_latents",
+                  "pooled_prompt_embeds", "negative_pooled_prompt_embeds")
+    INT_KEYS = ("blip_input_ids", "blip_attention_mask")
+
+    def __init__(self, trainer, use_head=True, use_d=True, dry=False):
+        """dry: run every segment's function eagerly through the same hooks, never capture (checks the host logic of the
+        hooks where there is no GPU: tests/test_segments.py)"""
+        self.tr = trainer
+        self.dry = dry
+        self.unet_segs, self.slot_pools = {}, {}
+        self.head_seg = self.d_seg = None
+        self.use_head, self.use_d = use_head, use_d
+        self.static = {}
+        self.enabled = trainer.device.type == "cuda"
+
+    # ---- batch staging: every tensor of the batch at a fixed device address ------------------------------------------
+    def _stage(self, batch):
+        dev = self.tr.device
+        out = dict(batch)
+        for k in self.FLOAT_KEYS + self.INT_KEYS:
+            if k not in batch:
+                continue
+            src = batch[k]
+            dst = self.static.get(k)
+            if dst is None or dst.shape != src.shape or dst.dtype != src.dtype:
+                dst = self.static[k] = torch.empty_like(src, device=dev)
+            dst.copy_(src, non_blocking=True)
+            out[k] = dst
+        if batch.get("noises") is not None:
+            ns = self.static.get("noises")
+            if ns is None or len(ns) != len(batch["noises"]) or ns[0].shape != batch["noises"][0].shape:
+                ns = self.static["noises"] = [torch.empty_like(n, device=dev) for n in batch["noises"]]
+            for d, s in zip(ns, batch["noises"]):
+                d.copy_(s, non_blocking=True)
+            out["noises"] = ns
+        return out
+
+    # ---- U: trained UNet call -----------------------------------------------------------------------------------------
+    def _run_unet(self, slot, xin, B, H, W, t, ctx, L, cap, added, wanted=None):
+        """the pipeline's trained-call hook (pipeline.TrainableSDPipeline.trained_runner).  `wanted`: the (place,
+        resolution) pairs the attribute-concentration loss will read (train_layer_ls): only those maps leave the
+        segment - an unused map output would cost a zero-filled gradient buffer in every backward replay."""
+        unet = self.tr.pipe.unet
+        cap = tuple(cap)
+        wkey = None if wanted is None else tuple(sorted(wanted))
+        key = (slot, cap, wkey, B, H, W, L, bool(xin.requires_grad))
+        te = unet.time_sinusoid(t, B)
+
+        def fn(x, te_, ctx_, *rest):
+            eps, maps = unet(x, B, H, W, te_, ctx_, L, capture_places=cap, added=rest[0] if rest else None)
+            keep = {place: [p for p in maps[place]
+                            if wanted is None or (place, int(round(p.shape[2] ** 0.5))) in wanted] for place in cap}
+            self._map_counts[key] = [len(keep[place]) for place in cap]
+            return (eps,) + tuple(p for place in cap for p in keep[place])
+
+        self._map_counts = getattr(self, "_map_counts", {})
+        inputs = (xin, te, ctx) + ((added,) if added is not None else ())
+        seg = None if self.dry else self.unet_segs.get(key)
+        if self.dry:
+            outs = fn(*inputs)
+        elif seg is None:
+            pool = self.slot_pools.get(slot)
+            if pool is None:
+                pool = self.slot_pools[slot] = torch.cuda.graph_pool_handle()
+            seg = self.unet_segs[key] = GraphedSegment(fn, f"unet slot {slot} capture={cap}", pool=pool)
+            outs = fn(*inputs)          # eager: this call's real work (and the memo / workspace warm-up of the capture)
+            seg.capture(inputs)
+        else:
+            outs = seg(*inputs)
+        eps, flat = outs[0], list(outs[1:])
+        maps, i = {}, 0
+        for place, n in zip(cap, self._map_counts[key]):
+            maps[place] = flat[i:i + n]
+            i += n
+        return eps, maps
+
+    # ---- H: VAE decode + BLIP reward + generator-side discriminator loss ------------------------------------------------
+    def _run_head(self, lat, batch, crop, bs, h, w):
+        tr = self.tr
+        cfg = tr.cfg
+        res = cfg.resolution
+        tr.blip.tables(res, res, crop)  # loads this crop's operator into the fixed-address tables the graph reads
+
+        def fn(lat_, ids, mask, *null):
+            b = dict(batch, blip_input_ids=ids, blip_attention_mask=mask)
+            if null:
+                b["gan_null_embeds"] = null[0]
+            o = tr.head_losses(lat_, b, crop, bs, h, w)
+            return (o["reward"], o["logp"]) + ((o["G_loss"],) if cfg.gan_loss else ()) + (o["image"][0],)
+
+        inputs = (lat, batch["blip_input_ids"], batch["blip_attention_mask"]) + \
+            ((batch["gan_null_embeds"],) if cfg.gan_loss else ())
+        if self.dry:
+            outs = fn(*inputs)
+            self._img_hw = tr._last_image_hw
+        elif self.head_seg is None:
+            tr.blip.install_static_tables(res, res, crop)
+            self.head_seg = GraphedSegment(fn, "head")
+            outs = fn(*inputs)
+            self._img_hw = tr._last_image_hw
+            self.head_seg.capture(inputs)
+        else:
+            outs = self.head_seg(*inputs)
+        o = dict(reward=outs[0], logp=outs[1], image=(outs[-1],) + tuple(self._img_hw))
+        if cfg.gan_loss:
+            o["G_loss"] = outs[2]
+        return o
+
+    # ---- D: discriminator step ---------------------------------------------------------------------------------------------
+    def _run_d(self, out, batch):
+        tr = self.tr
+
+        def fn(lat_, real, null):
+            return tr._d_step_eager(dict(training_latents=lat_), dict(batch, real_latents=real, gan_null_embeds=null))
+
+        dev = tr.device
+        real = batch["real_latents"]
+        inputs = (out["training_latents"].detach(), real, batch["gan_null_embeds"])
+        if self.dry:
+            return fn(*inputs)
+        if self.d_seg is None:
+            st = torch.cuda.current_stream(dev)  # the discriminator's stream (step.CoMatTrainer forks it) or the main one
+            if st.cuda_stream != torch.cuda.default_stream(dev).cuda_stream:
+                ops.prepare_capture_stream(dev, st)
+                self.d_seg = GraphedSegment(fn, "discriminator step", stream=st)
+            else:
+                self.d_seg = GraphedSegment(fn, "discriminator step")
+            loss = fn(*inputs)
+            self.d_seg.capture(inputs)
+            return loss
+        return self.d_seg(*inputs)[0]
+
+    # ---- the step --------------------------------------------------------------------------------------------------------------
+    def __call__(self, batch, training_steps=None, crop=None, attrcon_steps=None):
+        tr = self.tr
+        fixed = {k: v for k, v in (("training_steps", training_steps), ("crop", crop), ("attrcon_steps", attrcon_steps))
+                 if v is not None}
+        if not self.enabled and not self.dry:
+            return tr.train_step(batch, **fixed)
+        sb = self._stage(batch)
+        # the derived LoRA copies are refreshed HERE, eagerly: inside a capture the refresh would be baked into that one
+        # graph (and marked done without having run)
+        tr.bank.ensure_compute_copy()
+        if tr.D is not None:
+            tr.D.bank.ensure_compute_copy()
+        tr.pipe.trained_runner = self._run_unet
+        tr.head_runner = self._run_head if self.use_head else None
+        tr.d_runner = self._run_d if (self.use_d and tr.D is not None) else None
+        try:
+            return tr.train_step(sb, **fixed)
+        finally:
+            tr.pipe.trained_runner = None
+            tr.head_runner = tr.d_runner = None
+
+    def stats(self):
+        segs = list(self.unet_segs.values()) + [s for s in (self.head_seg, self.d_seg) if s is not None]
+        return {"segments": len(segs), "replays": sum(s.replays for s in segs)}

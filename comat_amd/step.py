@@ -132,6 +132,27 @@ class CoMatTrainer:
         self._d_keep = None
         self.serial_d = False  # GraphedStep: D step in stream order on the main stream
         self.flat_d = False    # GraphedStep: forked D stream, but no second-level fork for its weight gradients
+        # hooks of segments.SegmentedStep: replay the head (VAE + BLIP + generator-side D loss) / the D step from graphs
+        self.head_runner = None
+        self.d_runner = None
+        self._last_image_hw = None
+
+    def head_losses(self, lat, batch, crop, bs, h, w):
+        """final latents (channels-last tokens, fp32) -> VAE decode -> crop + BLIP caption reward [-> generator-side
+        discriminator loss]: TrainableSDPipeline.py:219-223, training_script.py:606-623."""
+        cfg = self.cfg
+        img, H, W = self.pipe.decode_tokens(lat, bs, h, w, return_latents=True)
+        _dbg("vae")
+        self._last_image_hw = (H, W)
+        reward, logp = self.blip.score(img, bs, H, W, batch["blip_input_ids"], batch["blip_attention_mask"], crop=crop,
+                                       label_smoothing=cfg.label_smoothing)
+        _dbg("blip")
+        o = dict(reward=reward, logp=logp, image=(img, H, W))
+        if cfg.gan_loss:
+            o["G_loss"] = self.D.D_sd_pipeline_forward(lat, "G", negative_prompt_embeds=batch["gan_null_embeds"],
+                                                       num_inference_steps=cfg.total_step, h=h, w=w)
+            _dbg("G loss")
+        return o
 
     def compute_losses(self, batch, training_steps=None, crop=None, attrcon_steps=None):
         """Forward graph of the step up to the scalar loss.  batch keys: prompt_embeds, negative_prompt_embeds
@@ -151,26 +172,25 @@ class CoMatTrainer:
             kw.update(pooled_prompt_embeds=batch["pooled_prompt_embeds"],
                       negative_pooled_prompt_embeds=batch["negative_pooled_prompt_embeds"],
                       add_time_ids=batch.get("add_time_ids"))
-        (img, H, W), lat = self.pipe.forward(
+        lat = self.pipe.forward(
             batch["prompt_embeds"], batch["negative_prompt_embeds"], height=res, width=res,
             training_timesteps=training_steps, num_inference_steps=cfg.total_step, guidance_scale=cfg.cfg_scale,
-            latents=batch.get("latents"), noises=batch.get("noises"), return_latents=True, output_type="tokens", **kw)
-        _dbg("sampler + vae")
+            latents=batch.get("latents"), noises=batch.get("noises"), return_latents=True, output_type="latent_tokens",
+            **kw)
+        _dbg("sampler")
         bs = batch["prompt_embeds"].shape[0]
         if crop is None:
             crop = sample_crop(res, self.rng)
-        reward, logp = self.blip.score(img, bs, H, W, batch["blip_input_ids"], batch["blip_attention_mask"], crop=crop,
-                                       label_smoothing=cfg.label_smoothing)
-        _dbg("blip")
-        out = dict(Blip=reward.detach(), token_logp=logp, training_steps=training_steps, crop=crop)
-        loss = -reward
         h, w = res // 8, res // 8
+        head = self.head_runner(lat, batch, crop, bs, h, w) if self.head_runner is not None else \
+            self.head_losses(lat, batch, crop, bs, h, w)
+        reward = head["reward"]
+        out = dict(Blip=reward.detach(), token_logp=head["logp"], training_steps=training_steps, crop=crop)
+        loss = -reward
         if cfg.gan_loss:
-            G_loss = self.D.D_sd_pipeline_forward(lat, "G", negative_prompt_embeds=batch["gan_null_embeds"],
-                                                  num_inference_steps=cfg.total_step, h=h, w=w)
-            loss = loss + cfg.gan_loss_weight * G_loss
-            out["G_loss"] = G_loss.detach()
-            _dbg("G loss")
+            loss = loss + cfg.gan_loss_weight * head["G_loss"]
+            out["G_loss"] = head["G_loss"].detach()
+        img, H, W = head["image"]
         if cfg.attrcon:
             tl, pl = mask_loss(self.pipe.attn_dict, batch["masks"], batch["attributes"], cfg.train_layer_ls, bs,
                                self.device)
@@ -184,6 +204,11 @@ class CoMatTrainer:
         return out
 
     def _d_step(self, out, batch):
+        if self.d_runner is not None:
+            return self.d_runner(out, batch)
+        return self._d_step_eager(out, batch)
+
+    def _d_step_eager(self, out, batch):
         """D forward + backward on [fake.detach(); real] (training_script.py:683-690)."""
         cfg = self.cfg
         h = w = cfg.resolution // 8
@@ -338,6 +363,9 @@ class GraphedStep:
             dst.copy_(src, non_blocking=True)
         for k in batch:  # host-side metadata (masks, token lists, time ids) passes through untouched
             if k not in self.BATCH_KEYS and k != "noises":
+                if torch.is_tensor(batch[k]):
+                    raise KeyError(f"batch tensor '{k}' has no fixed-address staging buffer (GraphedStep.BATCH_KEYS): a "
+                                   "captured graph would keep reading the address it saw at capture time")
                 self.static[k] = batch[k]
         return self.static
 
@@ -353,54 +381,57 @@ class GraphedStep:
             crop = sample_crop(cfg.resolution, tr.rng)
         sb = self._stage(batch)
         res = cfg.resolution
-        real_tab = tr.blip.tables(res, res, crop) if tr.blip.static_tables is None else None
-        if real_tab is None:  # static tables are installed: look the crop's operator up in the cache behind them
-            st = tr.blip.static_tables
-            tr.blip.static_tables = None
-            real_tab = tr.blip.tables(res, res, crop)
-            tr.blip.static_tables = st
         split = self.split()
-        key = (tuple(training_steps), split)
+        # host-side values the capture bakes in are part of the key (SDXL: add_time_ids feed the added time embedding)
+        meta = tuple(batch["add_time_ids"]) if batch.get("add_time_ids") is not None else None
+        key = (tuple(training_steps), split, meta, os.environ.get("COMAT_GRAPH_D", "fork"))
         ent = self.graphs.get(key)
         # D step inside the capture: forked onto its own stream (it overlaps the G backward chain: 187 -> 168 ms per C2 step
         # on MI355X) with its weight gradients kept on that stream - a fork from a forked stream (nested) crashes
         # hipStreamEndCapture on ROCm 7.2.  COMAT_GRAPH_D=serial runs it in stream order on the main stream instead.
+        saved = (tr.serial_d, tr.flat_d)
         if os.environ.get("COMAT_GRAPH_D", "fork") == "serial":
             tr.serial_d, tr.flat_d = True, False
         else:
             tr.serial_d, tr.flat_d = False, True
-        if ent is None:
-            # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
-            # tables, workspaces of the default stream) and is a real optimisation step of its own
-            if tr.blip.static_tables is not None:
-                tr.blip.static_tables.load(real_tab)  # the installed fixed-address tables serve the eager step too
-            logs = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
-            if tr.blip.static_tables is None:
-                tr.blip.static_tables = real_tab.static_copy()
-            tr.bank.mark_updated()
-            if tr.D is not None:
-                tr.D.bank.mark_updated()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            # more than one rank: RCCL's watchdog thread polls events while we capture - only THIS thread's calls may
-            # invalidate the capture ("thread_local"; the default "global" mode would abort it)
-            mode = {"capture_error_mode": "thread_local"} if split else {}
-            with torch.cuda.graph(g, pool=self.pool, **mode):
-                if split:
-                    out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
-                else:
-                    out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
-            if self.pool is None:
-                self.pool = g.pool()
-            self.graphs[key] = (g, out)
-            # the capture did not execute anything: the eager step above is this call's step
-            return logs
-        g, out = ent
-        tr.blip.static_tables.load(real_tab)
-        g.replay()
-        out = dict(out)
-        if split:
-            tr._apply_updates()
-            out["grad_norm_sq"] = tr.opt.gnorm_sq
-        out["training_steps"], out["crop"] = list(training_steps), crop
-        return out
+        try:
+            if ent is None:
+                # one eager step with these inputs first: fills every host-side memo (time embeddings, targets, crop
+                # tables, workspaces of the default stream) and is a real optimisation step of its own.  The fixed-address
+                # crop tables serve the eager step too.
+                tr.blip.install_static_tables(res, res, crop)
+                logs = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+                tr.bank.mark_updated()
+                if tr.D is not None:
+                    tr.D.bank.mark_updated()
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                # more than one rank: RCCL's watchdog thread polls events while we capture - only THIS thread's calls may
+                # invalidate the capture ("thread_local"; the default "global" mode would abort it)
+                mode = {"capture_error_mode": "thread_local"} if split else {}
+                # captured on the package's capture stream, whose workspaces (and its side stream's) exist and are zeroed
+                # already: nothing a later graph on the same stream relies on is initialised by a node of this one
+                cap = ops.capture_stream(tr.device)
+                if tr._d_stream is not None:
+                    ops.prepare_capture_stream(tr.device, tr._d_stream)
+                with torch.cuda.graph(g, pool=self.pool, stream=cap, **mode):
+                    if split:
+                        out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
+                    else:
+                        out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+                if self.pool is None:
+                    self.pool = g.pool()
+                self.graphs[key] = (g, out)
+                # the capture did not execute anything: the eager step above is this call's step
+                return logs
+            g, out = ent
+            tr.blip.tables(res, res, crop)  # loads this crop's operator into the fixed-address tables
+            g.replay()
+            out = dict(out)
+            if split:
+                tr._apply_updates()
+                out["grad_norm_sq"] = tr.opt.gnorm_sq
+            out["training_steps"], out["crop"] = list(training_steps), crop
+            return out
+        finally:
+            tr.serial_d, tr.flat_d = saved

@@ -249,11 +249,28 @@ class UNet:
             add = ops.concat_cols(ops.cast(text_embeds.to(self.device), self.dtype), ops.cast(tid, self.dtype))
             return ops.linear(ops.linear(add, self.a1, act=ops.ACT_SILU), self.a2)
 
+    def time_sinusoid(self, t, B):
+        """[B, C0] fp32 sinusoid of timestep t on the device (memoised: at most one host->device copy per timestep)"""
+        key = ("sin", int(t), B)
+        te = self._te_cache.get(key)
+        if te is None:
+            te = self._te_cache[key] = timestep_embedding(t, self.cfg.block_out_channels[0], B).to(self.device)
+        return te
+
     def _time_embedding(self, t, B, added):
         """{"silu_temb": SiLU(emb)} plus, lazily, each ResBlock's projection of it.  SD1.5: depends on (t, batch)
         and frozen weights only -> memoised.  SDXL: emb = temb(t) + added_embedding(prompt): the timestep half is
         memoised, the sum and the ResBlock projections are recomputed per call (they depend on the prompt)."""
         cfg = self.cfg
+        if torch.is_tensor(t):
+            # the sinusoid itself as a device tensor (time_sinusoid): nothing is memoised and nothing comes from the
+            # host, so ONE captured graph serves every timestep (comat_amd/segments.py).  Same arithmetic as below.
+            with torch.no_grad():
+                te = ops.linear(ops.cast(t, self.dtype), self.t1, act=ops.ACT_SILU)
+                if not cfg.addition_embed:
+                    return {"silu_temb": ops.linear(te, self.t2, act=ops.ACT_SILU)}
+                aug = added if torch.is_tensor(added) else self.added_embedding(*added)
+                return {"silu_temb": ops.silu(ops.linear(te, self.t2, residual=aug))}
         key = (int(t), B)
         if not cfg.addition_embed:
             temb_act = self._temb_cache.get(key)
@@ -275,8 +292,9 @@ class UNet:
             emb = ops.linear(te, self.t2, residual=aug)
             return {"silu_temb": ops.silu(emb)}
 
-    def __call__(self, x, B, H, W, t: int, ctx, L, capture_places=(), added=None, kv_cache=None):
-        """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim].  Returns (eps tokens [B*H*W, 4],
+    def __call__(self, x, B, H, W, t, ctx, L, capture_places=(), added=None, kv_cache=None):
+        """x: [B*H*W, 4] tokens (compute dtype), ctx: [B*L, cross_dim]; t: host integer timestep, or its sinusoid as a
+        device tensor (time_sinusoid) when the call is being captured for replay at any timestep.  Returns (eps tokens [B*H*W, 4],
         maps {place: [probs [B, heads, N, L], ...]}) — maps only for `capture_places` ⊆ {'down','mid','up'}.
         SDXL: added = (text_embeds [B, pooled], time_ids [B, 6]), or the precomputed `added_embedding(...)` tensor.
         kv_cache: a dict owned by the caller for ONE sampler invocation (LoRA factors and `ctx` must not change while
@@ -332,6 +350,7 @@ class GraphedUNetForward:
     def __init__(self, unet: "UNet"):
         self.unet = unet
         self.graphs = {}
+        self.pool = None  # one memory pool for all timesteps: the graphs never run concurrently, only `out` stays alive
 
     def __call__(self, x, B, H, W, t, ctx, L, added=None):
         """`added`: SDXL only — the precomputed UNet.added_embedding(...) tensor (a graph input like x and ctx)."""
@@ -349,8 +368,13 @@ class GraphedUNetForward:
                 u(sx, B, H, W, t, sc, L, added=sa)  # eager warm-up: temb memo, LoRA compute copy, split-K workspace
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                import torch.distributed as dist
+                kw = {"capture_error_mode": "thread_local"} if dist.is_available() and dist.is_initialized() else {}
+                # the package's capture stream: its workspaces exist (zeroed) before any capture begins
+                with torch.cuda.graph(g, pool=self.pool, stream=ops.capture_stream(u.device), **kw):
                     out, _ = u(sx, B, H, W, t, sc, L, added=sa)
+                if self.pool is None:
+                    self.pool = g.pool()
             ent = self.graphs[key] = (g, sx, sc, sa, out)
         g, sx, sc, sa, out = ent
         k = ops.kernels()
