@@ -468,12 +468,24 @@ def secondary_c3(trainer, batch, rank, sync, steps=3):
     sync()
     ms = (time.time() - t0) / steps * 1e3
     total = step_tflop(50, 5, True)
+    # where the step goes: HIP events around every segment replay and around the no-grad UNet replays (2 more steps)
+    st.set_timing(True)
+    ng = tr.pipe.graphed
+    ng.timing = []
+    for _ in range(2):
+        st(b, **fixed)
+    phases = st.timing_summary(2)
+    phases["unet no-grad"] = {"ms_per_step": round(sum(a.elapsed_time(c) for a, c in ng.timing) / 2, 2),
+                              "replays_per_step": len(ng.timing) / 2}
+    st.set_timing(False)
+    ng.timing = None
     return {"workload": "C3: SD1.5 512x512 bs=1, N=50 denoise steps (K=5 sampled with grad), concept-matching + GAN + attribute "
                         "concentration (2 steps), clip+AdamW for G and D - scripts/sd15.sh of the reference",
             "ms_per_step": round(ms, 1), "images_per_sec": round(1e3 / ms, 3), "steps": steps,
             "host_enqueue_ms_per_step": round(host / steps * 1e3, 1),
             "launch_mode": f"{n_graphs} no-grad UNet graphs + step segments ({st.stats()['segments']} segment graphs)",
-            "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS}
+            "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS,
+            "gpu_ms_per_step_by_piece": phases}
 
 
 def precapture_plan(scfg, fixed):
@@ -663,6 +675,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt  # one image (prompt) per rank per step
 
+    pieces = None
+    if seg_stepper is not None and world == 1 and not args.no_kernel_timing:
+        # where a step goes on the GPU: HIP events around every segment replay of two more steps (segments mode)
+        seg_stepper.set_timing(True)
+        for _ in range(2):
+            seg_stepper(batch, **fixed)
+        pieces = seg_stepper.timing_summary(2)
+        seg_stepper.set_timing(False)
     roofline = None
     if not args.no_kernel_timing and not args.selftest:
         # one extra eager step with a recorder around the kernel backend.  EVERY rank runs it (the step contains the
@@ -757,6 +777,7 @@ def main():
                        "host_enqueue_ms_per_step": round(host_s / args.steps * 1e3, 1), "launch_mode": graph_note,
                        "probe_ms_per_step": {k: round(v, 1) for k, v in probe_ms.items()} or None,
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 1),
+                       "gpu_ms_per_step_by_piece": pieces,
                        "per_rank_ms_per_step": per_rank_ms, "allreduce_ms_per_step": allreduce_ms},
             "roofline": roofline, "cpu_baseline": cpu, "attn_map": attn_map, "secondary": secondary,
         }

@@ -101,7 +101,7 @@ SIGNATURES = {
     "comat_attnmap_gather_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_attnmap_gather_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_sumsq": [_vp, _i64, _vp, _vp, _vp],
-    "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _vp, _f, _vp],
+    "comat_adamw": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _vp, _vp, _f, _f, _vp],
     "comat_adamw_tick": [_vp, _vp, _vp],
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
     "comat_set_option": [C.c_char_p, _i32],
@@ -225,12 +225,21 @@ class HipKernels:
         return ws
 
     def prepare_stream(self, dev, gn_groups=64):
-        """create (and zero) every per-stream workspace of the CURRENT stream now, outside any capture"""
+        """create (and zero) every per-stream workspace of the CURRENT stream now, outside any capture; idempotent.
+        -> True if something had to be created (the caller then synchronises before it starts a capture)"""
+        dev = torch.device(dev)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        key = ("prepared", dev, _stream())
+        if key in self._ws:
+            return False
         self._no_capture("workspaces")
         self._workspace(dev)
         self._gn_workspace(dev, gn_groups, 1)
         self._fp8_workspace(dev)
         self._scratch(dev, 1 << 20)
+        self._ws[key] = True
+        return True
 
     def gemm_workspace_bytes(self, M, N, K, batch=1, dtype=torch.bfloat16):
         return int(_lib.comat_gemm_workspace_bytes(M, N, K, batch, BF16 if dtype == torch.bfloat16 else F32))
@@ -518,11 +527,11 @@ class HipKernels:
         ws = self._scratch(x.device, 1024)
         _check(_lib.comat_sumsq(_ptr(x), n, _ptr(out), _ptr(ws), _stream()), "comat_sumsq")
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None):
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None, grad_scale=1.0):
         """step_dev: int32 [2] device counters (applied, skipped) or None; with it the bias correction uses
-        step_dev[0] + 1 and `step` is ignored (see adamw_tick)"""
+        step_dev[0] + 1 and `step` is ignored (see adamw_tick); grad_scale: 1 / world when g holds the ranks' SUM"""
         _check(_lib.comat_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, lr, beta1, beta2, eps, wd, step,
-                                _ptr(step_dev), _ptr(gnorm_sq), max_norm, _stream()), "comat_adamw")
+                                _ptr(step_dev), _ptr(gnorm_sq), max_norm, grad_scale, _stream()), "comat_adamw")
 
     def adamw_tick(self, counters, gnorm_sq):
         assert counters.dtype == torch.int32 and counters.numel() >= 2

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2s,
                                                    const int32_t* __restrict__ step_dev,
-                                                   const float* __restrict__ gnorm_sq, float max_norm) {
-    float clip = 1.0f;
+                                                   const float* __restrict__ gnorm_sq, float max_norm, float grad_scale) {
+    // grad_scale: the buffer holds the SUM of the data-parallel ranks' gradients (RCCL all-reduce SUM); 1 / world turns
+    // it - and its norm - into the mean here, instead of one more pass over the buffer
+    float clip = grad_scale;
     if (step_dev) {  // step count of applied updates lives on the device (see comat_adamw_tick)
         const float t = (float)(*step_dev + 1);
         bc1 = 1.0f - powf(b1, t);
@@ -40,8 +42,8 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* __restrict__ p, const 
     // of the reference's mixed-precision run (accelerate, training_script.py:661-664): parameters and moments stay
     if (gnorm_sq && !isfinite(*gnorm_sq)) return;
     if (gnorm_sq && max_norm > 0.f) {
-        const float c = max_norm / (sqrtf(*gnorm_sq) + 1e-6f);
-        clip = c < 1.0f ? c : 1.0f;
+        const float c = max_norm / (sqrtf(*gnorm_sq) * grad_scale + 1e-6f);
+        clip = c < 1.0f ? c * grad_scale : grad_scale;
     }
     for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += (int64_t)gridDim.x * NT) {
         const float gi = g[i] * clip;
@@ -71,12 +73,12 @@ extern "C" int comat_sumsq(const float* x, int64_t n, float* out, float* ws, voi
 
 extern "C" int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                            float eps, float weight_decay, int32_t step, const int32_t* step_dev,
-                           const float* gnorm_sq, float max_norm, void* stream) {
-    COMAT_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "comat_adamw: bad args");
+                           const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+    COMAT_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev) && grad_scale > 0.f, "comat_adamw: bad args");
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_1d(n, NT)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, bc2s, step_dev, gnorm_sq, max_norm);
+                       beta2, eps, weight_decay, bc1, bc2s, step_dev, gnorm_sq, max_norm, grad_scale);
     return comat_check_launch("comat_adamw");
 }
 

@@ -77,21 +77,24 @@ def capture_stream(dev):
     and zeroed HERE, eagerly, together with the set of the stream's side stream: a workspace first touched inside a
     capture would be zeroed by a node of that one graph only (see _hip.HipKernels._no_capture)."""
     dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     st = _capture.get(dev)
     if st is None:
         st = _capture[dev] = torch.cuda.Stream(device=dev)
-        prepare_capture_stream(dev, st)
+    prepare_capture_stream(dev, st)  # idempotent per kernel backend instance (tests install a fresh one per test)
     return st
 
 
 def prepare_capture_stream(dev, st):
-    """create the per-stream workspaces of `st` and of the side stream forked from it, outside any capture"""
+    """create the per-stream workspaces of `st` and of the side stream forked from it, outside any capture (idempotent)"""
     k = kernels()
     if not hasattr(k, "prepare_stream"):
         return
     global _side_suspended
+    made = False
     with torch.cuda.stream(st):
-        k.prepare_stream(dev)
+        made |= bool(k.prepare_stream(dev))
         saved, _side_suspended = _side_suspended, 0
         try:
             side = _side_stream(torch.device(dev))
@@ -99,8 +102,9 @@ def prepare_capture_stream(dev, st):
             _side_suspended = saved
         if side is not None:
             with torch.cuda.stream(side):
-                k.prepare_stream(dev)
-    torch.cuda.synchronize(dev)
+                made |= bool(k.prepare_stream(dev))
+    if made:
+        torch.cuda.synchronize(dev)
 
 
 class no_side_streams:

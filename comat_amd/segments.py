@@ -68,6 +68,7 @@ class GraphedSegment:
         self.fn, self.name, self.stream, self.pool = fn, name, stream, pool
         self.fg = self.bg = None
         self.replays = 0
+        self.timing = None  # [] -> (kind, start event, end event) per replay (SegmentedStep(timing=True))
 
     @property
     def captured(self):
@@ -102,17 +103,31 @@ class GraphedSegment:
         # expect them, but the pool may hand their addresses to a sibling capture (never live at the same time)
         self.outs = [o.detach() for o in outs]
         del outs
+        # the LoRA factors are not inputs of the replaying autograd node (their gradients are a side effect of the backward
+        # graph), so an input-less dependence is needed for its outputs to require grad when no INPUT does (the first
+        # trained denoise step; every SDXL step: the UNet input is detached there) - the usual dummy-leaf anchor
+        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+
+    def _replay(self, g, kind):
+        if self.timing is None:
+            g.replay()
+            return
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        self.timing.append((kind, s, e))
 
     def __call__(self, *inputs):
-        return _Replay.apply(self, *inputs)
+        return _Replay.apply(self, self.anchor, *inputs)
 
 
 class _Replay(Function):
     @staticmethod
-    def forward(ctx, seg, *inputs):
+    def forward(ctx, seg, anchor, *inputs):
         for s, x in zip(seg.si, inputs):
             _copy_into(s, x)
-        seg.fg.replay()
+        seg._replay(seg.fg, "fwd")
         seg.replays += 1
         ctx.seg = seg
         outs = tuple(o.detach() for o in seg.outs)
@@ -130,8 +145,8 @@ class _Replay(Function):
                 sg.zero_()
             else:
                 _copy_into(sg, g if g.is_contiguous() else g.contiguous())
-        seg.bg.replay()
-        return (None,) + tuple(None if gi is None else gi.detach() for gi in seg.sgi)
+        seg._replay(seg.bg, "bwd")
+        return (None, None) + tuple(None if gi is None else gi.detach() for gi in seg.sgi)
 
 
 class SegmentedStep:
@@ -296,6 +311,26 @@ class SegmentedStep:
             tr.pipe.trained_runner = None
             tr.head_runner = tr.d_runner = None
 
+    def _all(self):
+        return [("unet", s) for s in self.unet_segs.values()] + \
+            [(n, s) for n, s in (("head", self.head_seg), ("disc", self.d_seg)) if s is not None]
+
+    def set_timing(self, flag=True):
+        """HIP events around every segment replay from now on (they cost a few microseconds each: diagnostics only)"""
+        for _, s in self._all():
+            s.timing = [] if flag else None
+
+    def timing_summary(self, steps):
+        """-> {"unet fwd": ms per step, ...} from the replays since set_timing(); synchronises"""
+        torch.cuda.synchronize()
+        acc = {}
+        for name, s in self._all():
+            for kind, a, b in s.timing or ():
+                d = acc.setdefault(f"{name} {kind}", [0.0, 0])
+                d[0] += a.elapsed_time(b)
+                d[1] += 1
+        return {k: {"ms_per_step": round(v[0] / steps, 2), "replays_per_step": round(v[1] / steps, 2)} for k, v in sorted(acc.items())}
+
     def stats(self):
-        segs = list(self.unet_segs.values()) + [s for s in (self.head_seg, self.d_seg) if s is not None]
+        segs = [s for _, s in self._all()]
         return {"segments": len(segs), "replays": sum(s.replays for s in segs)}

@@ -86,14 +86,15 @@ class FlatAdamW:
         """number of applied updates (host read: synchronises; for logs and tests)"""
         return int(self.counters[0])
 
-    def step(self):
+    def step(self, grad_scale=1.0):
+        """grad_scale: 1 / world when the gradient buffers hold the SUM over data-parallel ranks (dist.GradReducer)"""
         k = ops.kernels()
         self.gnorm_sq.zero_()
         for _, g in self.segments:
             k.sumsq(g, g.numel(), self.gnorm_sq)
         for (p, g), m, v in zip(self.segments, self.m, self.v):
             k.adamw(p, g, m, v, p.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 0,
-                    self.gnorm_sq, self.max_norm, step_dev=self.counters)
+                    self.gnorm_sq, self.max_norm, step_dev=self.counters, grad_scale=grad_scale)
         k.adamw_tick(self.counters, self.gnorm_sq)
 
 
@@ -284,11 +285,11 @@ class CoMatTrainer:
             self._d_keep = None
         if self.cfg.gan_loss:
             self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
-        self.reducer.finish()
-        self.opt.step()
+        scale = self.reducer.finish()  # 1 / world: the mean is taken inside the clip + AdamW pass
+        self.opt.step(scale)
         self.bank.mark_updated()
         if self.cfg.gan_loss:
-            self.opt_D.step()
+            self.opt_D.step(scale)
             self.D.bank.mark_updated()
 
     def train_step(self, batch, **fixed):

@@ -350,6 +350,7 @@ class GraphedUNetForward:
     def __init__(self, unet: "UNet"):
         self.unet = unet
         self.graphs = {}
+        self.timing = None
         self.pool = None  # one memory pool for all timesteps: the graphs never run concurrently, only `out` stays alive
 
     def __call__(self, x, B, H, W, t, ctx, L, added=None):
@@ -384,7 +385,14 @@ class GraphedUNetForward:
             k.unary(ops.UN_COPY, added, sa, added.numel())
         if self.unet.lora is not None:
             self.unet.lora.ensure_compute_copy()
-        g.replay()
+        if self.timing is None:
+            g.replay()
+        else:  # diagnostics (bench.py): HIP events around the replay
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            g.replay()
+            e.record()
+            self.timing.append((s, e))
         return out
 
 

@@ -322,7 +322,9 @@ int comat_attnmap_gather_bwd(const float* g_num, const float* g_den, const float
 /* out[0] += sum(x^2)  (caller zeroes out); ws: >= 1024 floats.  Fixed summation order: every data-parallel rank gets
  * the bit-identical norm (and clip factor) from the all-reduced gradient. */
 int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
-/* AdamW with the global-norm clip folded in: g' = g * min(1, max_norm / (sqrt(*gnorm_sq) + 1e-6)).  A non-finite
+/* AdamW with the global-norm clip folded in: g' = s g * min(1, max_norm / (s sqrt(*gnorm_sq) + 1e-6)), s = grad_scale:
+ * the gradient buffer (and *gnorm_sq, the sum of ITS squares) may hold the SUM over data-parallel ranks, grad_scale =
+ * 1 / world makes it the mean (DDP semantics, training_script.py:659) without another pass over the buffer.  A non-finite
  * *gnorm_sq skips the update entirely (p, m, v untouched): the inf/NaN check of a mixed-precision optimizer step.
  * Step count t of the bias correction: `step` (host value, >= 1) when step_dev is NULL; otherwise *step_dev + 1 with
  * the count of APPLIED updates kept in device memory — advanced by comat_adamw_tick after the adamw launches of one
@@ -330,7 +332,7 @@ int comat_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
  * the moments, and a captured hipGraph of the whole step replays with the right count). */
 int comat_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                 float eps, float weight_decay, int32_t step, const int32_t* step_dev, const float* gnorm_sq,
-                float max_norm, void* stream);
+                float max_norm, float grad_scale, void* stream);
 /* counters[0] += 1 if *gnorm_sq is finite (update applied), else counters[1] += 1 (update skipped). */
 int comat_adamw_tick(int32_t* counters, const float* gnorm_sq, void* stream);
 

@@ -13,7 +13,8 @@ from . import sd as O
 
 def g_loss_terms(W, batch, cfg, training_steps, crop, attrcon_steps=()):
     """W: dict(unet, vae, blip, lora, d_unet, d_lora, head_w, head_b, ucfg, vcfg, bcfg[, d_ucfg: the discriminator's
-    UNet config when it differs from the generator's — SDXL generator + SD1.5 discriminator]).  cfg: the product's StepConfig
+    UNet config when it differs from the generator's — SDXL generator + SD1.5 discriminator; fp8_unet: True = generator UNet
+    forward on emulated fp8 operands, oracle/sd.py fp8_forward]).  cfg: the product's StepConfig
     (duck-typed).  Returns dict with loss, Blip (reward), G_loss, token_loss, pixel_loss, image, latents, logp."""
     kw = {}
     if cfg.attrcon:
@@ -24,7 +25,7 @@ def g_loss_terms(W, batch, cfg, training_steps, crop, attrcon_steps=()):
     img, lat, attn_dict = O.sample_with_grad(W["unet"], W["ucfg"], W["vae"], W["vcfg"], W["lora"],
                                              batch["negative_prompt_embeds"], batch["prompt_embeds"],
                                              batch["latents"], batch["noises"], cfg.total_step, training_steps,
-                                             cfg.cfg_scale, **kw)
+                                             cfg.cfg_scale, fp8_unet=bool(W.get("fp8_unet", False)), **kw)
     y0, x0, ch, cw = crop
     reward, logp = OB.score(W["blip"], W["bcfg"], img[:, :, y0:y0 + ch, x0:x0 + cw], batch["blip_input_ids"],
                             batch["blip_attention_mask"], label_smoothing=cfg.label_smoothing)

@@ -398,14 +398,14 @@ class SimKernels:
     def adamw_tick(self, counters, gnorm_sq):
         counters[0 if math.isfinite(float(gnorm_sq[0])) else 1] += 1
 
-    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None):
+    def adamw(self, p, g, m, v, n, lr, beta1, beta2, eps, wd, step, gnorm_sq, max_norm, step_dev=None, grad_scale=1.0):
         if step_dev is not None:
             step = int(step_dev[0]) + 1
-        clip = 1.0
+        clip = grad_scale
         if gnorm_sq is not None and not math.isfinite(float(gnorm_sq[0])):
             return  # non-finite gradient norm: the update is skipped
         if gnorm_sq is not None and max_norm > 0:
-            clip = min(1.0, max_norm / (math.sqrt(float(gnorm_sq[0])) + 1e-6))
+            clip = grad_scale * min(1.0, max_norm / (math.sqrt(float(gnorm_sq[0])) * grad_scale + 1e-6))
         gg = g * clip
         m.mul_(beta1).add_(gg, alpha=1 - beta1)
         v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, gpu=False):
+def _worker(rank, world, port, out_dir, gpu=False, segments=False):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -52,18 +52,24 @@ def _worker(rank, world, port, out_dir, gpu=False):
     mean = torch.stack(gathered).mean(0)
     # the real step: reduces, clips, updates
     p0 = trainer.bank.flat.clone()
-    trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    if segments:  # the launch path bench.py uses on 1 and on N GPUs alike (dry on CPU: the segments run eagerly)
+        from comat_amd.segments import SegmentedStep
+        SegmentedStep(trainer, dry=not gpu)(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    else:
+        trainer.train_step(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
     cpu = lambda t: t.detach().cpu().clone()
-    torch.save(dict(mean=cpu(mean), reduced=cpu(trainer.bank.flat_grad), params=cpu(trainer.bank.flat), p0=cpu(p0),
+    # the buffer holds the ranks' SUM after the exchange; the optimizer kernel applies 1 / world (grad_scale)
+    torch.save(dict(mean=cpu(mean), reduced=cpu(trainer.bank.flat_grad) / world, params=cpu(trainer.bank.flat), p0=cpu(p0),
                     local=cpu(local), d_params=cpu(trainer.D.bank.flat)), os.path.join(out_dir, f"rank{rank}.pt"))
     cdist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_grad_mean(tmp_path):
+@pytest.mark.parametrize("segments", [False, True])
+def test_two_rank_gloo_grad_mean(tmp_path, segments):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, segments), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(world)]
     assert not torch.allclose(r[0]["local"], r[1]["local"])           # ranks really saw different data
     for i in range(world):
@@ -71,6 +77,15 @@ def test_two_rank_gloo_grad_mean(tmp_path):
     assert torch.equal(r[0]["reduced"], r[1]["reduced"])
     assert torch.equal(r[0]["params"], r[1]["params"])                  # replicas stay in sync
     assert not torch.equal(r[0]["params"], r[0]["p0"])
+    # ... and the update is clip + AdamW on the MEAN gradient (the 1 / world factor lives inside the optimizer kernel)
+    from comat_amd.step import StepConfig
+    c = StepConfig()
+    p = r[0]["p0"].clone().requires_grad_(True)
+    p.grad = r[0]["mean"].clone()
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(c.adam_beta1, c.adam_beta2), eps=c.adam_epsilon, weight_decay=c.adam_weight_decay)
+    torch.nn.utils.clip_grad_norm_([p], c.max_grad_norm)
+    opt.step()
+    assert torch.allclose(p.detach(), r[0]["params"], rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.gpu
@@ -83,7 +98,7 @@ def test_two_rank_rccl_grad_mean(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, True), nprocs=world, join=True)
     r = [torch.load(os.path.join(tmp_path, f"rank{i}.pt")) for i in range(world)]
     assert not torch.allclose(r[0]["local"], r[1]["local"])
     for i in range(world):

@@ -329,3 +329,89 @@ def test_fp8_forward_touches_only_the_tagged_layers(sim):
     acts = calls[n_weights:]
     assert len(acts) > 20 and all(s[-1] % 64 == 0 for s in acts)  # activations only, contraction length % 64 == 0
     k.fp8_quantize = orig
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_step_against_oracle_emulation(dev, dtype):
+    """BASELINE config C5 in miniature, at STEP level: SDXL-layout generator with the fp8 forward (bf16 / fp32 backward on
+    the saved unquantised activations), attribute concentration on the two-resolution geometry C5 uses (mid at the lowest
+    map resolution, up at both: `mid_32, up_32, up_64` at 1024^2 -> `mid_2, up_2, up_4` here), SD1.5-layout
+    discriminator, one whole optimisation step against the oracle step with its fp8 emulation (oracle/sd.py fp8_forward:
+    value of the quantised product, gradient of the unquantised one).
+    Tolerance (stated): quantisers in series decorrelate two fp32 implementations (see
+    test_unet_fp8_forward_against_oracle_emulation), so the yardstick is the emulation's own distance to the EXACT step:
+    every loss term within 1.5x that distance (+1e-3 of its scale), LoRA gradients within 1.5x the emulation-vs-exact
+    gradient distance (+ the bf16 step bound for bf16 storage)."""
+    from comat_amd.blip import Blip
+    from comat_amd.gan import D_sd
+    from comat_amd.pipeline import TrainableSDXLPipeline
+    from comat_amd.step import CoMatTrainer, StepConfig
+    from comat_amd.unet import VAEDecoder
+    from oracle import blip as OB
+    from oracle import step as OS
+    ucfg = FP8_UNET
+    vcfg = dataclasses.replace(config.TINY_VAE, scaling_factor=0.13025)
+    q = lambda d: {k_: v.to(dtype).float() for k_, v in d.items()}
+    up5 = lambda d: {k_: (v * 5 if k_.endswith("up.weight") else v) for k_, v in d.items()}
+    usd, vsd = q(weights.make_unet_weights(ucfg, perturb_norms=True)), q(weights.make_vae_weights(vcfg, perturb_norms=True))
+    lsd, bsd = q(up5(weights.make_lora_weights(ucfg))), q(weights.make_blip_weights(config.TINY_BLIP, perturb_norms=True))
+    dsd = q(weights.make_unet_weights(config.TINY_UNET, seed=77, perturb_norms=True))
+    dl = q(up5(weights.make_lora_weights(config.TINY_UNET, seed=78)))
+    g = torch.Generator().manual_seed(6)
+    r = lambda *s: torch.randn(*s, generator=g)
+    head_w, head_b = r(4) * 0.5, r(1) * 0.1
+    cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=True, attrcon_train_steps=1,
+                     train_layer_ls=("mid_2", "up_2", "up_4"), attn_reses=(4, 2), lr=1e-2, lr_D=1e-2,
+                     mask_token_loss_weight=0.5, mask_pixel_loss_weight=0.1)
+    bs, L, T = 1, 7, 9
+    ids = torch.randint(1, config.TINY_BLIP.vocab_size, (bs, T), generator=g)
+    m = np.zeros((2, 64, 64), dtype=bool)
+    m[0, 5:30, 8:40] = True
+    m[1, 34:60, 20:64] = True
+    rq = lambda *s: r(*s).to(dtype).float()
+    batch = dict(prompt_embeds=rq(bs, L, ucfg.cross_attention_dim), negative_prompt_embeds=rq(bs, L, ucfg.cross_attention_dim),
+                 pooled_prompt_embeds=rq(bs, ucfg.pooled_dim), negative_pooled_prompt_embeds=rq(bs, ucfg.pooled_dim),
+                 add_time_ids=(64, 64, 0, 0, 64, 64), gan_null_embeds=rq(bs, L, config.TINY_UNET.cross_attention_dim),
+                 latents=r(bs, 4, 8, 8), noises=[r(bs, 4, 8, 8) for _ in range(3)], real_latents=r(bs, 4, 8, 8),
+                 blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids), masks=[m], attributes=[[[2, 3], [5]]])
+
+    def oracle_world(fp8):
+        return dict(unet=usd, vae=vsd, blip=bsd, d_unet=dsd, ucfg=O.UNetConfig(**dataclasses.asdict(ucfg)),
+                    d_ucfg=O.UNetConfig(**dataclasses.asdict(config.TINY_UNET)), vcfg=O.VAEConfig(**dataclasses.asdict(vcfg)),
+                    bcfg=OB.BlipConfig(**dataclasses.asdict(config.TINY_BLIP)), fp8_unet=fp8,
+                    lora={k_: v.clone().requires_grad_(True) for k_, v in lsd.items()},
+                    d_lora={k_: v.clone().requires_grad_(True) for k_, v in dl.items()},
+                    head_w=head_w.clone().requires_grad_(True), head_b=head_b.clone().requires_grad_(True))
+    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
+    ref8 = OS.train_step(oracle_world(True), batch, cfg, ts, crop, acs)
+    ref = OS.train_step(oracle_world(False), batch, cfg, ts, crop, acs)
+    bank = LoRABank(ucfg, lsd, dtype, dev)
+    unet = UNet(ucfg, usd, dtype, dev, bank, fp8_forward=True)
+    pipe = TrainableSDXLPipeline(unet, VAEDecoder(vcfg, vsd, dtype, dev))
+    dbank = LoRABank(config.TINY_UNET, dl, dtype, dev)
+    disc = D_sd(UNet(config.TINY_UNET, dsd, dtype, dev, dbank), dbank, head_w, head_b)
+    trainer = CoMatTrainer(pipe, bank, Blip(config.TINY_BLIP, bsd, dtype, dev), disc, cfg, seed=0)
+    n_q = []
+    k = ops.kernels()
+    kq = k.fp8_quantize
+    k.fp8_quantize = lambda t, **kw: (n_q.append(t.numel()), kq(t, **kw))[1]
+    try:
+        logs = trainer.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    finally:
+        k.fp8_quantize = kq
+    assert len(n_q) > 40  # the trained and the no-grad generator calls really ran their block layers on fp8 operands
+    names = bank.names
+    cat = lambda d: torch.cat([d[n].reshape(-1) for n in names])
+    g8, gx = cat(ref8["g_grads"]), cat(ref["g_grads"])
+    own = rel_l2(g8, gx)  # the emulation's own distance to the exact step
+    got = rel_l2(bank.flat_grad, g8)
+    line = [f"fp8 step ({dtype}): grads emulation-vs-exact {own:.3e}, product-vs-emulation {got:.3e}"]
+    slack = 0.0 if dtype == torch.float32 else 0.27  # bf16 storage: the SDXL-layout step bound of tests/test_step.py
+    assert own > 1e-3 and got < 1.5 * own + slack, line
+    for key, rk in (("Blip", "Blip"), ("G_loss", "G_loss"), ("D_loss", "D_loss"), ("step_loss", "loss"),
+                    ("token_loss", "token_loss"), ("pixel_loss", "pixel_loss")):
+        a, b8, bx = float(logs[key]), float(ref8[rk]), float(ref[rk])
+        tol_ = 1.5 * abs(b8 - bx) + (1e-3 if dtype == torch.float32 else 3e-2) * max(1.0, abs(b8))
+        line.append(f"{key}: product {a:.5f} emulation {b8:.5f} exact {bx:.5f}")
+        assert abs(a - b8) <= tol_, line
+    print("\n".join(line))
