@@ -1,160 +1,235 @@
 // norm.hip — GroupNorm(+SiLU) and LayerNorm, forward and data-gradient, on channels-last token matrices.
 // HBM-bound kernels: every pass reads whole rows (C contiguous elements) so that a wave's accesses coalesce.
-// Statistics are accumulated per block in fp32 and combined across blocks in fp64 (hardware double atomics),
-// which keeps E[x^2]-E[x]^2 stable enough for the fp32 parity mode.
+// Statistics are accumulated per thread in fp32 and combined in fp64 in a FIXED order (no floating-point atomics), which
+// keeps E[x^2]-E[x]^2 stable enough for the fp32 parity mode and the results bit-reproducible.
 #include "gemm_shared.h"  // splitk_arrive_is_last: the agent-scope ticket protocol, reused for the statistics
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int GN_ROWS = 32;     // rows of one sample handled per block in the statistics passes
-constexpr int MAX_SLOTS = 16;   // channels per thread: C <= 256*16 = 4096
 constexpr int MAX_G = 64;
 
-// ---- GroupNorm forward: per-(b,g) sum / sum of squares -----------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_stats_kernel(const T* __restrict__ x, double* __restrict__ ws, int64_t HW,
-                                                      int C, int G) {
-    __shared__ float s_sum[MAX_G], s_sq[MAX_G];
-    const int b = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS;
-    const int64_t r1 = (r0 + GN_ROWS < HW) ? r0 + GN_ROWS : HW;
-    const int cpg = C / G;
-    if (threadIdx.x < MAX_G) { s_sum[threadIdx.x] = 0.f; s_sq[threadIdx.x] = 0.f; }
-    __syncthreads();
-    float a1[MAX_SLOTS], a2[MAX_SLOTS];
+__device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) { a1[s] = 0.f; a2[s] = 0.f; }
-    const T* base = x + ((int64_t)b * HW) * C;
-    for (int64_t r = r0; r < r1; ++r) {
-        const T* row = base + r * C;
-#pragma unroll
-        for (int s = 0; s < MAX_SLOTS; ++s) {
-            const int c = threadIdx.x + s * NT;
-            if (c < C) {
-                const float v = ldf<T>(row + c);
-                a1[s] += v;
-                a2[s] += v * v;
-            }
-        }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- one-launch GroupNorm: a workgroup owns ONE (sample, group) and keeps its elements in registers ------------------
+// The three-launch form below (statistics over row blocks -> fixed-order combine -> apply) uses the whole chip, which the
+// VAE's 512^2 tensors need; the UNet's groups are small (64^2 x 10 channels = 41 k elements at most levels, 10 k at
+// 16^2) and there each of the three launches is a ~5-9 us latency chain (profiles/r02_k_kernel_trace_eager.txt:
+// gn_vstats 9.5 + gn_reduce 5 + gn_vapply2 8.3 us; 2 700 launches per C2 step).  Here B x G workgroups each read their
+// group once (every thread holds <= MAXU register units of it), reduce in a fixed order (thread-sequential partials in
+// fp32, fixed wave butterfly and wave-sequential combine in fp64), and write the result: one launch, one read of x.
+// A register unit is VEC elements: 2 bf16 (one dword), or one element (fp32, or bf16 groups with an odd channel count).
+// No floating-point atomics anywhere in this file: a shape that fits neither this form nor the vectorised three-launch
+// form is rejected (COMAT_EUNSUPPORTED).
+template <typename T, int VEC> struct GnUnit {
+    static __device__ __forceinline__ uint32_t load(const T* p) {
+        if (sizeof(T) == 4 || VEC == 2) return *(const uint32_t*)p;
+        return (uint32_t)*(const uint16_t*)p;
     }
-#pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        const int c = threadIdx.x + s * NT;
-        if (c < C) {
-            atomicAdd(&s_sum[c / cpg], a1[s]);
-            atomicAdd(&s_sq[c / cpg], a2[s]);
-        }
+    static __device__ __forceinline__ void store(T* p, uint32_t u) {
+        if (sizeof(T) == 4 || VEC == 2) *(uint32_t*)p = u;
+        else *(uint16_t*)p = (uint16_t)u;
+    }
+    static __device__ __forceinline__ float get(uint32_t u, int e) {
+        if (sizeof(T) == 4) return __uint_as_float(u);
+        return bf16_to_f32((bf16_t)(e == 0 ? (u & 0xffffu) : (u >> 16)));
+    }
+    static __device__ __forceinline__ uint32_t pack(float a, float b2) {
+        if (sizeof(T) == 4) return __float_as_uint(a);
+        if (VEC == 1) return (uint32_t)f32_to_bf16(a);
+        return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b2) << 16);
+    }
+};
+
+// block-wide sum of two doubles in a fixed order; NTB / 64 waves
+template <int NTB> __device__ __forceinline__ void gn_block_sum2(double& a, double& b, double* s_red) {
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_red[2 * wave] = a;
+        s_red[2 * wave + 1] = b;
     }
     __syncthreads();
-    if (threadIdx.x < G) {
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_sum[threadIdx.x]);
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_sq[threadIdx.x]);
+    a = 0.0;
+    b = 0.0;
+#pragma unroll
+    for (int w = 0; w < NTB / 64; ++w) {
+        a += s_red[2 * w];
+        b += s_red[2 * w + 1];
     }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ stats, int n, double count,
-                                   float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const double mean = ws[2 * i] / count;
-        double var = ws[2 * i + 1] / count - mean * mean;
+constexpr int GN_ONE_MAXCPG = 256;
+
+// MODE 0: y = silu?(xhat * gamma + beta), stats[b, g] = (mean, rstd).   MODE 1: dx = rstd * (g - (s1 + xhat * s2) / n) [+ add]
+template <typename T, int VEC, int NTB, int MAXU, int MODE>
+__global__ __launch_bounds__(NTB) void gn_one_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ stats, T* __restrict__ out, int HW, int C, int G,
+                                                     float eps, int silu, const T* __restrict__ add) {
+    typedef GnUnit<T, VEC> U;
+    __shared__ float s_gamma[GN_ONE_MAXCPG], s_beta[GN_ONE_MAXCPG];
+    __shared__ double s_red[2 * (NTB / 64)];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G, upr = cpg / VEC, n_u = HW * upr;
+    for (int c = tid; c < cpg; c += NTB) {
+        s_gamma[c] = gamma[g * cpg + c];
+        s_beta[c] = beta[g * cpg + c];
+    }
+    // uniform base pointers (SGPRs) + 32-bit per-lane element offsets (the host checks HW * C < 2^31)
+    const int64_t base = (int64_t)b * HW * C + (int64_t)g * cpg;
+    const T* xb = x + base;
+    const T* gb = MODE == 1 ? dy + base : nullptr;
+    const T* ab = (MODE == 1 && add) ? add + base : nullptr;
+    T* ob = out + base;
+    const int row0 = tid / upr, col0 = tid % upr, drow = NTB / upr, dcol = NTB % upr;
+    float mean = 0.f, rstd = 0.f;
+    if (MODE == 1) {
+        mean = stats[2 * ((int64_t)b * G + g)];
+        rstd = stats[2 * ((int64_t)b * G + g) + 1];
+    }
+    __syncthreads();
+    uint32_t ux[MAXU], ug[MODE == 1 ? MAXU : 1];
+    float a1 = 0.f, a2 = 0.f;
+    {
+        int row = row0, col = col0;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (tid + i * NTB < n_u) {
+                const unsigned off = (unsigned)row * (unsigned)C + (unsigned)(col * VEC);
+                ux[i] = U::load(xb + off);
+                if (MODE == 1) ug[i] = U::load(gb + off);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const float xe = U::get(ux[i], e);
+                    if (MODE == 0) {
+                        a1 += xe;
+                        a2 += xe * xe;
+                    } else {
+                        const int c = col * VEC + e;
+                        const float xh = (xe - mean) * rstd;
+                        float gg = U::get(ug[i], e);
+                        if (silu) gg *= silu_grad_f(xh * s_gamma[c] + s_beta[c]);
+                        gg *= s_gamma[c];
+                        a1 += gg;
+                        a2 += gg * xh;
+                    }
+                }
+            }
+            row += drow;
+            col += dcol;
+            if (col >= upr) {
+                col -= upr;
+                ++row;
+            }
+        }
+    }
+    double d1 = (double)a1, d2 = (double)a2;
+    gn_block_sum2<NTB>(d1, d2, s_red);
+    const double count = (double)HW * cpg;
+    float s1 = 0.f, s2 = 0.f;
+    if (MODE == 0) {
+        const double m = d1 / count;
+        double var = d2 / count - m * m;
         if (var < 0) var = 0;
-        stats[2 * i] = (float)mean;
-        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (tid == 0) {
+            stats[2 * ((int64_t)b * G + g)] = mean;
+            stats[2 * ((int64_t)b * G + g) + 1] = rstd;
+        }
+    } else {
+        s1 = (float)d1;
+        s2 = (float)d2;
     }
-}
-
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, const float* __restrict__ stats,
-                                                      T* __restrict__ y, int64_t HW, int C, int G, int silu,
-                                                      int64_t total) {
-    const int cpg = C / G;
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-        const int c = (int)(i % C);
-        const int64_t b = i / ((int64_t)HW * C);
-        const float* st = stats + (b * G + c / cpg) * 2;
-        float v = (ldf<T>(x + i) - st[0]) * st[1] * gamma[c] + beta[c];
-        if (silu) v = silu_f(v);
-        stf<T>(y + i, v);
-    }
-}
-
-// ---- GroupNorm backward ------------------------------------------------------------------------------------------
-// gy = dy * silu'(yhat) (if fused), yhat = xhat*gamma + beta;  s1 = sum gy*gamma,  s2 = sum gy*gamma*xhat
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          const float* __restrict__ stats, double* __restrict__ ws,
-                                                          int64_t HW, int C, int G, int silu) {
-    __shared__ float s_1[MAX_G], s_2[MAX_G];
-    const int b = blockIdx.y;
-    const int64_t r0 = (int64_t)blockIdx.x * GN_ROWS;
-    const int64_t r1 = (r0 + GN_ROWS < HW) ? r0 + GN_ROWS : HW;
-    const int cpg = C / G;
-    if (threadIdx.x < MAX_G) { s_1[threadIdx.x] = 0.f; s_2[threadIdx.x] = 0.f; }
-    __syncthreads();
-    float a1[MAX_SLOTS], a2[MAX_SLOTS];
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    {
+        int row = row0, col = col0;
+        asm volatile("" : "+v"(row), "+v"(col));  // recompute the offsets: keeping MAXU of them live would spill
 #pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) { a1[s] = 0.f; a2[s] = 0.f; }
-    const int64_t base = ((int64_t)b * HW) * C;
-    for (int64_t r = r0; r < r1; ++r) {
+        for (int i = 0; i < MAXU; ++i) {
+            if (tid + i * NTB < n_u) {
+                const unsigned off = (unsigned)row * (unsigned)C + (unsigned)(col * VEC);
+                uint32_t ua = 0;
+                if (MODE == 1 && add) ua = U::load(ab + off);
+                float o[2] = {0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < MAX_SLOTS; ++s) {
-            const int c = threadIdx.x + s * NT;
-            if (c < C) {
-                const float* st = stats + ((int64_t)b * G + c / cpg) * 2;
-                const int64_t i = base + r * C + c;
-                const float xh = (ldf<T>(x + i) - st[0]) * st[1];
-                float g = ldf<T>(dy + i);
-                if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
-                g *= gamma[c];
-                a1[s] += g;
-                a2[s] += g * xh;
+                for (int e = 0; e < VEC; ++e) {
+                    const int c = col * VEC + e;
+                    const float xh = (U::get(ux[i], e) - mean) * rstd;
+                    if (MODE == 0) {
+                        float y = xh * s_gamma[c] + s_beta[c];
+                        if (silu) y = silu_f(y);
+                        o[e] = y;
+                    } else {
+                        float gg = U::get(ug[i], e);
+                        if (silu) gg *= silu_grad_f(xh * s_gamma[c] + s_beta[c]);
+                        gg *= s_gamma[c];
+                        float d = rstd * (gg - (s1 + xh * s2) * inv_n);
+                        if (add) d += U::get(ua, e);
+                        o[e] = d;
+                    }
+                }
+                U::store(ob + off, U::pack(o[0], o[1]));
+            }
+            row += drow;
+            col += dcol;
+            if (col >= upr) {
+                col -= upr;
+                ++row;
             }
         }
     }
-#pragma unroll
-    for (int s = 0; s < MAX_SLOTS; ++s) {
-        const int c = threadIdx.x + s * NT;
-        if (c < C) {
-            atomicAdd(&s_1[c / cpg], a1[s]);
-            atomicAdd(&s_2[c / cpg], a2[s]);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 0], (double)s_1[threadIdx.x]);
-        atomicAdd(&ws[((int64_t)b * G + threadIdx.x) * 2 + 1], (double)s_2[threadIdx.x]);
-    }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          const float* __restrict__ stats,
-                                                          const double* __restrict__ ws, T* __restrict__ dx,
-                                                          int64_t HW, int C, int G, int silu, int64_t total,
-                                                          const T* __restrict__ add) {
+// Which one-launch variant serves a group of n_u register units: 0 = none (too large).  Forward keeps x (MAXU units per
+// thread), backward keeps x and dy (2 * MAXU).
+static inline int gn_one_variant(int64_t n_u, bool bwd) {
+    if (n_u <= 256 * 24) return 1;                  // 256 threads x 24 units
+    if (n_u <= 1024 * 16) return 2;                 // 1024 threads x 16
+    if (n_u <= 1024 * (bwd ? 40 : 64)) return 3;    // 1024 threads x 64 (forward) / 40 (backward): <= 128 VGPRs per thread
+    return 0;
+}
+
+template <typename T, int VEC, int MODE>
+static bool gn_one_launch(const void* x, const void* dy, const float* gamma, const float* beta, float* stats, void* out,
+                          int B, int64_t HW, int C, int G, float eps, int silu, const void* add, hipStream_t st) {
     const int cpg = C / G;
-    const float inv_n = 1.0f / (float)((double)HW * cpg);
-    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += (int64_t)gridDim.x * NT) {
-        const int c = (int)(i % C);
-        const int64_t b = i / ((int64_t)HW * C);
-        const int64_t sg = b * G + c / cpg;
-        const float mean = stats[2 * sg], rstd = stats[2 * sg + 1];
-        const float s1 = (float)ws[2 * sg], s2 = (float)ws[2 * sg + 1];
-        const float xh = (ldf<T>(x + i) - mean) * rstd;
-        float g = ldf<T>(dy + i);
-        if (silu) g *= silu_grad_f(xh * gamma[c] + beta[c]);
-        g *= gamma[c];
-        float d = rstd * (g - (s1 + xh * s2) * inv_n);
-        if (add) d += ldf<T>(add + i);
-        stf<T>(dx + i, d);
+    const int64_t n_u = HW * (cpg / VEC);
+    const int v = gn_one_variant(n_u, MODE == 1);
+    if (v == 0) return false;
+    const dim3 grid((unsigned)G, (unsigned)B);
+#define GN_ONE(NTB_, MAXU_)                                                                                                  \
+    hipLaunchKernelGGL((gn_one_kernel<T, VEC, NTB_, MAXU_, MODE>), grid, dim3(NTB_), 0, st, (const T*)x, (const T*)dy, gamma, \
+                       beta, stats, (T*)out, (int)HW, C, G, eps, silu, (const T*)add)
+    if (v == 1) GN_ONE(256, 24);
+    else if (v == 2) GN_ONE(1024, 16);
+    else if constexpr (MODE == 0) GN_ONE(1024, 64);
+    else GN_ONE(1024, 40);
+#undef GN_ONE
+    return true;
+}
+
+// option norm_fused: 3 (default) = one launch wherever a group fits a workgroup's registers, 0 = always three launches,
+// 1 / 2 = the two-launch forms.  -> true when the one-launch form took the call
+template <int MODE>
+static bool gn_try_one(const void* x, const void* dy, const float* gamma, const float* beta, float* stats, void* out, int B,
+                       int64_t HW, int C, int G, float eps, int silu, const void* add, int dtype, bool must, hipStream_t st) {
+    if (!must && comat_option(COMAT_OPT_NORM_FUSED) != 3) return false;
+    const int cpg = C / G;
+    if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
+    if (dtype == COMAT_F32) {
+        if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy | (uintptr_t)add) & 3) != 0) return false;
+        return gn_one_launch<float, 1, MODE>(x, dy, gamma, beta, stats, out, B, HW, C, G, eps, silu, add, st);
     }
+    const bool even = cpg % 2 == 0 && C % 2 == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy | (uintptr_t)add) & 3) == 0;
+    if (even) return gn_one_launch<bf16_t, 2, MODE>(x, dy, gamma, beta, stats, out, B, HW, C, G, eps, silu, add, st);
+    return gn_one_launch<bf16_t, 1, MODE>(x, dy, gamma, beta, stats, out, B, HW, C, G, eps, silu, add, st);
 }
 
 // ---- vectorised GroupNorm (C % (16/sizeof(T)) == 0): 16-byte accesses, fixed channel vector per thread -----------
@@ -169,12 +244,6 @@ template <typename T> __device__ __forceinline__ float gv_get(const GV16& v, int
 template <typename T> __device__ __forceinline__ void gv_set(GV16& v, int e, float x) {
     if (sizeof(T) == 2) v.h[e] = f32_to_bf16(x);
     else v.f[e] = x;
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 constexpr int VSLOTS = 2;  // channel vectors per thread: C <= 256 * 2 * EPV
@@ -720,34 +789,22 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
                                    int32_t dtype, void* stream) {
     COMAT_REQUIRE(x && gamma && beta && y && stats && ws, "comat_groupnorm_fwd: null pointer");
     COMAT_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "comat_groupnorm_fwd: bad shape");
-    COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_fwd: C or G too large");
+    COMAT_REQUIRE(G <= MAX_G && B <= 65535, "comat_groupnorm_fwd: G or B too large");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_fwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (gn_vec_ok(x, y, C, dtype, HW)) {
-        if (dtype == COMAT_BF16) gn_fwd_vec<bf16_t>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
-        else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
+    const bool vec = gn_vec_ok(x, y, C, dtype, HW);
+    // one launch where a (sample, group) fits a workgroup's registers (every UNet level); the vectorised three-launch form
+    // for the large tensors of the VAE; nothing else: a shape neither takes is an error, not a slower kernel
+    if (gn_try_one<0>(x, nullptr, gamma, beta, stats, y, B, HW, C, G, eps, silu, nullptr, dtype, !vec, st))
         return comat_check_launch("comat_groupnorm_fwd");
+    if (!vec) {
+        comat_set_error("comat_groupnorm_fwd: unsupported shape (C = %d, G = %d, HW = %lld): groups of more than 65 536 "
+                        "register units need C %% %d == 0 and 16-byte aligned tensors", C, G, (long long)HW,
+                        dtype == COMAT_BF16 ? 8 : 4);
+        return COMAT_EUNSUPPORTED;
     }
-    ws += GN_TICKETS / 2;  // the ticket counters at the head of the workspace stay untouched (zero)
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {  // scalar fallback: fp64 atomics
-        comat_set_error("comat_groupnorm_fwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
-    dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
-    const int64_t total = (int64_t)B * HW * C;
-    if (dtype == COMAT_BF16)
-        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, sg, dim3(NT), 0, st, (const bf16_t*)x, ws, HW, C, G);
-    else
-        hipLaunchKernelGGL(gn_stats_kernel<float>, sg, dim3(NT), 0, st, (const float*)x, ws, HW, C, G);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, (const double*)ws, stats,
-                       B * G, (double)HW * (C / G), eps);
-    const int grid = grid_1d(total, NT, 8192);
-    if (dtype == COMAT_BF16)
-        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)x, gamma, beta,
-                           (const float*)stats, (bf16_t*)y, HW, C, G, silu, total);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)x, gamma, beta,
-                           (const float*)stats, (float*)y, HW, C, G, silu, total);
+    if (dtype == COMAT_BF16) gn_fwd_vec<bf16_t>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
+    else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, st);
     return comat_check_launch("comat_groupnorm_fwd");
 }
 
@@ -756,36 +813,20 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
                                    int32_t G, int32_t silu, const void* add, int32_t dtype, void* stream) {
     COMAT_REQUIRE(dy && x && gamma && beta && stats && dx && ws, "comat_groupnorm_bwd: null pointer");
     COMAT_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "comat_groupnorm_bwd: bad shape");
-    COMAT_REQUIRE(G <= MAX_G && C <= NT * MAX_SLOTS && B <= 65535, "comat_groupnorm_bwd: C or G too large");
+    COMAT_REQUIRE(G <= MAX_G && B <= 65535, "comat_groupnorm_bwd: G or B too large");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_groupnorm_bwd: bad dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0) {
-        COMAT_REQUIRE(!add || ((uintptr_t)add % 16) == 0, "comat_groupnorm_bwd: `add` must be 16-byte aligned");
-        if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
-        else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
+    const bool vec = gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0 && (!add || ((uintptr_t)add % 16) == 0);
+    if (gn_try_one<1>(x, dy, gamma, beta, (float*)stats, dx, B, HW, C, G, 0.f, silu, add, dtype, !vec, st))
         return comat_check_launch("comat_groupnorm_bwd");
+    if (!vec) {
+        comat_set_error("comat_groupnorm_bwd: unsupported shape (C = %d, G = %d, HW = %lld): groups of more than 40 960 "
+                        "register units need C %% %d == 0 and 16-byte aligned tensors", C, G, (long long)HW,
+                        dtype == COMAT_BF16 ? 8 : 4);
+        return COMAT_EUNSUPPORTED;
     }
-    ws += GN_TICKETS / 2;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B * G, st) != hipSuccess) {
-        comat_set_error("comat_groupnorm_bwd: memset failed");
-        return COMAT_ELAUNCH;
-    }
-    dim3 sg((unsigned)cdiv64(HW, GN_ROWS), (unsigned)B);
-    const int64_t total = (int64_t)B * HW * C;
-    const int grid = grid_1d(total, NT, 8192);
-    if (dtype == COMAT_BF16) {
-        hipLaunchKernelGGL(gn_bwd_stats_kernel<bf16_t>, sg, dim3(NT), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
-                           gamma, beta, stats, ws, HW, C, G, silu);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(NT), 0, st, (const bf16_t*)dy,
-                           (const bf16_t*)x, gamma, beta, stats, (const double*)ws, (bf16_t*)dx, HW, C, G, silu,
-                           total, (const bf16_t*)add);
-    } else {
-        hipLaunchKernelGGL(gn_bwd_stats_kernel<float>, sg, dim3(NT), 0, st, (const float*)dy, (const float*)x, gamma,
-                           beta, stats, ws, HW, C, G, silu);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(NT), 0, st, (const float*)dy,
-                           (const float*)x, gamma, beta, stats, (const double*)ws, (float*)dx, HW, C, G, silu, total,
-                           (const float*)add);
-    }
+    if (dtype == COMAT_BF16) gn_bwd_vec<bf16_t>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
+    else gn_bwd_vec<float>(dy, x, gamma, beta, stats, dx, ws, B, HW, C, G, silu, add, st);
     return comat_check_launch("comat_groupnorm_bwd");
 }
 

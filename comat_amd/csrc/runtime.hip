@@ -48,9 +48,10 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
-    {"norm_fused", "COMAT_NORM_FUSED", 0, 0, false},      // GroupNorm in 2 launches instead of 3: 1 = statistics finalised
-                                                          // by the last-arriving block (measured 5 % slower per step),
-                                                          // 2 = by the prologue of the apply kernel (<= 64 slabs)
+    {"norm_fused", "COMAT_NORM_FUSED", 3, 0, false},      // GroupNorm: 3 = ONE launch wherever a (sample, group) fits a
+                                                          // workgroup's registers (every UNet level), 0 = always the
+                                                          // three-launch form, 1 / 2 = two launches (statistics finalised
+                                                          // by the last-arriving block / by the apply kernel's prologue)
     {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
                                                           // kernel with hardware transpose reads
 };

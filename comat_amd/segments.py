@@ -67,6 +67,7 @@ class GraphedSegment:
     def __init__(self, fn, name, stream=None, pool=None):
         self.fn, self.name, self.stream, self.pool = fn, name, stream, pool
         self.fg = self.bg = None
+        self.side_out = None
         self.replays = 0
         self.timing = None  # [] -> (kind, start event, end event) per replay (SegmentedStep(timing=True))
 
@@ -74,7 +75,10 @@ class GraphedSegment:
     def captured(self):
         return self.fg is not None
 
-    def capture(self, inputs):
+    def capture(self, inputs, bwd_side=None):
+        """bwd_side = (fn, stream): fn() is captured INSIDE the backward graph on `stream`, forked at its beginning and
+        joined at its end (work that is independent of this backward and should overlap it: the discriminator step);
+        its result is kept in `self.side_out`.  `stream` needs its own workspaces (ops.prepare_capture_stream)."""
         dev = inputs[0].device
         st = self.stream or ops.capture_stream(dev)
         if self.pool is None:
@@ -94,8 +98,15 @@ class GraphedSegment:
         if any(self.out_req):
             self.bg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bg, pool=self.pool, stream=st, **kw):
+                if bwd_side is not None:
+                    side_fn, side_st = bwd_side
+                    side_st.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side_st):
+                        self.side_out = side_fn()
                 torch.autograd.backward([o for o, r in zip(outs, self.out_req) if r],
                                         [g for g in self.sgo if g is not None])
+                if bwd_side is not None:
+                    torch.cuda.current_stream(dev).wait_stream(side_st)
             self.sgi = [x.grad for x in self.si]
             for x in self.si:
                 x.grad = None
@@ -161,14 +172,16 @@ class SegmentedStep:
                   "pooled_prompt_embeds", "negative_pooled_prompt_embeds")
     INT_KEYS = ("blip_input_ids", "blip_attention_mask")
 
-    def __init__(self, trainer, use_head=True, use_d=True, dry=False):
-        """dry: run every segment's function eagerly through the same hooks, never capture (checks the host logic of the
+    def __init__(self, trainer, use_head=True, use_d="head", dry=False):
+        """use_d: "head" = the discriminator step is captured inside the head's backward graph (on its own stream, it
+        overlaps the generator's backward), "own" = its own graph on the discriminator's stream, False = eager.
+        dry: run every segment's function eagerly through the same hooks, never capture (checks the host logic of the
         hooks where there is no GPU: tests/test_segments.py)"""
         self.tr = trainer
         self.dry = dry
         self.unet_segs, self.slot_pools = {}, {}
         self.head_seg = self.d_seg = None
-        self.use_head, self.use_d = use_head, use_d
+        self.use_head, self.use_d = use_head, (use_d if use_head or use_d != "head" else "own")
         self.static = {}
         self.enabled = trainer.device.type == "cuda"
 
@@ -249,15 +262,33 @@ class SegmentedStep:
 
         inputs = (lat, batch["blip_input_ids"], batch["blip_attention_mask"]) + \
             ((batch["gan_null_embeds"],) if cfg.gan_loss else ())
+        d_in_head = self.use_d == "head" and cfg.gan_loss and tr.D is not None
+        if d_in_head:
+            inputs = inputs + (batch["real_latents"],)  # staged with the head's inputs, read by the D branch
         if self.dry:
             outs = fn(*inputs)
             self._img_hw = tr._last_image_hw
         elif self.head_seg is None:
             tr.blip.install_static_tables(res, res, crop)
-            self.head_seg = GraphedSegment(fn, "head")
+            seg = self.head_seg = GraphedSegment(fn, "head")
             outs = fn(*inputs)
             self._img_hw = tr._last_image_hw
-            self.head_seg.capture(inputs)
+            side = None
+            if d_in_head:
+                # The discriminator step reads the (detached) final latents and nothing of the generator's backward: it is
+                # captured INSIDE the head's backward graph on the discriminator's stream and overlaps it (two graphs
+                # launched on two streams do not overlap on this runtime: measured 176 vs 153 ms per C2 step).  A fork
+                # from a forked stream crashes hipStreamEndCapture on ROCm 7.2, so its weight gradients stay on that stream.
+                if tr._d_stream is None:
+                    tr._d_stream = torch.cuda.Stream(device=tr.device)
+                ops.prepare_capture_stream(tr.device, tr._d_stream)
+
+                def d_side():
+                    with ops.no_side_streams():
+                        return tr._d_step_eager(dict(training_latents=seg.si[0].detach()),
+                                                dict(batch, real_latents=seg.si[-1], gan_null_embeds=seg.si[3]))
+                side = (d_side, tr._d_stream)
+            seg.capture(inputs, bwd_side=side)
         else:
             outs = self.head_seg(*inputs)
         o = dict(reward=outs[0], logp=outs[1], image=(outs[-1],) + tuple(self._img_hw))
@@ -276,6 +307,11 @@ class SegmentedStep:
         real = batch["real_latents"]
         inputs = (out["training_latents"].detach(), real, batch["gan_null_embeds"])
         if self.dry:
+            return fn(*inputs)
+        if self.use_d == "head":
+            # replayed inside the head's backward graph; until that graph exists (first step) the step runs eagerly here
+            if self.head_seg is not None and self.head_seg.replays > 0 and self.head_seg.side_out is not None:
+                return self.head_seg.side_out  # fixed-address scalar, written when the backward graph replays
             return fn(*inputs)
         if self.d_seg is None:
             st = torch.cuda.current_stream(dev)  # the discriminator's stream (step.CoMatTrainer forks it) or the main one

@@ -159,10 +159,14 @@ def test_groupnorm(dev, dtype, silu, shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 4096, 320, 32), (2, 64, 1280, 32), (1, 16384, 128, 32), (2, 50, 32, 8), (1, 130, 320, 32)])
+@pytest.mark.parametrize("shape", [(2, 4096, 320, 32), (2, 64, 1280, 32), (1, 16384, 128, 32), (2, 50, 32, 8), (1, 130, 320, 32),
+                                   (2, 1024, 640, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), (2, 256, 2560, 32),
+                                   (3, 77, 24, 8)])
 def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
-    """option norm_fused: 1 = the last-arriving statistics block finalises, 2 = the prologue of the apply kernel does (no
-    reduce launch in either).  Same statistics up to the fp64 summation order of the per-block partials: outputs and
+    """option norm_fused: 3 (default) = ONE launch, a workgroup per (sample, group) holding the group in registers (the
+    shapes cover its three register variants, forward and backward capacity limits - beyond them the call takes the
+    three-launch form - and a group with an odd channel count); 1 = the last-arriving statistics block finalises, 2 = the
+    prologue of the apply kernel does.  Same statistics up to the summation order of the partial sums: outputs and
     gradients agree with the three-launch form to fp32 rounding, and with the torch reference as in test_groupnorm."""
     B_, HW, C, G = shape
     x = rnd(B_, HW, C, dtype=dtype, seed=1) * 2 + 0.7
@@ -174,7 +178,11 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
     (yr * gy).sum().backward()
     xr.grad += gy2.reshape(B_, HW, C)
     res = []
-    for mode in (0, 1, 2):
+    vec_ok = C % (4 if dtype == torch.float32 else 8) == 0  # what the multi-launch forms need (else: one launch or an error)
+    for mode in (0, 1, 2, 3, 3):
+        if mode != 3 and not vec_ok:
+            res.append(None)
+            continue
         _set_opts(norm_fused=mode)
         xd = dv(x.reshape(B_ * HW, C), hip, dtype, grad=True)
         y, xa = ops.group_norm_fork(xd, dv(gamma, hip), dv(beta, hip), B_, HW, G=G, eps=1e-5, silu=True)
@@ -183,9 +191,12 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
         check(y, yr, dtype, f"gn fwd (norm_fused={mode})")
         check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, f"gn bwd (norm_fused={mode})", factor=2)
     lim = 2e-6 if dtype == torch.float32 else 1e-2  # bf16: an output may flip by one ulp
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
+        if res[0] is None:
+            continue
         for a, b_, name in zip(res[0], res[mode], ("y", "dx")):
             assert rel_l2(b_, a) < lim, f"norm_fused={mode}: {name} differs from the three-launch form by {rel_l2(b_, a):.2e}"
+    assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])  # run-to-run bit-identical
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -710,7 +721,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=0)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=3)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)

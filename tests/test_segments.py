@@ -120,8 +120,20 @@ def test_segmented_step_matches_eager(hip, dtype, attrcon):
     st = SegmentedStep(tr_g)
     run_plan(tr_e, st, batch, dtype, attrcon, torch.equal)
     s = st.stats()
-    assert s["replays"] > 20, s
+    assert s["replays"] >= 15, s
     assert st.head_seg is not None and st.head_seg.replays == len(PLAN) - 1
+    assert st.d_seg is None and st.head_seg.side_out is not None  # the D step lives inside the head's backward graph
+
+
+@pytest.mark.gpu
+def test_segmented_step_with_its_own_discriminator_graph(hip):
+    """use_d="own": the discriminator step as a separate graph on the discriminator's stream (same bits, less overlap)"""
+    dtype = torch.bfloat16
+    cfg, batch, W, tr_e = make_world(dtype, hip, False)
+    cfg, _, _, tr_g = make_world(dtype, hip, False)
+    tr_e.pipe.share_text_kv = False
+    st = SegmentedStep(tr_g, use_d="own")
+    run_plan(tr_e, st, batch, dtype, False, torch.equal)
     assert st.d_seg is not None and st.d_seg.replays == len(PLAN) - 1
 
 
