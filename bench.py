@@ -331,55 +331,82 @@ def cpu_baseline(usd, scfg):
     are absent) on a BOUNDED sample of the same workload, per SURVEY.md 8d: one UNet call without grad and one with
     grad (LoRA + input gradients) at the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens), one BLIP
     reward forward + backward at 510^2 -> 384^2, one VAE decode forward + backward on a 32x32 latent (a quarter of the
-    pixels; x4), each timed once after the UNet forward has warmed the thread pool; the step time is these times
-    combined by the step's call counts (the discriminator is the same UNet: G side batch 1 = half a trained call, D
-    side batch 2 = one trained call)."""
+    pixels; x4).  Each component: 1 warm-up + 3 timed repetitions, median.  Threads: all host threads or 64 of them,
+    whichever runs the no-grad UNet call faster on this box (both are reported).  The step time is the medians combined by
+    the step's call counts (the discriminator is the same UNet: G side batch 1 = half a trained call, D side batch 2 = one
+    trained call)."""
     from comat_amd import config, weights
     from oracle import blip as OB
     from oracle import sd as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
     import dataclasses
+    cores = os.cpu_count() or 1
+
+    def timed(fn, reps=3, warm=1):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return sorted(ts)[len(ts) // 2], ts
+
     ocfg = O.UNetConfig(**dataclasses.asdict(config.SD15_UNET))
     g = torch.Generator().manual_seed(0)
     x, ctx = torch.randn(2, 4, 64, 64, generator=g), torch.randn(2, 77, 768, generator=g)
     lora = {k: v.clone().requires_grad_(True) for k, v in weights.make_lora_weights(config.SD15_UNET, seed=4321).items()}
-    t = {}
-    with torch.no_grad():
-        t0 = time.time()
-        O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
-        t["unet_nograd"] = time.time() - t0
-    xg = x.clone().requires_grad_(True)
-    t0 = time.time()
-    O.unet_forward(usd, ocfg, xg, 801, ctx, lora, None).float().square().mean().backward()
-    t["unet_train"] = time.time() - t0
-    del lora, xg
+    t, reps_all = {}, {}
+
+    def nograd():
+        with torch.no_grad():
+            O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
+
+    by_threads = {}
+    for th in sorted({cores, min(cores, 64)}, reverse=True):
+        torch.set_num_threads(th)
+        by_threads[th] = timed(nograd)
+    threads = min(by_threads, key=lambda th: by_threads[th][0])
+    torch.set_num_threads(threads)
+    t["unet_nograd"], reps_all["unet_nograd"] = by_threads[threads]
+
+    def train():
+        for p in lora.values():
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        O.unet_forward(usd, ocfg, xg, 801, ctx, lora, None).float().square().mean().backward()
+    t["unet_train"], reps_all["unet_train"] = timed(train, warm=0)  # the pool is warm; 13 s per repetition
+    del lora
     vcfg = O.VAEConfig(**dataclasses.asdict(config.SD15_VAE))
     vsd = weights.make_vae_weights(config.SD15_VAE, seed=2345)
-    z = torch.randn(1, 4, 32, 32, generator=g).requires_grad_(True)
-    t0 = time.time()
-    O.vae_decode(vsd, vcfg, z).square().mean().backward()
-    t["vae_quarter_train"] = time.time() - t0
-    del vsd, z
+    z0 = torch.randn(1, 4, 32, 32, generator=g)
+
+    def vae():
+        z = z0.clone().requires_grad_(True)
+        O.vae_decode(vsd, vcfg, z).square().mean().backward()
+    t["vae_quarter_train"], reps_all["vae_quarter_train"] = timed(vae)
+    del vsd
     bcfg = OB.BlipConfig(**dataclasses.asdict(config.BLIP_LARGE))
     bsd = weights.make_blip_weights(config.BLIP_LARGE, seed=3456)
-    img = torch.rand(1, 3, 510, 510, generator=g).requires_grad_(True)
+    img0 = torch.rand(1, 3, 510, 510, generator=g)
     ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
                      torch.tensor([102])]).reshape(1, 16)
-    t0 = time.time()
-    reward, _ = OB.score(bsd, bcfg, img, ids, torch.ones_like(ids), label_smoothing=0.1)
-    reward.backward()
-    t["blip_train"] = time.time() - t0
+
+    def blip():
+        img = img0.clone().requires_grad_(True)
+        reward, _ = OB.score(bsd, bcfg, img, ids, torch.ones_like(ids), label_smoothing=0.1)
+        reward.backward()
+    t["blip_train"], reps_all["blip_train"] = timed(blip)
     del bsd
     step_s = (scfg.K * t["unet_train"] + (scfg.total_step - scfg.K) * t["unet_nograd"] + 4 * t["vae_quarter_train"]
               + t["blip_train"] + (1.5 * t["unet_train"] if scfg.gan_loss else 0.0))
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle/ (CPU fp32) components timed once each on " + f"{threads} of {cores} host threads: "
-                      + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
+            "sample": f"oracle/ (CPU fp32) components, median of 3 repetitions after a warm-up, on {threads} of {cores} host "
+                      "threads (no-grad UNet call: " + ", ".join(f"{v[0]:.1f} s on {k} threads" for k, v in by_threads.items())
+                      + "): " + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
                       + f"; step = {scfg.K} x unet_train + {scfg.total_step - scfg.K} x unet_nograd + 4 x vae_quarter_train + "
                       f"blip_train + 1.5 x unet_train (discriminator G and D sides) = {step_s:.0f} s",
-            "components_s": {k: round(v, 2) for k, v in t.items()}}
+            "components_s": {k: round(v, 2) for k, v in t.items()},
+            "repetitions_s": {k: [round(x_, 2) for x_ in v] for k, v in reps_all.items()}}
 
 
 def load_pmc_summary():
@@ -576,7 +603,12 @@ def main():
         if not ok:
             trainer.blip.static_tables = None
             trainer.pipe.trained_runner = trainer.head_runner = trainer.d_runner = None
-            sync()
+            ops.reset_capture_stream(device)  # a failed capture may leave its streams in capture mode
+            trainer._d_stream = None
+            try:
+                sync()
+            except Exception:  # noqa: BLE001 - the pending error of the failed capture
+                pass
         return (cand if ok else None), err
 
     def probe(fn, n=3):

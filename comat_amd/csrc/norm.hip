@@ -220,7 +220,11 @@ static bool gn_one_launch(const void* x, const void* dy, const float* gamma, con
 template <int MODE>
 static bool gn_try_one(const void* x, const void* dy, const float* gamma, const float* beta, float* stats, void* out, int B,
                        int64_t HW, int C, int G, float eps, int silu, const void* add, int dtype, bool must, hipStream_t st) {
-    if (!must && comat_option(COMAT_OPT_NORM_FUSED) != 3) return false;
+    // Measured on MI355X (profiles/r03_f_mb_gn.txt): B x G workgroups reading 20..160-byte row pieces win where a group is
+    // small (8x8 and 16x16 levels: 5.8 vs 10.7 us, 10.0 vs 15.0 us) and lose where the tensor needs the whole chip's
+    // bandwidth (64x64 x 320: 28 vs 14 us) - so the one-launch form serves HW <= 256, and whatever the vectorised form
+    // cannot take at all (`must`).
+    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) != 3 || HW > 256)) return false;
     const int cpg = C / G;
     if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
     if (dtype == COMAT_F32) {

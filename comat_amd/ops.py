@@ -86,6 +86,17 @@ def capture_stream(dev):
     return st
 
 
+def reset_capture_stream(dev):
+    """after a FAILED capture: the capture stream (and streams forked from it) may be left in capture mode by the runtime -
+    forget it, the next capture_stream() call makes a fresh one"""
+    dev = torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _capture.pop(dev, None)
+    if st is not None:
+        _side.pop((dev, st.cuda_stream), None)
+
+
 def prepare_capture_stream(dev, st):
     """create the per-stream workspaces of `st` and of the side stream forked from it, outside any capture (idempotent)"""
     k = kernels()

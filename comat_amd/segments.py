@@ -288,6 +288,14 @@ class SegmentedStep:
                         return tr._d_step_eager(dict(training_latents=seg.si[0].detach()),
                                                 dict(batch, real_latents=seg.si[-1], gan_null_embeds=seg.si[3]))
                 side = (d_side, tr._d_stream)
+                # the capture must find every host-side memo of the discriminator's D-side call filled (its time embedding,
+                # targets): run that step once eagerly now.  It leaves nothing behind - the step's real D step, which
+                # follows in this same optimisation step, starts by zeroing the discriminator's gradients.
+                cur = torch.cuda.current_stream(tr.device)
+                tr._d_stream.wait_stream(cur)
+                with torch.cuda.stream(tr._d_stream), ops.no_side_streams():
+                    tr._d_step_eager(dict(training_latents=lat.detach()), batch)
+                cur.wait_stream(tr._d_stream)
             seg.capture(inputs, bwd_side=side)
         else:
             outs = self.head_seg(*inputs)
