@@ -129,6 +129,7 @@ class CoMatTrainer:
         self.reducer = GradReducer()
         self.device = torch.device(pipeline.device)
         self._d_stream = None
+        self._g_stream = None  # generator-side discriminator loss, next to VAE + BLIP (head_losses)
         self._d_pending = False
         self._d_keep = None
         self.serial_d = False  # GraphedStep: D step in stream order on the main stream
@@ -142,6 +143,21 @@ class CoMatTrainer:
         """final latents (channels-last tokens, fp32) -> VAE decode -> crop + BLIP caption reward [-> generator-side
         discriminator loss]: TrainableSDPipeline.py:219-223, training_script.py:606-623."""
         cfg = self.cfg
+        # The generator-side discriminator loss needs the final latents and nothing of the decode / caption chain: on a
+        # GPU it runs on its own stream next to VAE + BLIP (both chains are ~1 k latency-bound launches that leave most
+        # of the chip idle), forward and - autograd keeps a node on the stream of its forward - backward.  Same kernels,
+        # same bits (the two latent gradients are added, a + b == b + a); COMAT_G_STREAM=0 restores one stream.
+        fork = (cfg.gan_loss and self.device.type == "cuda" and ops.side_streams_enabled() and not self.serial_d
+                and os.environ.get("COMAT_G_STREAM", "1") != "0")
+        G_loss = None
+        if fork:
+            main = torch.cuda.current_stream(self.device)
+            if self._g_stream is None:
+                self._g_stream = torch.cuda.Stream(device=self.device)
+            self._g_stream.wait_stream(main)
+            with torch.cuda.stream(self._g_stream):
+                G_loss = self.D.D_sd_pipeline_forward(lat, "G", negative_prompt_embeds=batch["gan_null_embeds"],
+                                                      num_inference_steps=cfg.total_step, h=h, w=w)
         img, H, W = self.pipe.decode_tokens(lat, bs, h, w, return_latents=True)
         _dbg("vae")
         self._last_image_hw = (H, W)
@@ -149,7 +165,10 @@ class CoMatTrainer:
                                        label_smoothing=cfg.label_smoothing)
         _dbg("blip")
         o = dict(reward=reward, logp=logp, image=(img, H, W))
-        if cfg.gan_loss:
+        if fork:
+            main.wait_stream(self._g_stream)
+            o["G_loss"] = G_loss
+        elif cfg.gan_loss:
             o["G_loss"] = self.D.D_sd_pipeline_forward(lat, "G", negative_prompt_embeds=batch["gan_null_embeds"],
                                                        num_inference_steps=cfg.total_step, h=h, w=w)
             _dbg("G loss")

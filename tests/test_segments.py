@@ -120,7 +120,7 @@ def test_segmented_step_matches_eager(hip, dtype, attrcon):
     st = SegmentedStep(tr_g)
     run_plan(tr_e, st, batch, dtype, attrcon, torch.equal)
     s = st.stats()
-    assert s["replays"] >= 15, s
+    assert s["replays"] >= 10, s
     assert st.head_seg is not None and st.head_seg.replays == len(PLAN) - 1
     assert st.d_seg is None and st.head_seg.side_out is not None  # the D step lives inside the head's backward graph
 
