@@ -18,6 +18,7 @@
 //   flash_dkdv  : block = 4 waves x 32 keys, loops over 32-query tiles; dV^T += dO^T P, dK^T += Q^T dS
 #include "common.h"
 #include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -171,6 +172,43 @@ template <typename T> __device__ __forceinline__ typename FragOf<T>::type pack_a
     __builtin_memcpy(&out, &v, 16);
     return out;
 }
+// ---- k-major bf16 fragments through the hardware transpose read (ds_read_b64_tr_b16, gfx950) ------------------------------
+// The k-major operand tiles (V in the forward, K in dQ, Q and dO in dK/dV) are stored as they come from memory - rows =
+// keys / queries, head dim contiguous - and the MFMA A fragment "8 consecutive k of head-dim row n" is exactly what the
+// transpose read hands out (semantics probed on gfx950: tools/probes/tr_read_probe.hip): inside a
+// 16-lane group, lane 4k'+q supplies the address of 4 consecutive elements (columns 4q..4q+3) of row k', and lane i
+// receives column i of those 4 rows.  With rows = tile rows (the contraction index) and columns = head-dim indices, two
+// reads give lane (r, hh) the tile rows 16j + 4hh + {0..3} and 16j + 8 + 4hh + {0..3} of head-dim column n = 32 t2 + r:
+// the accumulator order crow() that pack_acc() uses for the other operand.  No transposed LDS image (rounds 1-2 built one
+// with 8 two-byte LDS writes per 16-byte chunk), no gathers: every head dim takes this path.
+// The compiler does not count asm loads (cdna_hip_programming.md 5.7, form ii): all reads of a phase are issued first,
+// then every fragment passes through a wait statement that names its registers before the MFMA consumes it.
+struct TrF {
+    unsigned long long lo, hi;
+};
+__device__ __forceinline__ unsigned lds_addr32(const char* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF> __device__ __forceinline__ void tr_read(unsigned long long& d, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF) : "memory");
+}
+// per-lane part of the address: row 4 hh + k' of the k-step, columns 16 * (second 16-lane group) + 4 q
+template <int RS> __device__ __forceinline__ unsigned tr_lane_off(int lane) {
+    return (unsigned)((4 * (lane >> 5) + ((lane & 15) >> 2)) * RS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
+}
+// the NT32 fragments (32-wide head-dim tiles t2) of k-step J (tile rows 16 J .. 16 J + 15) of one tile
+template <int RS, int J, int... T2>
+__device__ __forceinline__ void tr_issue_j(unsigned addr, TrF* f, std::integer_sequence<int, T2...>) {
+    ((tr_read<J * 16 * RS + T2 * 64>(f[T2].lo, addr), tr_read<J * 16 * RS + T2 * 64 + 8 * RS>(f[T2].hi, addr)), ...);
+}
+__device__ __forceinline__ short8_t tr_take(TrF& f) {  // wait for the LDS queue, then hand the fragment to the MFMA
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo), "+v"(f.hi));
+    short8_t out;
+    __builtin_memcpy(&out, &f, 16);
+    return out;
+}
+
 // per-lane fragment (column = this lane's row of the global matrix, chunk 2s+hh of the head dim) straight from HBM
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
 __device__ __forceinline__ void load_col_frags(typename FragOf<T>::type* f, const T* base, int64_t ld, int row,
@@ -206,11 +244,13 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     typedef typename FragOf<T>::type F;
     // LDS: [K tile | V tile (TR: its transposed image)], TWICE when it fits (DB): the next tile is written into the other
     // buffer right after this tile's MFMAs, so a key tile costs ONE block barrier instead of two
-    constexpr int ONE = G::TILE_BYTES + (TR ? G::TT_BYTES : G::TILE_BYTES);
+    constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain tile
+    constexpr bool SWT = TR && !HW;            // fp32: software-built transposed image
+    constexpr int ONE = G::TILE_BYTES + (SWT ? G::TT_BYTES : G::TILE_BYTES);
     constexpr bool DB = 2 * ONE <= 65536;
     __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Kt = smem;
-    char* Vt = smem + G::TILE_BYTES;  // TR: the transposed image of the V tile
+    char* Vt = smem + G::TILE_BYTES;  // SWT: the transposed image of the V tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
@@ -234,9 +274,10 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     km.load(Kb, a.ldk, 0, a.Nk, a.d);
     vm.load(Vb, a.ldv, 0, a.Nk, a.d);
     km.store(Kt);
-    if (TR) vm.store_t(Vt);
+    if (SWT) vm.store_t(Vt);
     else vm.store(Vt);
     __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
         if (more) {
@@ -279,11 +320,25 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
         }
         l += ps;
         m = m_new;
+        if constexpr (HW) {
+            const unsigned va = lds_addr32(Vt) + tr_off;
+            auto step = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                TrF vf[G::NT32];
+                tr_issue_j<G::RS, j>(va, vf, std::make_integer_sequence<int, G::NT32>{});
+                const F pb = pack_acc<T>(st, j);
 #pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            const F pb = pack_acc<T>(st, j);
+                for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[t2]), pb);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+        } else {
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], TR ? frag_km_t<T, DMAX>(Vt, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
+            for (int j = 0; j < G::NJ; ++j) {
+                const F pb = pack_acc<T>(st, j);
+#pragma unroll
+                for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], SWT ? frag_km_t<T, DMAX>(Vt, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Vt, t2 * 32 + r, j, hh), pb);
+            }
         }
         if (DB) {
             // the other buffer was last read in iteration t-1, which every wave left through the barrier below
@@ -294,7 +349,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
         }
         if (more) {
             km.store(Kt);
-            if (TR) vm.store_t(Vt);
+            if (SWT) vm.store_t(Vt);
             else vm.store(Vt);
         }
         if (DB || more) __syncthreads();
@@ -317,7 +372,9 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    constexpr int ONE = 2 * G::TILE_BYTES + (TR ? G::TT_BYTES : 0);
+    constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain K tile
+    constexpr bool SWT = TR && !HW;
+    constexpr int ONE = 2 * G::TILE_BYTES + (SWT ? G::TT_BYTES : 0);
     constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per key tile (see flash_fwd_kernel)
     __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Kt = smem;
@@ -367,9 +424,10 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     km.load(Kb, a.ldk, 0, a.Nk, a.d);
     vm.load(Vb, a.ldv, 0, a.Nk, a.d);
     km.store(Kt);
-    if (TR) km.store_t(KtT);
+    if (SWT) km.store_t(KtT);
     vm.store(Vt);
     __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = 0; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
         if (more) {
@@ -394,11 +452,25 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
             for (int i = 0; i < 16; ++i)
                 if (t * 32 + crow(i, hh) >= a.Nk) st[i] = 0.f;
         }
+        if constexpr (HW) {
+            const unsigned ka = lds_addr32(Kt) + tr_off;
+            auto step = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                TrF kfr[G::NT32];
+                tr_issue_j<G::RS, j>(ka, kfr, std::make_integer_sequence<int, G::NT32>{});
+                const F db = pack_acc<T>(st, j);
 #pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            const F db = pack_acc<T>(st, j);
+                for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[t2]), db);
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+        } else {
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], TR ? frag_km_t<T, DMAX>(KtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
+            for (int j = 0; j < G::NJ; ++j) {
+                const F db = pack_acc<T>(st, j);
+#pragma unroll
+                for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], SWT ? frag_km_t<T, DMAX>(KtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Kt, t2 * 32 + r, j, hh), db);
+            }
         }
         if (DB) {
             Kt = smem + ((t + 1) & 1) * ONE;
@@ -409,7 +481,7 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
         }
         if (more) {
             km.store(Kt);
-            if (TR) km.store_t(KtT);
+            if (SWT) km.store_t(KtT);
             vm.store(Vt);
         }
         if (DB || more) __syncthreads();
@@ -430,7 +502,9 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
-    constexpr int ONE = 2 * G::TILE_BYTES + 256 + (TR ? 2 * G::TT_BYTES : 0);
+    constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain Q / dO tiles
+    constexpr bool SWT = TR && !HW;
+    constexpr int ONE = 2 * G::TILE_BYTES + 256 + (SWT ? 2 * G::TT_BYTES : 0);
     constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per query tile (see flash_fwd_kernel)
     __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Qt = smem;
@@ -476,12 +550,13 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     }
     qm.store(Qt);
     gm.store(Gt);
-    if (TR) {
+    if (SWT) {
         qm.store_t(QtT);
         gm.store_t(GtT);
     }
     if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
     __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = tbeg; t < ntiles; ++t) {
         const bool more = t + 1 < ntiles;
         if (more) {
@@ -510,14 +585,33 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
             sc[i] = p;
             dp[i] = p * a.scale * (dp[i] - D_s[qr]);
         }
+        if constexpr (HW) {
+            const unsigned qa = lds_addr32(Qt) + tr_off, ga = lds_addr32(Gt) + tr_off;
+            auto step = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                TrF gfr[G::NT32], qfr[G::NT32];
+                tr_issue_j<G::RS, j>(ga, gfr, std::make_integer_sequence<int, G::NT32>{});
+                tr_issue_j<G::RS, j>(qa, qfr, std::make_integer_sequence<int, G::NT32>{});
+                const F pb = pack_acc<T>(sc, j);
+                const F db = pack_acc<T>(dp, j);
 #pragma unroll
-        for (int j = 0; j < G::NJ; ++j) {
-            const F pb = pack_acc<T>(sc, j);
-            const F db = pack_acc<T>(dp, j);
+                for (int t2 = 0; t2 < G::NT32; ++t2) {
+                    mma(dvT[t2], tr_take(gfr[t2]), pb);
+                    mma(dkT[t2], tr_take(qfr[t2]), db);
+                }
+            };
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1>{});
+        } else {
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) {
-                mma(dvT[t2], TR ? frag_km_t<T, DMAX>(GtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Gt, t2 * 32 + r, j, hh), pb);
-                mma(dkT[t2], TR ? frag_km_t<T, DMAX>(QtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
+            for (int j = 0; j < G::NJ; ++j) {
+                const F pb = pack_acc<T>(sc, j);
+                const F db = pack_acc<T>(dp, j);
+#pragma unroll
+                for (int t2 = 0; t2 < G::NT32; ++t2) {
+                    mma(dvT[t2], SWT ? frag_km_t<T, DMAX>(GtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Gt, t2 * 32 + r, j, hh), pb);
+                    mma(dkT[t2], SWT ? frag_km_t<T, DMAX>(QtT, t2 * 32 + r, j, hh) : frag_km<T, DMAX>(Qt, t2 * 32 + r, j, hh), db);
+                }
             }
         }
         if (DB) {
@@ -533,7 +627,7 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
         if (more) {
             qm.store(Qt);
             gm.store(Gt);
-            if (TR) {
+            if (SWT) {
                 qm.store_t(QtT);
                 gm.store_t(GtT);
             }
@@ -633,7 +727,9 @@ template <typename T> int dispatch(const FlashArgs& a, bool bwd, hipStream_t st)
     // flash_tr: 0 never, 2 always, 1 (default) by head dim: building the transposed image costs 8 scalar LDS writes per
     // 16-byte chunk, which pays off for d <= 64 only (profiles/r02_h_mb_flash.txt: d = 80 backward 133 vs 144 us,
     // d = 160 81 vs 92 us without it; d = 40 441 vs 474 us with it)
-    if (tr_v == 2 || (tr_v == 1 && a.d <= 64)) return dispatch_tr<T, true>(a, bwd, trim_v == 1, st);
+    // (round 3) bf16: TR = hardware transpose reads straight from the plain tiles (no transposed image to build), which pays
+    // for every head dim; the head-dim rule above still governs the software image of the fp32 parity mode
+    if (tr_v == 2 || (tr_v == 1 && (a.d <= 64 || sizeof(T) == 2))) return dispatch_tr<T, true>(a, bwd, trim_v == 1, st);
     return dispatch_tr<T, false>(a, bwd, trim_v == 1, st);
 }
 
