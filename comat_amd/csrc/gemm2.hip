@@ -47,6 +47,8 @@ struct Args2 {
     Seg2 seg[MAXSEG2];
     int nseg;
     int Hin, Win, Cin, Hout, Wout, KW, stride, pad, ups;  // conv only (seg[0].A = X, seg[0].B = W, ldb = K)
+    int zins;  // conv, ups == 2: the upsampling INSERTS ZEROS (only even coordinates hold samples): the data-gradient of a
+               // stride-2 conv as a stride-1 gather over the zero-stuffed output gradient (comat_conv2d mode 1)
     int64_t M, N;
     int nkt;  // k-tiles in total
     int tiles_m, tiles_n, splits;
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 int sy = by[i] + ky, sx = bx[i] + kx;
-                const bool ok = rv[i] && (unsigned)sy < (unsigned)lim_y && (unsigned)sx < (unsigned)lim_x;
+                bool ok = rv[i] && (unsigned)sy < (unsigned)lim_y && (unsigned)sx < (unsigned)lim_x;
+                if (g.zins) ok = ok && !((sy | sx) & 1);
                 if (g.ups == 2) {
                     sy >>= 1;
                     sx >>= 1;
@@ -1230,7 +1233,11 @@ int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segmen
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
     const bool fp8 = p->in_dtype == COMAT_FP8_E4M3;
     const int eb = fp8 ? 1 : 2, ke = RB / eb;
-    if ((!g2_enabled() && !fp8) || (p->in_dtype != COMAT_BF16 && !fp8) || p->mode != 0 || p->Cin % ke) return 0;
+    // mode 1 (transposed gather) with stride 2 = the data-gradient of the UNet's downsamplers: three of four taps fall
+    // between samples, but the zero-stuffed form runs on THIS kernel (3/4 of its MFMA work is on zeros and it is still 3x
+    // faster than the register-staged kernel's 35 TFLOP/s: profiles/r02_l_bench_shapes.txt, 100 us per call)
+    const bool zins = p->mode == 1 && p->stride == 2 && p->ups == 1 && !fp8 && comat_option(COMAT_OPT_GEMM2) != 0;
+    if ((!g2_enabled() && !fp8) || (p->in_dtype != COMAT_BF16 && !fp8) || (p->mode != 0 && !zins) || p->Cin % ke) return 0;
     if (!al16(p->X) || !al16(p->W)) return 0;
     const int64_t M = (int64_t)p->B * p->Hout * p->Wout;
     const int64_t K = (int64_t)p->KH * p->KW * p->Cin;
@@ -1245,6 +1252,12 @@ int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
     a.nkt = a.seg[0].nkt;
     a.Hin = p->Hin; a.Win = p->Win; a.Cin = p->Cin; a.Hout = p->Hout; a.Wout = p->Wout;
     a.KW = p->KW; a.stride = p->stride; a.pad = p->pad; a.ups = p->ups;
+    if (zins) {  // src = (dst + k - pad) / 2 where divisible  ==  stride-1 gather over the 2x zero-stuffed input
+        if (p->Hout > 2 * p->Hin || p->Wout > 2 * p->Win) return 0;
+        a.stride = 1;
+        a.ups = 2;
+        a.zins = 1;
+    }
     a.M = M; a.N = p->Cout;
     a.sC = a.sR = a.sBias = 0;
     a.ep.C = p->Y; a.ep.bias = p->bias; a.ep.bias2 = p->bias2; a.ep.R = p->R;

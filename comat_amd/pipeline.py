@@ -141,6 +141,8 @@ class TrainableSDPipeline:
         tmin = min(training_timesteps) if training_timesteps else 0
         places = sorted({s.split("_")[0] for s in train_layer_ls})
         self.attn_dict = {}
+        if self.graphed is not None:
+            self.graphed.new_sampler_call()  # this call's context / LoRA factors: its text keys / values are projected once
         # text key / value projections shared by the denoise steps of this call (see UNet.__call__)
         kv_cache = {} if (self.share_text_kv and self.trained_runner is None) else None
         wanted = {(s_.split("_")[0], int(s_.split("_")[1])) for s_ in train_layer_ls}

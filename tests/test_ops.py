@@ -103,6 +103,8 @@ CONV_CASES = [
     (1, 8, 8, 32, 16, 3, 1, 1, 2),     # Upsample2D: nearest 2x fused
     (2, 10, 10, 24, 136, 1, 1, 0, 1),  # 1x1
     (1, 24, 24, 64, 132, 3, 1, 1, 1),  # several k-tiles / n-tiles
+    (2, 16, 16, 32, 64, 3, 2, 1, 1),   # Downsample2D whose dgrad runs on the pipelined kernel (zero-stuffed stride-1 gather)
+    (1, 15, 17, 32, 32, 3, 2, 1, 1),   # ... odd sizes: the last source row / column lies beyond the stuffed image
 ]
 
 
@@ -134,6 +136,31 @@ def test_conv2d_fwd_bwd(dev, dtype, case):
     check(y, tok(yref), dtype, "conv fwd")
     check(xd.grad, tok(xr.grad), dtype, "conv dgrad")
     check(rd.grad, tok(rr.grad), dtype, "conv residual grad")
+
+
+@pytest.mark.gpu
+def test_strided_conv_dgrad_runs_on_the_pipelined_kernel(hip):
+    """comat_conv2d mode 1 (transposed gather), stride 2, bf16, Cin % 32 == 0: served by gemm2_kernel's zero-insertion
+    gather, bit-identical in value to the register-staged kernel's result up to fp32 summation order"""
+    from comat_amd import _hip
+    dtype = torch.bfloat16
+    B_, H, W, Cin, Cout = 2, 32, 32, 64, 96
+    w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=1.0 / math.sqrt(Cin * 9))
+    conv = ops.FrozenConv(w, None, dtype, hip, stride=2, pad=1)
+    g = dv(rnd(B_ * 16 * 16, Cout, dtype=dtype, seed=3), hip, dtype)
+    k = ops.kernels()
+    outs = []
+    for use in (1, 0):
+        _hip.set_option("gemm2", use)
+        dx = torch.empty(B_ * H * W, Cin, dtype=dtype, device=hip)
+        k.conv2d(g, conv.wd, dx, B_, 16, 16, Cout, H, W, Cin, 3, 3, 2, 1, mode=1)
+        assert _hip.last_gemm_kernel() == (1 if use else 0)
+        outs.append(dx.float())
+    _hip.set_option("gemm2", 1)
+    assert rel_l2(outs[0], outs[1]) < 1e-2  # two bf16 roundings of fp32 sums taken in different orders
+    gy = g.float().cpu().reshape(B_, 16, 16, Cout).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(gy, w, stride=2, padding=1, output_padding=1)
+    check(outs[0].cpu().reshape(B_, H, W, Cin).permute(0, 3, 1, 2), ref, dtype, "strided dgrad", factor=2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
