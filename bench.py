@@ -576,8 +576,8 @@ def main():
     #   segments - the trained UNet calls, the head and the discriminator step replayed from per-piece graphs behind the eager
     #              sampler loop / loss assembly / exchange / optimizer (comat_amd.segments.SegmentedStep): ANY configuration,
     #              ANY number of ranks, the same path on 1 and on 8 GPUs (no collective is ever captured).
-    #   auto     - segments everywhere; on one GPU with a static topology the whole-step graph is probed against it (3 steps
-    #              each) and the faster one is timed.  Every decision is agreed across ranks, so collectives stay matched.
+    #   auto     - segments everywhere; with a static topology the whole-step graph is probed against it (3 steps each) and
+    #              the faster one is timed.  Every decision is agreed across ranks, so collectives stay matched.
     stepper, graph_note = None, "eager launches"
     mode = os.environ.get("COMAT_STEP_MODE") or {"1": "graph", "0": "eager"}.get(os.environ.get("COMAT_STEP_GRAPH", ""), "auto")
     probe_ms = {}
@@ -623,11 +623,11 @@ def main():
 
     static_topology = not scfg.attrcon and "training_steps" in fixed
     seg_stepper = graph_stepper = None
-    if not args.selftest and mode in ("auto", "segments"):
+    if mode in ("auto", "segments"):
         from comat_amd.segments import SegmentedStep
 
         def make_segments():
-            st = SegmentedStep(trainer)
+            st = SegmentedStep(trainer, dry=args.selftest)  # selftest: the same hooks, segments run eagerly (no GPU)
             for kw in precapture_plan(scfg, fixed):  # real optimisation steps that visit every (slot, variant) once
                 st(batch, **kw)
             st(batch, **fixed)
@@ -638,7 +638,11 @@ def main():
             stepper, graph_note = seg_stepper, "segments: trained UNet calls, head and D step replayed from hipGraphs"
         else:
             graph_note = f"eager launches (segment capture failed: {err})"
-    if not args.selftest and static_topology and (mode == "graph" or (mode == "auto" and world == 1)):
+        if args.selftest and seg_stepper is not None:
+            graph_note = "SELFTEST: segment hooks run eagerly on the CPU simulator"
+    # (more than one rank: GraphedStep captures forward + backward only, the exchange and the optimizer follow eagerly - the
+    # same split as the segments, so no collective is captured in either form)
+    if not args.selftest and static_topology and mode in ("graph", "auto"):
         from comat_amd.step import GraphedStep
 
         def make_graph():
@@ -655,7 +659,8 @@ def main():
         probe_ms["segments"] = probe(lambda: seg_stepper(batch, **fixed)) * 1e3
         probe_ms["graph"] = probe(lambda: graph_stepper(batch, **fixed)) * 1e3
         if probe_ms["graph"] < probe_ms["segments"]:
-            stepper, graph_note = graph_stepper, "whole step replayed from one hipGraph"
+            stepper, graph_note = graph_stepper, ("whole step replayed from one hipGraph" if not graph_stepper.split() else
+                                                  "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")
         graph_note += f" (probe: segments {probe_ms['segments']:.0f} ms, whole-step graph {probe_ms['graph']:.0f} ms)"
     eager_ms = None
     if not args.selftest and world == 1 and static_topology and os.environ.get("COMAT_PROBE_EAGER", "1") != "0":
@@ -708,7 +713,7 @@ def main():
     value = world * args.steps / dt  # one image (prompt) per rank per step
 
     pieces = None
-    if seg_stepper is not None and world == 1 and not args.no_kernel_timing:
+    if seg_stepper is not None and world == 1 and not args.no_kernel_timing and not args.selftest:
         # where a step goes on the GPU: HIP events around every segment replay of two more steps (segments mode)
         seg_stepper.set_timing(True)
         for _ in range(2):

@@ -440,6 +440,7 @@ class LoRAStore:
                 k.unary(UN_COPY, self.flat, self.flat_c, self.flat.numel())
             k.transpose_cast_tiles(self.flat, self.flat_t, self._tiles)
             self._fresh = True
+            self.epoch = getattr(self, "epoch", 0) + 1  # consumers that cache products of the copies compare this
             for ent in self._merged.values():  # merged inference weights that exist follow the parameters
                 self._merge_into(ent)
 

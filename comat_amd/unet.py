@@ -368,8 +368,9 @@ class GraphedUNetForward:
     read from the bank's flat compute copy at replay time, so optimizer updates are seen without re-capture.
     The cross-attention key / value projections of the text context are the same for every denoise step of a sampler call
     (same context, same LoRA factors): they live in ONE more graph that is replayed once per sampler call
-    (`new_sampler_call()` marks the boundary) and writes fixed-address tensors the per-timestep graphs read - 2 launches
-    per cross-attention layer and step less (SD1.5: 32 of ~700, SDXL: 140 of ~2 000)."""
+    (`new_sampler_call()` marks the boundary: CALL IT whenever the text context changes - the pipeline does at the start
+    of every `forward`; an update of the LoRA factors is noticed by itself) and writes fixed-address tensors the
+    per-timestep graphs read - 2 launches per cross-attention layer and step less (SD1.5: 32 of ~700, SDXL: 140 of ~2 000)."""
 
     def __init__(self, unet: "UNet"):
         self.unet = unet
@@ -440,6 +441,8 @@ class GraphedUNetForward:
             k.unary(ops.UN_COPY, added, sa, added.numel())
         if self.unet.lora is not None:
             self.unet.lora.ensure_compute_copy()
+            if st.get("lora_epoch") != getattr(self.unet.lora, "epoch", 0):  # the factors changed: so do the projections
+                st["kv_fresh"], st["lora_epoch"] = False, getattr(self.unet.lora, "epoch", 0)
         if not st["kv_fresh"] or st["kv_graph"] is None:
             k.unary(ops.UN_COPY, ctx, sc, ctx.numel())
             if st["kv_graph"] is not None:

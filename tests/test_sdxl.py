@@ -121,6 +121,7 @@ def test_sdxl_graphed_nograd_unet_matches_eager(hip):
             aug = unet.added_embedding(pooled, time_ids)
             ref, _ = unet(x, B, h, w, 334, ctx, L, added=aug)
             ref2, _ = unet(x, B, h, w, 334, ctx, L, added=(pooled, time_ids))
+            gu.new_sampler_call()  # a new text context (the pipeline says so at the start of every forward)
             got = gu(x, B, h, w, 334, ctx, L, added=aug).clone()
         assert torch.equal(ref, ref2), "precomputed added embedding == tuple form"
         assert torch.equal(got, ref), f"iteration {it}: graph replay != eager"
