@@ -412,8 +412,9 @@ def cpu_baseline(usd, scfg):
 def load_pmc_summary():
     """HBM traffic / MFMA-busy figures of the dominant kernel from the committed counter pass (separate rocprofv3 --pmc
     runs of tools/pmc_targets.py, converted by tools/pmc_to_json.py).  Counters cannot be collected inside a timed run."""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
-    if not os.path.exists(p):
+    p = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_kernels.json", "r02_pmc_kernels.json"))
+              if os.path.exists(q)), None)
+    if p is None:
         return None
     with open(p) as f:
         d = json.load(f)
@@ -757,7 +758,7 @@ def main():
             "achieved": f_dom / t_dom / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": f_dom / t_dom / 1e12 / PEAK_BF16_TFLOPS,
             "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
-            "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r02_pmc_kernels.json)",
+            "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r03_pmc_kernels.json)",
             "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
             "algorithmic_bytes_per_launch": int(b_dom / n_dom),
             "launches_per_step": n_dom, "avg_launch_ms": t_dom / n_dom * 1e3,

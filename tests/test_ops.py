@@ -49,7 +49,7 @@ def dv(x, dev, dtype=None, grad=False):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("transA", [False, True])
 @pytest.mark.parametrize("transB", [False, True])
-@pytest.mark.parametrize("shape", [(150, 77, 93), (256, 320, 128), (33, 500, 40), (300, 200, 264)])
+@pytest.mark.parametrize("shape", [(150, 77, 93), (256, 320, 128), (33, 500, 40), (300, 200, 264), (16, 768, 768), (20, 72, 64)])
 def test_gemm_layouts(dev, dtype, transA, transB, shape):
     M, N, K = shape
     A = rnd(M, K, dtype=dtype, seed=1)

@@ -1,0 +1,37 @@
+#!/bin/bash
+# round 3, final GPU calls: the whole GPU suite + smoke, the default bench line (with cpu_baseline and the C3 secondary),
+# the kernel trace and the counter passes behind the roofline block, the bf16 gradient-norm report, C5
+#   bash tools/calls/r3_final.sh [tests|bench|trace|pmc|shrink|c5 ...]   (default: all)
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp HIP_FORCE_DEV_KERNARG=1
+O=gpurun_out
+mkdir -p $O
+WHAT="${*:-tests bench trace pmc shrink c5}"
+for w in $WHAT; do case $w in
+tests)
+  echo "== GPU suite"; COMAT_TEST_REPORT=$O/r3z_bf16_errors.txt timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/r3z_test_all.log 2>&1; tail -4 $O/r3z_test_all.log
+  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+bench)
+  echo "== bench default"; COMAT_BENCH_DUMP=$O/r3z_bench_shapes.txt timeout 1500 python bench.py > $O/r3z_bench_default.log 2>&1; tail -c 12000 $O/r3z_bench_default.log | grep -o '"ms_per_step": [0-9.]*\|"value": [0-9.e-]*\|"launch_mode": "[^"]*"\|"probe_ms_per_step": {[^}]*}\|"eager_ms_per_step": [0-9.]*\|"cores": [0-9]*' | head -14 ;;
+trace)
+  echo "== kernel trace (eager C2, 3 steps)"
+  (cd /tmp && COMAT_STEP_MODE=eager COMAT_PROBE_EAGER=0 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 0 --no-cpu-baseline --no-kernel-timing > "$GRAFT_REPO_ROOT/$O/r3z_bench_traced.log" 2>&1)
+  python tools/rocpd_summary.py $(find /tmp/kt -name "*_results.db" | head -1) 3 > $O/r3z_kernel_trace_eager.txt 2>&1; head -24 $O/r3z_kernel_trace_eager.txt | cut -c1-150 ;;
+pmc)
+  echo "== pmc step passes"
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $pass | cut -c1-5 | tr -d ' ')
+    (cd /tmp && COMAT_STEP_MODE=eager COMAT_PROBE_EAGER=0 timeout 300 rocprofv3 --pmc $pass -d /tmp/pmc_step_$tag -o s -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > "$GRAFT_REPO_ROOT/$O/r3z_pmc_step_$tag.log" 2>&1)
+  done
+  echo "== pmc targets"
+  for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $pass | cut -c1-5 | tr -d ' ')
+    (cd /tmp && timeout 150 rocprofv3 --pmc $pass -d /tmp/pmc_tgt_$tag -o t -- python "$GRAFT_REPO_ROOT/tools/pmc_targets.py" > "$GRAFT_REPO_ROOT/$O/r3z_pmc_tgt_$tag.log" 2>&1)
+  done
+  python tools/pmc_to_json.py $(find /tmp/pmc_tgt_* -name "*_results.db") --step $(find /tmp/pmc_step_* -name "*_results.db") > $O/r3z_pmc_kernels.json 2> $O/r3z_pmc_to_json.err; tail -c 700 $O/r3z_pmc_kernels.json; tail -3 $O/r3z_pmc_to_json.err ;;
+shrink)
+  echo "== bf16 gradient-norm report (C1 full size)"; timeout 400 python tools/grad_shrink_report.py > $O/r3z_grad_shrink.txt 2>&1; tail -40 $O/r3z_grad_shrink.txt ;;
+c5)
+  echo "== bench c5"; timeout 1500 python bench.py --config c5 --no-cpu-baseline --no-kernel-timing > $O/r3z_bench_c5.log 2>&1; grep -o '"ms_per_step": [0-9.]*\|"launch_mode": "[^"]*"' $O/r3z_bench_c5.log ;;
+esac; done
+echo done

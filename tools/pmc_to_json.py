@@ -1,6 +1,6 @@
-"""rocprofv3 --pmc passes (rocpd databases) of tools/pmc_targets.py -> profiles/r02_pmc_kernels.json.
+"""rocprofv3 --pmc passes (rocpd databases) of tools/pmc_targets.py -> profiles/r03_pmc_kernels.json.
 
-    python tools/pmc_to_json.py fetch_results.db write_results.db busy_results.db > profiles/r02_pmc_kernels.json
+    python tools/pmc_to_json.py fetch_results.db write_results.db busy_results.db [--step step_*.db] > profiles/r03_pmc_kernels.json
 
 Per kernel: average duration, HBM-side bytes per launch (FETCH_SIZE is in KiB and, on gfx950, counts a wide coalesced read
 stream at half its bytes: x 2 as MI355X_MICROARCH.md prescribes; WRITE_SIZE in KiB, uncorrected), MFMA busy share =
@@ -144,7 +144,7 @@ def main():
                 "mfma_busy_frac": dom.get("mfma_busy_frac"), "launches_in_pass": dom["launches"],
                 "note": "HBM-side bytes per gemm2_kernel launch averaged over every launch of whole eager C2 steps under "
                         "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate passes; "
-                        "tools/r2_call7.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE calibrated on a known stream"}
+                        "tools/calls/r3_final.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE calibrated on a known stream"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
