@@ -86,6 +86,33 @@ def capture_stream(dev):
     return st
 
 
+class graph_capture:
+    """`torch.cuda.graph(g, pool=..., stream=...)` with Python's cyclic garbage collector switched off for the duration of
+    the capture.  torch collects garbage BEFORE the capture begins; a collection that the allocation counters trigger in the
+    MIDDLE of it runs finalizers of whatever became unreachable - an old CUDAGraph, a stream, pool memory of a finished
+    test or stepper - and those release HIP objects while a stream is capturing: the capture is invalidated at best (the
+    replay then faults), the process aborts at worst (both seen on MI355X, round 3).  Captures are short; the collector
+    is switched back on (to its previous state) at the end."""
+
+    def __init__(self, graph, pool=None, stream=None, **kw):
+        self._ctx = torch.cuda.graph(graph, pool=pool, stream=stream, **kw)
+
+    def __enter__(self):
+        import gc
+        self._gc_was_on = gc.isenabled()
+        r = self._ctx.__enter__()  # synchronises, collects garbage, empties the cache, begins the capture
+        gc.disable()
+        return r
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            if self._gc_was_on:
+                gc.enable()
+
+
 def reset_capture_stream(dev):
     """after a FAILED capture: the capture stream (and streams forked from it) may be left in capture mode by the runtime -
     forget it, the next capture_stream() call makes a fresh one"""

@@ -89,7 +89,7 @@ class GraphedSegment:
             _copy_into(s, x.detach())
         kw = _capture_kwargs()
         self.fg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fg, pool=self.pool, stream=st, **kw):
+        with ops.graph_capture(self.fg, pool=self.pool, stream=st, **kw):
             outs = self.fn(*self.si)
         outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
         self.out_req = [bool(o.requires_grad) for o in outs]
@@ -97,7 +97,7 @@ class GraphedSegment:
         self.sgi = [None] * len(self.si)
         if any(self.out_req):
             self.bg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bg, pool=self.pool, stream=st, **kw):
+            with ops.graph_capture(self.bg, pool=self.pool, stream=st, **kw):
                 if bwd_side is not None:
                     side_fn, side_st = bwd_side
                     side_st.wait_stream(torch.cuda.current_stream(dev))

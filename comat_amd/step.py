@@ -434,7 +434,7 @@ class GraphedStep:
                 cap = ops.capture_stream(tr.device)
                 if tr._d_stream is not None:
                     ops.prepare_capture_stream(tr.device, tr._d_stream)
-                with torch.cuda.graph(g, pool=self.pool, stream=cap, **mode):
+                with ops.graph_capture(g, pool=self.pool, stream=cap, **mode):
                     if split:
                         out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
                     else:

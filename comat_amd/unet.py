@@ -409,7 +409,7 @@ class GraphedUNetForward:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
                     kv = {}
-                    with torch.cuda.graph(g, pool=self.pool, stream=ops.capture_stream(u.device), **self._capture_kwargs()):
+                    with ops.graph_capture(g, pool=self.pool, stream=ops.capture_stream(u.device), **self._capture_kwargs()):
                         u.project_text_kv(sc, kv)
                     if self.pool is None:
                         self.pool = g.pool()
@@ -429,7 +429,7 @@ class GraphedUNetForward:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # the package's capture stream: its workspaces exist (zeroed) before any capture begins
-                with torch.cuda.graph(g, pool=self.pool, stream=ops.capture_stream(u.device), **self._capture_kwargs()):
+                with ops.graph_capture(g, pool=self.pool, stream=ops.capture_stream(u.device), **self._capture_kwargs()):
                     out, _ = u(sx, B, H, W, t, sc, L, added=sa, kv_cache=st["kv"])
                 if self.pool is None:
                     self.pool = g.pool()

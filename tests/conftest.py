@@ -29,6 +29,23 @@ def _use_hip():
     return torch.device("cuda:0")
 
 
+def _reset_stream_state():
+    """a test owns its kernel backend instance (and with it every per-stream workspace): drop the package-level stream
+    state that refers to the previous test's - the capture stream (a test that failed inside a capture leaves it in capture
+    mode), queued weight gradients, side-stream bookkeeping"""
+    from comat_amd import ops
+    if torch.cuda.is_available():
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001 - a pending error of the test that just failed
+            pass
+        ops.reset_capture_stream(torch.device("cuda:0"))
+    ops._ttq.clear()
+    ops._side_dirty.clear()
+    ops._side_keep.clear()
+    ops._join_queued = False
+
+
 @pytest.fixture(params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
 def dev(request):
     """Device + kernel backend: 'sim' = CPU simulator of the C ABI (host-logic check, runs anywhere),
@@ -36,6 +53,7 @@ def dev(request):
     d = _use_sim() if request.param == "sim" else _use_hip()
     yield d
     from comat_amd import ops
+    _reset_stream_state()
     ops.set_kernel_backend(None)
 
 
@@ -52,4 +70,5 @@ def hip():
     d = _use_hip()
     yield d
     from comat_amd import ops
+    _reset_stream_state()
     ops.set_kernel_backend(None)
