@@ -331,8 +331,8 @@ def cpu_baseline(usd, scfg):
     are absent) on a BOUNDED sample of the same workload, per SURVEY.md 8d: one UNet call without grad and one with
     grad (LoRA + input gradients) at the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens), one BLIP
     reward forward + backward at 510^2 -> 384^2, one VAE decode forward + backward on a 32x32 latent (a quarter of the
-    pixels; x4).  Each component: 1 warm-up + 3 timed repetitions, median.  Threads: all host threads or 64 of them,
-    whichever runs the no-grad UNet call faster on this box (both are reported).  The step time is the medians combined by
+    pixels; x4).  Each component: 1 warm-up + 3 timed repetitions, median, on min(host threads, 64) threads (see below).
+    The step time is the medians combined by
     the step's call counts (the discriminator is the same UNet: G side batch 1 = half a trained call, D side batch 2 = one
     trained call)."""
     from comat_amd import config, weights
@@ -361,12 +361,12 @@ def cpu_baseline(usd, scfg):
         with torch.no_grad():
             O.unet_forward(usd, ocfg, x, 801, ctx, None, None)
 
-    by_threads = {}
-    for th in sorted({cores, min(cores, 64)}, reverse=True):
-        torch.set_num_threads(th)
-        by_threads[th] = timed(nograd)
-    threads = min(by_threads, key=lambda th: by_threads[th][0])
+    # Threads: at most 64.  On the 256-thread host of an MI355X box the same call takes 158.8 s with all 256 threads against
+    # 4.9 s with 64 (measured in round 3, profiles/r03_z_bench_default.log: oversubscribed fork-join of many small ops) -
+    # timing that again in every run would cost ten minutes for a number nobody would quote; COMAT_CPU_THREADS overrides.
+    threads = int(os.environ.get("COMAT_CPU_THREADS", min(cores, 64)))
     torch.set_num_threads(threads)
+    by_threads = {threads: timed(nograd)}
     t["unet_nograd"], reps_all["unet_nograd"] = by_threads[threads]
 
     def train():
@@ -401,8 +401,7 @@ def cpu_baseline(usd, scfg):
               + t["blip_train"] + (1.5 * t["unet_train"] if scfg.gan_loss else 0.0))
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"oracle/ (CPU fp32) components, median of 3 repetitions after a warm-up, on {threads} of {cores} host "
-                      "threads (no-grad UNet call: " + ", ".join(f"{v[0]:.1f} s on {k} threads" for k, v in by_threads.items())
-                      + "): " + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
+                      "threads (all 256 threads of an MI355X host measured 32x slower in round 3): " + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
                       + f"; step = {scfg.K} x unet_train + {scfg.total_step - scfg.K} x unet_nograd + 4 x vae_quarter_train + "
                       f"blip_train + 1.5 x unet_train (discriminator G and D sides) = {step_s:.0f} s",
             "components_s": {k: round(v, 2) for k, v in t.items()},

@@ -224,7 +224,10 @@ static bool gn_try_one(const void* x, const void* dy, const float* gamma, const 
     // small (8x8 and 16x16 levels: 5.8 vs 10.7 us, 10.0 vs 15.0 us) and lose where the tensor needs the whole chip's
     // bandwidth (64x64 x 320: 28 vs 14 us) - so the one-launch form serves HW <= 256, and whatever the vectorised form
     // cannot take at all (`must`).
-    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) != 3 || HW > 256)) return false;
+    // The backward form holds two tensors per thread and gains less: 16x16 x 1 280 channels 13.8 -> 16.6 us (a loss), x 2 560
+    // 21.4 -> 14.4 us, 8x8 13.5 -> 7.4 us - it serves HW <= 64, and HW <= 256 from 1 920 channels on.
+    const bool pays = MODE == 0 ? HW <= 256 : (HW <= 64 || (HW <= 256 && C >= 1920));
+    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) != 3 || !pays)) return false;
     const int cpg = C / G;
     if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
     if (dtype == COMAT_F32) {
