@@ -250,6 +250,11 @@ class CoMatTrainer:
         results are bit-identical to the serial order (no atomics anywhere); COMAT_D_STREAM=0 restores it."""
         cfg = self.cfg
         ops.reset_side_stream_state()
+        if self._d_pending and self.device.type == "cuda":
+            # a previous step raised between the D fork and the join in _apply_updates: its D kernels may still read
+            # buffers this step is about to reuse - join before anything else is queued
+            torch.cuda.current_stream(self.device).wait_stream(self._d_stream)
+            self._d_pending, self._d_keep = False, None
         self.bank.set_requires_grad(True)
         self.bank.zero_grad()
         out = self.compute_losses(batch, **fixed)
@@ -266,6 +271,7 @@ class CoMatTrainer:
             # the D stream reads the final latents: they stay referenced until that stream has been joined
             # (_apply_updates), so the allocator cannot hand their memory to main-stream work in the meantime
             self._d_keep = out["training_latents"]
+            self._d_pending = True  # from here on the D stream holds work that must be joined, whatever happens below
             with torch.cuda.stream(self._d_stream):
                 if self.flat_d:
                     with ops.no_side_streams():
