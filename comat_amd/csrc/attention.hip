@@ -367,6 +367,128 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     }
 }
 
+// Forward with TWO 32-key tiles per iteration (bf16, hardware transpose reads; option flash_kt = 2): one block barrier, one
+// running-max update and one rescale decision per 64 keys, and the two score tiles are independent MFMA chains whose
+// results the softmax of the other can overlap.  Same arithmetic per score as flash_fwd_kernel; the running maximum moves
+// at 64-key granularity, so results agree with the 32-key kernel to rounding, not bit for bit.
+template <int DMAX, int NK>
+__global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
+    typedef bf16_t T;
+    typedef Geo<T, DMAX> G;
+    typedef short8_t F;
+    constexpr int ONE = 2 * G::TILE_BYTES;  // [K tile | V tile] of one 32-key tile
+    constexpr int PAIR = 2 * ONE;
+    static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
+    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
+    char* cur = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    F qf[NK];
+    load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    f32x16_t oT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oT[t][i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float c2 = a.scale * LOG2E;
+    TileMover<T, DMAX> km0, vm0, km1, vm1;
+    const int npairs = (a.Nk + 63) / 64;
+    auto load_pair = [&](int p) {  // rows beyond Nk come back as zeros (TileMover), their scores are masked below
+        km0.load(Kb, a.ldk, p * 64, a.Nk, a.d);
+        vm0.load(Vb, a.ldv, p * 64, a.Nk, a.d);
+        km1.load(Kb, a.ldk, p * 64 + 32, a.Nk, a.d);
+        vm1.load(Vb, a.ldv, p * 64 + 32, a.Nk, a.d);
+    };
+    auto store_pair = [&](char* dst) {
+        km0.store(dst);
+        vm0.store(dst + G::TILE_BYTES);
+        km1.store(dst + ONE);
+        vm1.store(dst + ONE + G::TILE_BYTES);
+    };
+    load_pair(0);
+    store_pair(cur);
+    __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
+    for (int p = 0; p < npairs; ++p) {
+        const bool more = p + 1 < npairs;
+        if (more) load_pair(p + 1);
+        f32x16_t s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            mma(s0, frag_kc<T, DMAX>(cur, r, s, hh), qf[s]);
+            mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
+        }
+        if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (p * 64 + crow(i, hh) >= a.Nk) s0[i] = -INFINITY;
+                if (p * 64 + 32 + crow(i, hh) >= a.Nk) s1[i] = -INFINITY;
+            }
+        }
+        float mt = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
+        mt = half_max(mt);
+        const float m_new = fmaxf(m, mt);
+        const float neg = -m_new * c2;
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p0 = exp2_fast(__builtin_fmaf(s0[i], c2, neg));
+            const float p1 = exp2_fast(__builtin_fmaf(s1[i], c2, neg));
+            s0[i] = p0;
+            s1[i] = p1;
+            ps += p0 + p1;
+        }
+        ps = half_sum(ps);
+        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
+            const float alpha = exp2_fast((m - m_new) * c2);
+            l *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oT[t2][i] *= alpha;
+        }
+        l += ps;
+        m = m_new;
+        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        auto step = [&](auto jc, unsigned va, const f32x16_t& st) {
+            constexpr int j = decltype(jc)::value;
+            TrF vf[G::NT32];
+            tr_issue_j<G::RS, j>(va, vf, std::make_integer_sequence<int, G::NT32>{});
+            const F pb = pack_acc<T>(st, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[t2]), pb);
+        };
+        step(std::integral_constant<int, 0>{}, va0, s0);
+        step(std::integral_constant<int, 1>{}, va0, s0);
+        step(std::integral_constant<int, 0>{}, va1, s1);
+        step(std::integral_constant<int, 1>{}, va1, s1);
+        cur = smem + ((p + 1) & 1) * PAIR;  // last read in iteration p-1, which every wave left through the barrier below
+        if (more) store_pair(cur);
+        __syncthreads();
+    }
+    if (q < a.Nq) {
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
+            }
+        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * a.scale + __logf(l);
+    }
+}
+
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
@@ -659,6 +781,272 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     }
 }
 
+// ---- backward with TWO 32-row tiles per iteration (bf16, hardware transpose reads; option flash_kt = 2) ---------------------
+// As flash_fwd2_kernel: half the block barriers, and four independent MFMA chains (scores and dP of two tiles) whose
+// element-wise work overlaps.  Same arithmetic per element as the 32-row kernels (no running state here: the statistics
+// come from the forward), so dQ / dK / dV differ from theirs only in the order the two tiles' MFMA products are added.
+template <int DMAX, int NK>
+__global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
+    typedef bf16_t T;
+    typedef Geo<T, DMAX> G;
+    typedef short8_t F;
+    constexpr int ONE = 2 * G::TILE_BYTES;  // [K tile | V tile]
+    constexpr int PAIR = 2 * ONE;
+    static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
+    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
+    char* cur = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    T* dQb = (T*)a.dQ + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    F qf[NK], gf[NK];
+    load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
+    load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
+    const float lse_q = (q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f) * LOG2E;
+    float D_q;
+    {  // D[q] = sum_d dO[q, d] O[q, d] (fixed order), stored for the dK/dV pass - as in flash_dq_kernel
+        const T* Ob = (const T*)a.O + (int64_t)b * a.Nq * a.ldo + h * a.d;
+        F of[NK];
+        load_col_frags<T, DMAX, NK>(of, Ob, a.ldo, q, a.Nq, a.d, hh);
+        float part = 0.f;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            V16 gv, ov;
+            __builtin_memcpy(&gv, &gf[s], 16);
+            __builtin_memcpy(&ov, &of[s], 16);
+#pragma unroll
+            for (int e = 0; e < G::KC; ++e) part += bf16_to_f32(gv.h[e]) * bf16_to_f32(ov.h[e]);
+        }
+        D_q = half_sum(part);
+        if (q < a.Nq && hh == 0) a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] = D_q;
+    }
+    const float c2 = a.scale * LOG2E;
+    f32x16_t dqT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dqT[t][i] = 0.f;
+    TileMover<T, DMAX> km0, vm0, km1, vm1;
+    const int npairs = (a.Nk + 63) / 64;
+    auto load_pair = [&](int p) {
+        km0.load(Kb, a.ldk, p * 64, a.Nk, a.d);
+        vm0.load(Vb, a.ldv, p * 64, a.Nk, a.d);
+        km1.load(Kb, a.ldk, p * 64 + 32, a.Nk, a.d);
+        vm1.load(Vb, a.ldv, p * 64 + 32, a.Nk, a.d);
+    };
+    auto store_pair = [&](char* dst) {
+        km0.store(dst);
+        vm0.store(dst + G::TILE_BYTES);
+        km1.store(dst + ONE);
+        vm1.store(dst + ONE + G::TILE_BYTES);
+    };
+    load_pair(0);
+    store_pair(cur);
+    __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
+    for (int p = 0; p < npairs; ++p) {
+        const bool more = p + 1 < npairs;
+        if (more) load_pair(p + 1);
+        f32x16_t s0, d0, s1, d1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; d0[i] = 0.f; s1[i] = 0.f; d1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            mma(s0, frag_kc<T, DMAX>(cur, r, s, hh), qf[s]);
+            mma(d0, frag_kc<T, DMAX>(cur + G::TILE_BYTES, r, s, hh), gf[s]);
+            mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
+            mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), gf[s]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p0 = exp2_fast(__builtin_fmaf(s0[i], c2, -lse_q));
+            const float p1 = exp2_fast(__builtin_fmaf(s1[i], c2, -lse_q));
+            s0[i] = p0 * a.scale * (d0[i] - D_q);
+            s1[i] = p1 * a.scale * (d1[i] - D_q);
+        }
+        if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (p * 64 + crow(i, hh) >= a.Nk) s0[i] = 0.f;
+                if (p * 64 + 32 + crow(i, hh) >= a.Nk) s1[i] = 0.f;
+            }
+        }
+        const unsigned ka0 = lds_addr32(cur) + tr_off, ka1 = lds_addr32(cur + ONE) + tr_off;
+        auto step = [&](auto jc, unsigned ka, const f32x16_t& ds) {
+            constexpr int j = decltype(jc)::value;
+            TrF kfr[G::NT32];
+            tr_issue_j<G::RS, j>(ka, kfr, std::make_integer_sequence<int, G::NT32>{});
+            const F db = pack_acc<T>(ds, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[t2]), db);
+        };
+        step(std::integral_constant<int, 0>{}, ka0, s0);
+        step(std::integral_constant<int, 1>{}, ka0, s0);
+        step(std::integral_constant<int, 0>{}, ka1, s1);
+        step(std::integral_constant<int, 1>{}, ka1, s1);
+        cur = smem + ((p + 1) & 1) * PAIR;
+        if (more) store_pair(cur);
+        __syncthreads();
+    }
+    if (q < a.Nq) {
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, dqT[t2][i]);
+            }
+    }
+}
+
+template <int DMAX, int NK>
+__global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
+    typedef bf16_t T;
+    typedef Geo<T, DMAX> G;
+    typedef short8_t F;
+    constexpr int ONE = 2 * G::TILE_BYTES + 256;  // [Q tile | dO tile | lse (32 floats) | D (32 floats)] of one 32-query tile
+    constexpr int PAIR = 2 * ONE;
+    static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
+    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
+    char* cur = smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
+    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    T* dKb = (T*)a.dK + (int64_t)b * a.Nk * a.ldk + h * a.d;
+    T* dVb = (T*)a.dV + (int64_t)b * a.Nk * a.ldv + h * a.d;
+    const int key = blockIdx.x * 128 + wave * 32 + r;
+    F kf[NK], vf[NK];
+    load_col_frags<T, DMAX, NK>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
+    load_col_frags<T, DMAX, NK>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
+    f32x16_t dkT[G::NT32], dvT[G::NT32];
+#pragma unroll
+    for (int t = 0; t < G::NT32; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dkT[t][i] = 0.f; dvT[t][i] = 0.f; }
+    const float* lse_g = a.lse + (int64_t)blockIdx.y * a.Nq;
+    const float* D_g = a.Dbuf + (int64_t)blockIdx.y * a.Nq;
+    TileMover<T, DMAX> qm0, gm0, qm1, gm1;
+    // query-tile range [tbeg, tend) of this block (gridDim.z ranges, see flash_dkdv_kernel), walked two tiles at a time; a
+    // second tile at or beyond `tend` belongs to the next range (or to nobody): its probabilities are forced to zero
+    const int ntq = (a.Nq + 31) / 32;
+    const int per = (ntq + a.qsplit - 1) / a.qsplit;
+    const int tbeg = (int)blockIdx.z * per;
+    const int tend = tbeg + per < ntq ? tbeg + per : ntq;
+    const float c2 = a.scale * LOG2E;
+    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..63: queries of the pair (lse in log2 units)
+    auto load_pair = [&](int t) {
+        qm0.load(Qb, a.ldq, t * 32, a.Nq, a.d);
+        gm0.load(Gb, a.ldo, t * 32, a.Nq, a.d);
+        qm1.load(Qb, a.ldq, t * 32 + 32, a.Nq, a.d);
+        gm1.load(Gb, a.ldo, t * 32 + 32, a.Nq, a.d);
+        if (threadIdx.x < 64) {
+            const int qi = t * 32 + threadIdx.x;
+            lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
+            D_r = qi < a.Nq ? D_g[qi] : 0.f;
+        }
+    };
+    auto store_pair = [&](char* dst) {
+        qm0.store(dst);
+        gm0.store(dst + G::TILE_BYTES);
+        qm1.store(dst + ONE);
+        gm1.store(dst + ONE + G::TILE_BYTES);
+        if (threadIdx.x < 64) {
+            float* st = (float*)(dst + (threadIdx.x >> 5) * ONE + 2 * G::TILE_BYTES);
+            st[threadIdx.x & 31] = lse_r;
+            st[32 + (threadIdx.x & 31)] = D_r;
+        }
+    };
+    if (tbeg < tend) {
+        load_pair(tbeg);
+        store_pair(cur);
+    }
+    __syncthreads();
+    const unsigned tr_off = tr_lane_off<G::RS>(lane);
+    for (int t = tbeg; t < tend; t += 2) {
+        const bool more = t + 2 < tend;
+        if (more) load_pair(t + 2);
+        const bool has1 = t + 1 < tend;
+        f32x16_t c0, d0, c1, d1;  // [query rows x key cols]
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c0[i] = 0.f; d0[i] = 0.f; c1[i] = 0.f; d1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            mma(c0, frag_kc<T, DMAX>(cur, r, s, hh), kf[s]);
+            mma(d0, frag_kc<T, DMAX>(cur + G::TILE_BYTES, r, s, hh), vf[s]);
+            mma(c1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), kf[s]);
+            mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), vf[s]);
+        }
+        const float* st0 = (const float*)(cur + 2 * G::TILE_BYTES);
+        const float* st1 = (const float*)(cur + ONE + 2 * G::TILE_BYTES);
+        const bool edge = (t + 2) * 32 > a.Nq || key >= a.Nk || !has1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qr = crow(i, hh);
+            float p0 = exp2_fast(__builtin_fmaf(c0[i], c2, -st0[qr]));
+            float p1 = exp2_fast(__builtin_fmaf(c1[i], c2, -st1[qr]));
+            if (edge) {
+                if (!((t * 32 + qr < a.Nq) && (key < a.Nk))) p0 = 0.f;
+                if (!(has1 && ((t + 1) * 32 + qr < a.Nq) && (key < a.Nk))) p1 = 0.f;
+            }
+            c0[i] = p0;
+            c1[i] = p1;
+            d0[i] = p0 * a.scale * (d0[i] - st0[32 + qr]);
+            d1[i] = p1 * a.scale * (d1[i] - st1[32 + qr]);
+        }
+        const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
+        const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        auto step = [&](auto jc, unsigned qa, unsigned ga, const f32x16_t& pr, const f32x16_t& ds) {
+            constexpr int j = decltype(jc)::value;
+            TrF gfr[G::NT32], qfr[G::NT32];
+            tr_issue_j<G::RS, j>(ga, gfr, std::make_integer_sequence<int, G::NT32>{});
+            tr_issue_j<G::RS, j>(qa, qfr, std::make_integer_sequence<int, G::NT32>{});
+            const F pb = pack_acc<T>(pr, j);
+            const F db = pack_acc<T>(ds, j);
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2) {
+                mma(dvT[t2], tr_take(gfr[t2]), pb);
+                mma(dkT[t2], tr_take(qfr[t2]), db);
+            }
+        };
+        step(std::integral_constant<int, 0>{}, qa0, ga0, c0, d0);
+        step(std::integral_constant<int, 1>{}, qa0, ga0, c0, d0);
+        step(std::integral_constant<int, 0>{}, qa1, ga1, c1, d1);
+        step(std::integral_constant<int, 1>{}, qa1, ga1, c1, d1);
+        cur = smem + (((t - tbeg) / 2 + 1) & 1) * PAIR;
+        if (more) store_pair(cur);
+        __syncthreads();
+    }
+    if (key < a.Nk) {
+        const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
+        float* pk = a.qsplit > 1
+                        ? a.part + ((int64_t)blockIdx.z * a.B * a.H + blockIdx.y) * a.Nk * a.d + (int64_t)key * a.d
+                        : nullptr;
+        float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
+#pragma unroll
+        for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int n = t2 * 32 + crow(i, hh);
+                if (n < a.d) {
+                    if (a.qsplit > 1) {
+                        pk[n] = dkT[t2][i];
+                        pv[n] = dvT[t2][i];
+                    } else {
+                        stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
+                        stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
+                    }
+                }
+            }
+    }
+}
+
 // dK / dV = sum over the query ranges of the fp32 partials, in range order (bit-reproducible)
 template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kernel(FlashArgs a) {
     const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
@@ -679,12 +1067,31 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kern
 
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_fwd(const FlashArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES <= 65536) {
+        if (comat_option(COMAT_OPT_FLASH_KT) >= 2 && a.Nk > 64) {  // two key tiles per iteration
+            hipLaunchKernelGGL((flash_fwd2_kernel<DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((flash_fwd_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_bwd(const FlashArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-    hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    // option flash_kt: 1 = one 32-row tile per iteration everywhere, 2 = two in the forward, 3 = + dQ, 4 = + dK/dV
+    if constexpr (sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES + 1024 <= 65536) {
+        const int kt = comat_option(COMAT_OPT_FLASH_KT);
+        if (kt >= 3 && a.Nk > 64)
+            hipLaunchKernelGGL((flash_dq2_kernel<DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+        else
+            hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+        if (kt >= 4 && a.Nq > 64)
+            hipLaunchKernelGGL((flash_dkdv2_kernel<DMAX, NK>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+        else
+            hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
+        hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    }
     if (a.qsplit > 1) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
         hipLaunchKernelGGL((flash_kv_reduce_kernel<T>), dim3((unsigned)cdiv64(slab, NT)), dim3(NT), 0, st, a);

@@ -748,7 +748,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, norm_fused=3)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=3, norm_fused=3)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -959,6 +959,7 @@ def test_flash_trim_is_bit_identical(hip, dtype, cfg, default_opts):
     q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
     g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
     res = []
+    _set_opts(flash_kt=1)  # the one-tile kernels: the two-tile ones (flash_kt >= 2) add their products in another order
     for trim, tr in ((0, 0), (1, 0), (0, 2), (1, 2), (1, 1)):  # tr: 0 never, 2 always, 1 by head dim (the default)
         _set_opts(flash_trim=trim, flash_tr=tr)
         qd, kd, vd = (dv(t, hip, dtype, grad=True) for t in (q, k_, v))
@@ -968,6 +969,81 @@ def test_flash_trim_is_bit_identical(hip, dtype, cfg, default_opts):
     for i, variant in enumerate(res[1:], 1):
         for a, b, name in zip(res[0], variant, ("O", "dQ", "dK", "dV")):
             assert torch.equal(a, b), f"variant {i}: {name} differs from the default kernels"
+
+
+@pytest.mark.gpu
+def test_workspaces_are_created_before_a_capture_not_inside_it(hip):
+    """A split-K workspace carries ticket counters that must be zero before their first use.  Created inside a capture it
+    would be zeroed by a node of that one graph: a SECOND graph captured on the same stream and replayed first would run on
+    whatever the memory holds.  So creation during a capture raises, `prepare_stream()` creates the workspaces
+    eagerly, and then two graphs captured on one stream give the right result in either replay order."""
+    from comat_amd import _hip
+    k = _hip.HipKernels()
+    dtype = torch.bfloat16
+    M, N, K = 64, 64, 4096  # few tiles, long contraction: split along k (tickets + slabs in the workspace)
+    A, B = dv(rnd(M, K, dtype=dtype, seed=1, scale=0.1), hip, dtype), dv(rnd(N, K, dtype=dtype, seed=2, scale=0.1), hip, dtype)
+    ref = A.float() @ B.float().t()
+    st = torch.cuda.Stream()
+    g0 = torch.cuda.CUDAGraph()
+    C0 = torch.empty(M, N, device=hip)
+    with pytest.raises(RuntimeError, match="must exist before the capture"):
+        with torch.cuda.graph(g0, stream=st):
+            k.gemm(A, B, C0, M, N, K, K, K, N)
+    st2 = torch.cuda.Stream()  # (the failed capture may have left `st` in capture mode)
+    with torch.cuda.stream(st2):
+        assert k.prepare_stream(hip) and not k.prepare_stream(hip)  # created once, idempotent
+    torch.cuda.synchronize()
+    graphs, outs = [], []
+    for _ in range(2):
+        g, C = torch.cuda.CUDAGraph(), torch.full((M, N), float("nan"), device=hip)
+        with torch.cuda.graph(g, stream=st2):
+            k.gemm(A, B, C, M, N, K, K, K, N)
+        graphs.append(g)
+        outs.append(C)
+    for i in (1, 0, 1):  # the graph captured SECOND replays first
+        outs[i].fill_(float("nan"))
+        graphs[i].replay()
+        torch.cuda.synchronize()
+        check(outs[i], ref.cpu(), torch.float32, f"graph {i}", factor=50)  # bf16 products, fp32 sums: ~1e-2 of the scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 1024, 1024, 8, 40), (1, 300, 200, 8, 80), (2, 70, 130, 2, 40), (1, 577, 577, 3, 64),
+                                 (1, 130, 65, 1, 48), (2, 1024, 77, 8, 80), (1, 96, 4096, 2, 40), (1, 4096, 100, 2, 40)])
+def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
+    """option flash_kt = 4 (2: forward only, 3: + dQ): the bf16 fused attention kernels with two 32-row tiles per iteration (one barrier per 64 keys /
+    queries; forward: one rescale decision per 64 keys) against the one-tile kernels - same arithmetic per element, other
+    summation order / max granularity: equal to bf16 rounding (log-sum-exp to fp32 rounding) - and against a materialised
+    fp32 reference.  Ragged tile counts (a masked second tile), the query-split dK/dV path (77 keys) included."""
+    dtype = torch.bfloat16
+    B, Nq, Nk, H, d = cfg
+    q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
+    g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
+    K = ops.kernels()
+    outs = []
+    for kt in (1, 4):
+        _set_opts(flash_kt=kt)
+        qd, kd, vd, gd = (dv(t, hip, dtype) for t in (q, k_, v, g))
+        o = torch.empty_like(qd)
+        lse, dbuf = torch.empty(B, H, Nq, device=hip), torch.empty(B, H, Nq, device=hip)
+        HD = H * d
+        K.flash_attn_fwd(qd, kd, vd, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        dq, dk, dvv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+        K.flash_attn_bwd(qd, kd, vd, o, gd, lse, dbuf, dq, dk, dvv, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        outs.append((o.float(), lse.clone(), dq.float(), dk.float(), dvv.float()))
+    for i, name in ((0, "O"), (2, "dQ"), (3, "dK"), (4, "dV")):
+        assert rel_l2(outs[1][i], outs[0][i]) < 6e-3, f"{name}: two-tile kernels differ from the one-tile kernels by {rel_l2(outs[1][i], outs[0][i]):.2e}"
+    assert (outs[1][1] - outs[0][1]).abs().max() < 1e-4 * (1 + outs[0][1].abs().max())
+    qr = q.reshape(B, Nq, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    kr = k_.reshape(B, Nk, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    vr = v.reshape(B, Nk, H, d).permute(0, 2, 1, 3).clone().requires_grad_(True)
+    ref = (torch.softmax(qr @ kr.transpose(-1, -2) * d ** -0.5, -1) @ vr).permute(0, 2, 1, 3).reshape(B * Nq, H * d)
+    ref.backward(g)
+    back = lambda t, n: t.grad.permute(0, 2, 1, 3).reshape(B * n, H * d)
+    check(outs[1][0], ref, dtype, "flash forward, two tiles per iteration")
+    check(outs[1][2], back(qr, Nq), dtype, "flash dQ, two tiles per iteration", factor=3)
+    check(outs[1][3], back(kr, Nk), dtype, "flash dK, two tiles per iteration", factor=3)
+    check(outs[1][4], back(vr, Nk), dtype, "flash dV, two tiles per iteration", factor=3)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
