@@ -57,7 +57,9 @@ def grounding_loss_by_layer(masks_res: torch.Tensor, word_token_idx_ls, res, att
         token_loss = token_loss + (((1.0 - act) ** 2) * inv_len).sum()
         avg_sum = avg if avg_sum is None else avg_sum + avg
     token_loss = token_loss / n_obj
-    word = onehot.t() @ (avg_sum / len(attn_maps))  # [n_obj, npix]: tokens of one object are summed
+    # [n_obj, npix]: the tokens of one object are summed - a masked reduction over <= a handful of tokens, in a fixed
+    # order (no vendor GEMM on the path, no atomics)
+    word = (onehot.t()[:, :, None] * (avg_sum / len(attn_maps))[None]).sum(1)
     pixel_loss = F.binary_cross_entropy(word, masks_res, reduction="none").mean(1).sum() / n_obj
     return token_loss, pixel_loss
 

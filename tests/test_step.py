@@ -141,7 +141,7 @@ def test_train_step_matches_oracle(dev, dtype, attrcon):
 def test_cm_only_step_matches_oracle(dev, dtype):
     """BASELINE config C1's loss set in miniature: concept matching alone (--gan_loss off, no attribute concentration):
     the step loss is minus the BLIP caption reward, there is no discriminator pass, no D update, and the discriminator's
-    parameters stay untouched (reference training_script.py:902-907: the GAN branch is skipped as a whole)."""
+    parameters stay untouched (reference training_script.py:593-600,620-625,670-686: every GAN branch hangs on args.gan_loss)."""
     cfg, batch, W, trainer = make_world(dtype, dev, False, gan=False)
     ts, crop = [0, 2], (0, 1, 63, 63)
     opt = torch.optim.AdamW(list(W["lora"].values()), lr=cfg.lr, betas=(cfg.adam_beta1, cfg.adam_beta2),
