@@ -37,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0  # dense MFMA fp8 (e4m3), same guide: the peak an fp8 kernel family is priced against
 # algorithmic TFLOP per step per prompt: UNet fwd 0.839 (incl. LoRA), VAE 2.515, BLIP 0.408
 F_UNET, F_VAE, F_BLIP = 0.839, 2.515, 0.408
 
@@ -752,10 +753,11 @@ def main():
         total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config in ("c4", "c5"), res=scfg.resolution)
         pmc = load_pmc_summary()
         n_other = sum(rec.other.values())
+        peak_of = lambda family: PEAK_FP8_TFLOPS if "fp8" in family else PEAK_BF16_TFLOPS
         roofline = {
             "bound": "mfma", "kernel": dom,
-            "achieved": f_dom / t_dom / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": f_dom / t_dom / 1e12 / PEAK_BF16_TFLOPS,
+            "achieved": f_dom / t_dom / 1e12, "peak": peak_of(dom), "unit": "TFLOP/s",
+            "frac": f_dom / t_dom / 1e12 / peak_of(dom),
             "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
             "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r03_pmc_kernels.json)",
             "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
@@ -776,6 +778,7 @@ def main():
             "other_launches_per_step": n_other,
             "families": {k: {"ms": round(v[4] * 1e3, 2), "ms_replayed": round(v[0] * 1e3, 2), "tflop": round(v[1] / 1e12, 3),
                              "launches": v[2], "TFLOP/s": round(v[1] / v[4] / 1e12, 1),
+                             "frac_of_peak": round(v[1] / v[4] / 1e12 / peak_of(k), 4),
                              "TFLOP/s_replayed": round(v[1] / v[0] / 1e12, 1)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][4])},
         }

@@ -9,10 +9,10 @@ mkdir -p $O
 WHAT="${*:-tests bench trace pmc shrink c5}"
 for w in $WHAT; do case $w in
 tests)
-  echo "== GPU suite"; COMAT_TEST_REPORT=$O/r3z_bf16_errors.txt timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/r3z_test_all.log 2>&1; tail -4 $O/r3z_test_all.log
+  echo "== GPU suite"; COMAT_TEST_REPORT=$O/r3z_bf16_errors.txt timeout 480 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/r3z_test_all.log 2>&1; tail -4 $O/r3z_test_all.log
   echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
 bench)
-  echo "== bench default"; COMAT_BENCH_DUMP=$O/r3z_bench_shapes.txt timeout 1500 python bench.py > $O/r3z_bench_default.log 2>&1; tail -c 12000 $O/r3z_bench_default.log | grep -o '"ms_per_step": [0-9.]*\|"value": [0-9.e-]*\|"launch_mode": "[^"]*"\|"probe_ms_per_step": {[^}]*}\|"eager_ms_per_step": [0-9.]*\|"cores": [0-9]*' | head -14 ;;
+  echo "== bench default"; COMAT_BENCH_DUMP=$O/r3z_bench_shapes.txt timeout 420 python bench.py > $O/r3z_bench_default.log 2>&1; tail -c 12000 $O/r3z_bench_default.log | grep -o '"ms_per_step": [0-9.]*\|"value": [0-9.e-]*\|"launch_mode": "[^"]*"\|"probe_ms_per_step": {[^}]*}\|"eager_ms_per_step": [0-9.]*\|"cores": [0-9]*' | head -14 ;;
 trace)
   echo "== kernel trace (eager C2, 3 steps)"
   (cd /tmp && COMAT_STEP_MODE=eager COMAT_PROBE_EAGER=0 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 0 --no-cpu-baseline --no-kernel-timing > "$GRAFT_REPO_ROOT/$O/r3z_bench_traced.log" 2>&1)
@@ -32,6 +32,6 @@ pmc)
 shrink)
   echo "== bf16 gradient-norm report (C1 full size)"; timeout 400 python tools/grad_shrink_report.py > $O/r3z_grad_shrink.txt 2>&1; tail -40 $O/r3z_grad_shrink.txt ;;
 c5)
-  echo "== bench c5"; timeout 1500 python bench.py --config c5 --no-cpu-baseline --no-kernel-timing > $O/r3z_bench_c5.log 2>&1; grep -o '"ms_per_step": [0-9.]*\|"launch_mode": "[^"]*"' $O/r3z_bench_c5.log ;;
+  echo "== bench c5 (with the per-kernel roofline block)"; COMAT_BENCH_DUMP=$O/r3z_bench_c5_shapes.txt timeout 420 python bench.py --config c5 --no-cpu-baseline > $O/r3z_bench_c5.log 2>&1; grep -o '"ms_per_step": [0-9.]*\|"launch_mode": "[^"]*"' $O/r3z_bench_c5.log ;;
 esac; done
 echo done
