@@ -78,6 +78,19 @@ template <typename T, int DMAX> struct Geo {
     static constexpr int TT_BYTES = DMAX * TRS;
 };
 
+// static LDS bytes of the backward bodies (flash_dq_body / flash_dkdv_body and their two-tile forms): the kernels that run one
+// body, and the kernel that runs either (flash_bwd_kernel), size their buffer from here
+template <typename T, int DMAX, bool TR> struct BwdLds {
+    typedef Geo<T, DMAX> G;
+    static constexpr bool SWT = TR && sizeof(T) != 2;  // software-transposed tile images (fp32 parity mode)
+    static constexpr int DQ_ONE = 2 * G::TILE_BYTES + (SWT ? G::TT_BYTES : 0);
+    static constexpr int DQ = 2 * DQ_ONE <= 65536 ? 2 * DQ_ONE : DQ_ONE;
+    static constexpr int DKDV_ONE = 2 * G::TILE_BYTES + 256 + (SWT ? 2 * G::TT_BYTES : 0);
+    static constexpr int DKDV = 2 * DKDV_ONE <= 65536 ? 2 * DKDV_ONE : DKDV_ONE;
+    static constexpr int DQ2 = 8 * G::TILE_BYTES;            // two double-buffered [K | V] tile pairs
+    static constexpr int DKDV2 = 8 * G::TILE_BYTES + 1024;   // two double-buffered [Q | dO | lse | D] tile pairs
+};
+
 // cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
 template <typename T, int DMAX> struct TileMover {
     typedef Geo<T, DMAX> G;
@@ -490,30 +503,29 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
 }
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
-template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false, bool WRITE_D = true>
+__device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, int bx, int by) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain K tile
     constexpr bool SWT = TR && !HW;
     constexpr int ONE = 2 * G::TILE_BYTES + (SWT ? G::TT_BYTES : 0);
     constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per key tile (see flash_fwd_kernel)
-    __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Kt = smem;
     char* Vt = smem + G::TILE_BYTES;
     char* KtT = smem + 2 * G::TILE_BYTES;  // TR: transposed image of the K tile (for dQ^T += K^T dS^T)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
     T* dQb = (T*)a.dQ + (int64_t)b * a.Nq * a.ldq + h * a.d;
-    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const int q = bx * 128 + wave * 32 + r;
     F qf[NK], gf[NK];
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
-    const float lse_q = (q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f) * LOG2E;  // log2 units
+    const float lse_q = (q < a.Nq ? a.lse[(int64_t)by * a.Nq + q] : 0.f) * LOG2E;  // log2 units
     // D[q] = sum_d dO[q, d] O[q, d]: the lane already holds its half of row q of dO; O comes in the same fragments.  Fixed
     // order (chunks ascending, then the two halves), written for the dK/dV pass that follows on the stream: the separate
     // "prep" launch of round 1 (260 launches per C2 step) is gone.
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
                 part += sizeof(T) == 2 ? bf16_to_f32(gv.h[e]) * bf16_to_f32(ov.h[e]) : gv.f[e] * ov.f[e];
         }
         D_q = half_sum(part);
-        if (q < a.Nq && hh == 0) a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] = D_q;
+        if (WRITE_D && q < a.Nq && hh == 0) a.Dbuf[(int64_t)by * a.Nq + q] = D_q;
     }
     const float c2 = a.scale * LOG2E;
     f32x16_t dqT[G::NT32];
@@ -618,17 +630,21 @@ __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
             }
     }
 }
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
+__global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DQ];
+    flash_dq_body<T, DMAX, NK, TR>(a, smem, blockIdx.x, blockIdx.y);
+}
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
+__device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, int bx, int by, int bz) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain Q / dO tiles
     constexpr bool SWT = TR && !HW;
     constexpr int ONE = 2 * G::TILE_BYTES + 256 + (SWT ? 2 * G::TT_BYTES : 0);
     constexpr bool DB = 2 * ONE <= 65536;  // double-buffered tiles: one barrier per query tile (see flash_fwd_kernel)
-    __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
     char* Qt = smem;
     char* Gt = smem + G::TILE_BYTES;
     float* lse_s = (float*)(smem + 2 * G::TILE_BYTES);
@@ -636,14 +652,14 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     char* QtT = smem + 2 * G::TILE_BYTES + 256;  // TR: transposed images of the Q and dO tiles (dK^T, dV^T products)
     char* GtT = QtT + G::TT_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
     T* dKb = (T*)a.dK + (int64_t)b * a.Nk * a.ldk + h * a.d;
     T* dVb = (T*)a.dV + (int64_t)b * a.Nk * a.ldv + h * a.d;
-    const int key = blockIdx.x * 128 + wave * 32 + r;
+    const int key = bx * 128 + wave * 32 + r;
     F kf[NK], vf[NK];
     load_col_frags<T, DMAX, NK>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
     load_col_frags<T, DMAX, NK>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
@@ -652,14 +668,14 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     for (int t = 0; t < G::NT32; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkT[t][i] = 0.f; dvT[t][i] = 0.f; }
-    const float* lse_g = a.lse + (int64_t)blockIdx.y * a.Nq;
-    const float* D_g = a.Dbuf + (int64_t)blockIdx.y * a.Nq;
+    const float* lse_g = a.lse + (int64_t)by * a.Nq;
+    const float* D_g = a.Dbuf + (int64_t)by * a.Nq;
     TileMover<T, DMAX> qm, gm;
     // query-tile range of this block: few keys (cross-attention: 77) leave one block per (batch, head), so the
     // query loop is cut into gridDim.z ranges whose partial sums a fixed-order reduce kernel adds up
     const int ntq = (a.Nq + 31) / 32;
     const int per = (ntq + a.qsplit - 1) / a.qsplit;
-    const int tbeg = (int)blockIdx.z * per;
+    const int tbeg = bz * per;
     const int ntiles = tbeg + per < ntq ? tbeg + per : ntq;
     float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31 (lse in log2 units)
     const float c2 = a.scale * LOG2E;
@@ -760,7 +776,7 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     if (key < a.Nk) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
         float* pk = a.qsplit > 1
-                        ? a.part + ((int64_t)blockIdx.z * a.B * a.H + blockIdx.y) * a.Nk * a.d + (int64_t)key * a.d
+                        ? a.part + ((int64_t)bz * a.B * a.H + by) * a.Nk * a.d + (int64_t)key * a.d
                         : nullptr;
         float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
 #pragma unroll
@@ -780,33 +796,37 @@ __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
             }
     }
 }
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
+__global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DKDV];
+    flash_dkdv_body<T, DMAX, NK, TR>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // ---- backward with TWO 32-row tiles per iteration (bf16, hardware transpose reads; option flash_kt = 2) ---------------------
 // As flash_fwd2_kernel: half the block barriers, and four independent MFMA chains (scores and dP of two tiles) whose
 // element-wise work overlaps.  Same arithmetic per element as the 32-row kernels (no running state here: the statistics
 // come from the forward), so dQ / dK / dV differ from theirs only in the order the two tiles' MFMA products are added.
-template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
+template <int DMAX, int NK, bool WRITE_D = true>
+__device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, int bx, int by) {
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
     constexpr int ONE = 2 * G::TILE_BYTES;  // [K tile | V tile]
     constexpr int PAIR = 2 * ONE;
     static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
-    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
     char* cur = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
     T* dQb = (T*)a.dQ + (int64_t)b * a.Nq * a.ldq + h * a.d;
-    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const int q = bx * 128 + wave * 32 + r;
     F qf[NK], gf[NK];
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
-    const float lse_q = (q < a.Nq ? a.lse[(int64_t)blockIdx.y * a.Nq + q] : 0.f) * LOG2E;
+    const float lse_q = (q < a.Nq ? a.lse[(int64_t)by * a.Nq + q] : 0.f) * LOG2E;
     float D_q;
     {  // D[q] = sum_d dO[q, d] O[q, d] (fixed order), stored for the dK/dV pass - as in flash_dq_kernel
         const T* Ob = (const T*)a.O + (int64_t)b * a.Nq * a.ldo + h * a.d;
@@ -822,7 +842,7 @@ __global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
             for (int e = 0; e < G::KC; ++e) part += bf16_to_f32(gv.h[e]) * bf16_to_f32(ov.h[e]);
         }
         D_q = half_sum(part);
-        if (q < a.Nq && hh == 0) a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] = D_q;
+        if (WRITE_D && q < a.Nq && hh == 0) a.Dbuf[(int64_t)by * a.Nq + q] = D_q;
     }
     const float c2 = a.scale * LOG2E;
     f32x16_t dqT[G::NT32];
@@ -902,26 +922,30 @@ __global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
             }
     }
 }
+template <int DMAX, int NK>
+__global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DQ2];
+    flash_dq2_body<DMAX, NK>(a, smem, blockIdx.x, blockIdx.y);
+}
 
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
+__device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem, int bx, int by, int bz) {
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
     constexpr int ONE = 2 * G::TILE_BYTES + 256;  // [Q tile | dO tile | lse (32 floats) | D (32 floats)] of one 32-query tile
     constexpr int PAIR = 2 * ONE;
     static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
-    __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
     char* cur = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
     T* dKb = (T*)a.dK + (int64_t)b * a.Nk * a.ldk + h * a.d;
     T* dVb = (T*)a.dV + (int64_t)b * a.Nk * a.ldv + h * a.d;
-    const int key = blockIdx.x * 128 + wave * 32 + r;
+    const int key = bx * 128 + wave * 32 + r;
     F kf[NK], vf[NK];
     load_col_frags<T, DMAX, NK>(kf, Kb, a.ldk, key, a.Nk, a.d, hh);
     load_col_frags<T, DMAX, NK>(vf, Vb, a.ldv, key, a.Nk, a.d, hh);
@@ -930,14 +954,14 @@ __global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
     for (int t = 0; t < G::NT32; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dkT[t][i] = 0.f; dvT[t][i] = 0.f; }
-    const float* lse_g = a.lse + (int64_t)blockIdx.y * a.Nq;
-    const float* D_g = a.Dbuf + (int64_t)blockIdx.y * a.Nq;
+    const float* lse_g = a.lse + (int64_t)by * a.Nq;
+    const float* D_g = a.Dbuf + (int64_t)by * a.Nq;
     TileMover<T, DMAX> qm0, gm0, qm1, gm1;
     // query-tile range [tbeg, tend) of this block (gridDim.z ranges, see flash_dkdv_kernel), walked two tiles at a time; a
     // second tile at or beyond `tend` belongs to the next range (or to nobody): its probabilities are forced to zero
     const int ntq = (a.Nq + 31) / 32;
     const int per = (ntq + a.qsplit - 1) / a.qsplit;
-    const int tbeg = (int)blockIdx.z * per;
+    const int tbeg = bz * per;
     const int tend = tbeg + per < ntq ? tbeg + per : ntq;
     const float c2 = a.scale * LOG2E;
     float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..63: queries of the pair (lse in log2 units)
@@ -1026,7 +1050,7 @@ __global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
     if (key < a.Nk) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;
         float* pk = a.qsplit > 1
-                        ? a.part + ((int64_t)blockIdx.z * a.B * a.H + blockIdx.y) * a.Nk * a.d + (int64_t)key * a.d
+                        ? a.part + ((int64_t)bz * a.B * a.H + by) * a.Nk * a.d + (int64_t)key * a.d
                         : nullptr;
         float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
 #pragma unroll
@@ -1044,6 +1068,60 @@ __global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
                     }
                 }
             }
+    }
+}
+template <int DMAX, int NK>
+__global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DKDV2];
+    flash_dkdv2_body<DMAX, NK>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// D[q] = sum_d dO[q, d] O[q, d] on its own: the prologue of the dQ bodies, statement for statement (same fragments, same
+// order, same bits), for the one-launch backward below whose dK/dV blocks must not wait for its dQ blocks
+template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS>
+__global__ __launch_bounds__(NT) void flash_delta_kernel(FlashArgs a) {
+    typedef Geo<T, DMAX> G;
+    typedef typename FragOf<T>::type F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const T* Gb = (const T*)a.dO + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    const T* Ob = (const T*)a.O + (int64_t)b * a.Nq * a.ldo + h * a.d;
+    const int q = blockIdx.x * 128 + wave * 32 + r;
+    F gf[NK], of[NK];
+    load_col_frags<T, DMAX, NK>(gf, Gb, a.ldo, q, a.Nq, a.d, hh);
+    load_col_frags<T, DMAX, NK>(of, Ob, a.ldo, q, a.Nq, a.d, hh);
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        V16 gv, ov;
+        __builtin_memcpy(&gv, &gf[s], 16);
+        __builtin_memcpy(&ov, &of[s], 16);
+#pragma unroll
+        for (int e = 0; e < G::KC; ++e)
+            part += sizeof(T) == 2 ? bf16_to_f32(gv.h[e]) * bf16_to_f32(ov.h[e]) : gv.f[e] * ov.f[e];
+    }
+    const float D_q = half_sum(part);
+    if (q < a.Nq && hh == 0) a.Dbuf[(int64_t)blockIdx.y * a.Nq + q] = D_q;
+}
+
+// dQ and dK/dV of one attention in ONE launch (option flash_merge): blocks [0, nqb) of the x dimension run the dQ body,
+// the other nkb * qsplit the dK/dV body.  The two passes are independent once D exists (flash_delta_kernel), and at the
+// deep levels of the UNet neither fills the chip on its own (16 x 16 latent, 2 x 8 heads: 32 blocks each on 256 CUs; the
+// 32 x 32 level: 128 each), so run side by side they take max(dQ, dK/dV) instead of the sum.  Same bodies, same bits as the
+// separate kernels.  DQ2: the dQ role walks two key tiles per iteration (flash_dq2_body).
+template <typename T, int DMAX, int NK, bool TR, bool DQ2>
+__global__ __launch_bounds__(NT) void flash_bwd_kernel(FlashArgs a, int nqb, int nkb) {
+    typedef BwdLds<T, DMAX, TR> L;
+    constexpr int LDQ = DQ2 ? L::DQ2 : L::DQ;
+    __shared__ __attribute__((aligned(16))) char smem[LDQ > L::DKDV ? LDQ : L::DKDV];
+    const int bx = blockIdx.x;
+    if (bx >= nqb) {
+        const int k = bx - nqb;
+        flash_dkdv_body<T, DMAX, NK, TR>(a, smem, k % nkb, blockIdx.y, k / nkb);
+    } else if constexpr (DQ2) {
+        flash_dq2_body<DMAX, NK, false>(a, smem, bx, blockIdx.y);
+    } else {
+        flash_dq_body<T, DMAX, NK, TR, false>(a, smem, bx, blockIdx.y);
     }
 }
 
@@ -1078,19 +1156,32 @@ void launch_fwd(const FlashArgs& a, hipStream_t st) {
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_bwd(const FlashArgs& a, hipStream_t st) {
     // option flash_kt: 1 = one 32-row tile per iteration everywhere, 2 = two in the forward, 3 = + dQ, 4 = + dK/dV
-    if constexpr (sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES + 1024 <= 65536) {
-        const int kt = comat_option(COMAT_OPT_FLASH_KT);
-        if (kt >= 3 && a.Nk > 64)
-            hipLaunchKernelGGL((flash_dq2_kernel<DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-        else
-            hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-        if (kt >= 4 && a.Nq > 64)
-            hipLaunchKernelGGL((flash_dkdv2_kernel<DMAX, NK>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
-        else
-            hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+    // option flash_merge: dQ and dK/dV in one launch (flash_bwd_kernel) - 0 never, 1 when the two grids together hold at
+    // most 768 blocks (neither fills 256 CUs x 2 resident blocks alone), 2 always
+    const dim3 gq((a.Nq + 127) / 128, a.B * a.H), gk((a.Nk + 127) / 128, a.B * a.H, a.qsplit);
+    const int kt = comat_option(COMAT_OPT_FLASH_KT), mg = comat_option(COMAT_OPT_FLASH_MERGE);
+    constexpr bool TWO = sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES + 1024 <= 65536;
+    const bool dq2 = TWO && kt >= 3 && a.Nk > 64, dkdv2 = TWO && kt >= 4 && a.Nq > 64;
+    const int64_t blocks = ((int64_t)gq.x + (int64_t)gk.x * gk.z) * gq.y;
+    if (!dkdv2 && (mg == 2 || (mg == 1 && blocks <= 768)) && (int64_t)gq.x + (int64_t)gk.x * gk.z <= 65535) {
+        hipLaunchKernelGGL((flash_delta_kernel<T, DMAX, NK>), gq, dim3(NT), 0, st, a);
+        const dim3 g(gq.x + gk.x * gk.z, gq.y);
+        if constexpr (TWO) {
+            if (dq2) hipLaunchKernelGGL((flash_bwd_kernel<T, DMAX, NK, TR, true>), g, dim3(NT), 0, st, a, (int)gq.x, (int)gk.x);
+            else hipLaunchKernelGGL((flash_bwd_kernel<T, DMAX, NK, TR, false>), g, dim3(NT), 0, st, a, (int)gq.x, (int)gk.x);
+        } else {
+            hipLaunchKernelGGL((flash_bwd_kernel<T, DMAX, NK, TR, false>), g, dim3(NT), 0, st, a, (int)gq.x, (int)gk.x);
+        }
     } else {
-        hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
-        hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), dim3((a.Nk + 127) / 128, a.B * a.H, a.qsplit), dim3(NT), 0, st, a);
+        if constexpr (TWO) {
+            if (dq2) hipLaunchKernelGGL((flash_dq2_kernel<DMAX, NK>), gq, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), gq, dim3(NT), 0, st, a);
+            if (dkdv2) hipLaunchKernelGGL((flash_dkdv2_kernel<DMAX, NK>), gk, dim3(NT), 0, st, a);
+            else hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), gk, dim3(NT), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((flash_dq_kernel<T, DMAX, NK, TR>), gq, dim3(NT), 0, st, a);
+            hipLaunchKernelGGL((flash_dkdv_kernel<T, DMAX, NK, TR>), gk, dim3(NT), 0, st, a);
+        }
     }
     if (a.qsplit > 1) {
         const int64_t slab = (int64_t)a.B * a.H * a.Nk * a.d;

@@ -33,7 +33,7 @@ enum { COMAT_ACT_NONE = 0, COMAT_ACT_SILU = 1, COMAT_ACT_GELU = 2 };
 int comat_abi_version(void);
 const char* comat_last_error(void);
 /* Kernel-selection options for A/B runs, microbenchmarks and the parity tests of every kernel variant: "flash_trim",
- * "flash_tr", "flash_kt", "gemm2", "gemm2_tt", "g2_cfg", "g2_splits", "force_splits", "norm_fused".  Each defaults to the environment variable
+ * "flash_tr", "flash_kt", "flash_merge", "gemm2", "gemm2_tt", "g2_cfg", "g2_splits", "force_splits", "norm_fused".  Each defaults to the environment variable
  * COMAT_<NAME> (read once) or its built-in default.  They select among kernels that compute the same function; results
  * differ at most in floating-point summation order. */
 int comat_set_option(const char* name, int32_t value);

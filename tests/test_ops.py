@@ -748,7 +748,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=3, norm_fused=3)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=3, flash_merge=0, norm_fused=3)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1044,6 +1044,39 @@ def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
     check(outs[1][2], back(qr, Nq), dtype, "flash dQ, two tiles per iteration", factor=3)
     check(outs[1][3], back(kr, Nk), dtype, "flash dK, two tiles per iteration", factor=3)
     check(outs[1][4], back(vr, Nk), dtype, "flash dV, two tiles per iteration", factor=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 256, 256, 8, 160), (2, 1024, 1024, 8, 80), (1, 577, 577, 16, 64), (2, 256, 77, 8, 160),
+                                 (2, 1024, 77, 8, 80), (1, 300, 200, 3, 40), (1, 16, 577, 12, 64), (2, 70, 130, 2, 32),
+                                 (1, 2048, 2048, 2, 40)])
+def test_flash_backward_in_one_launch_is_bit_identical(hip, cfg, dtype, default_opts):
+    """option flash_merge: D = rowsum(dO . O) from its own small kernel, then the dQ blocks and the dK/dV blocks of the
+    attention in ONE launch (side by side on the chip where neither grid fills it) - the same device bodies as the separate
+    kernels, so dQ / dK / dV / D are the same bits; one- and two-tile dQ (flash_kt 1 / 3), the query-split dK/dV path
+    (77 keys), ragged tiles, fp32 parity mode."""
+    B, Nq, Nk, H, d = cfg
+    q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
+    g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
+    K = ops.kernels()
+    HD = H * d
+    qd, kd, vd, gd = (dv(t, hip, dtype) for t in (q, k_, v, g))
+    o = torch.empty_like(qd)
+    lse = torch.empty(B, H, Nq, device=hip)
+    K.flash_attn_fwd(qd, kd, vd, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+    for kt in (1, 3):
+        got = []
+        for merge in (0, 2, 1):
+            _set_opts(flash_kt=kt, flash_merge=merge)
+            dbuf = torch.full((B, H, Nq), float("nan"), device=hip)
+            dq, dk, dvv = torch.full_like(qd, float("nan")), torch.full_like(kd, float("nan")), torch.full_like(vd, float("nan"))
+            K.flash_attn_bwd(qd, kd, vd, o, gd, lse, dbuf, dq, dk, dvv, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+            got.append((dq, dk, dvv, dbuf))
+        for other in got[1:]:
+            for name, a, b in zip(("dQ", "dK", "dV", "D"), got[0], other):
+                assert torch.isfinite(a.float()).all(), f"{name}: not written"
+                assert torch.equal(a, b), f"{name}: one-launch backward differs from the separate kernels (flash_kt={kt})"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -28,11 +28,60 @@ def timeit(fn, n=10):
     return s.elapsed_time(e) / n * 1e3
 
 
+def timeit_graph(fn, n=20):
+    """n launches back to back from a hipGraph (no host gaps): what the call costs inside a replayed step"""
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):  # this stream's workspaces exist before the capture
+        fn()
+        fn()
+    st.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n * 1e3
+
+
+def merge_table(k, dev):
+    """option flash_merge: dQ and dK/dV blocks in one launch (2) against the separate kernels (0), flash_kt at its default"""
+    T = torch.bfloat16
+    print("# backward, dQ + dK/dV in ONE launch (flash_merge = 2) against the separate kernels (0); replayed from a hipGraph")
+    for (B, H, Nq, Nk, d) in SHAPES + [(2, 8, 64, 77, 160), (1, 8, 4096, 4096, 40), (1, 8, 1024, 1024, 80), (1, 8, 256, 256, 160)]:
+        HD = H * d
+        q = torch.randn(B * Nq, HD, device=dev).to(T)
+        kk = torch.randn(B * Nk, HD, device=dev).to(T)
+        v = torch.randn(B * Nk, HD, device=dev).to(T)
+        g = torch.randn(B * Nq, HD, device=dev).to(T)
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, Nq, device=dev)
+        dbuf = torch.empty(B, H, Nq, device=dev)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
+        k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        row = []
+        for mg in (0, 2):
+            _hip.set_option("flash_merge", mg)
+            row.append(timeit_graph(lambda: k.flash_attn_bwd(q, kk, v, o, g, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, HD, HD, HD, HD,
+                                                             d ** -0.5)))
+        blocks = ((Nq + 127) // 128 + (Nk + 127) // 128) * B * H
+        print(f"flash merge B={B} H={H:2d} Nq={Nq:4d} Nk={Nk:4d} d={d:3d}  separate {row[0]:7.1f} us   one launch {row[1]:7.1f} us   "
+              f"({(Nq + 127) // 128 * B * H} dQ blocks + {(Nk + 127) // 128 * B * H} x qsplit dK/dV blocks, {blocks} unsplit)", flush=True)
+    _hip.set_option("flash_merge", 0)
+
+
 def main():
     dev = torch.device("cuda:0")
     k = _hip.HipKernels()
     ops.set_kernel_backend(k)
     T = torch.bfloat16
+    if "merge" in sys.argv[1:]:
+        return merge_table(k, dev)
     for (B, H, Nq, Nk, d) in SHAPES:
         HD = H * d
         q = torch.randn(B * Nq, HD, device=dev).to(T)
