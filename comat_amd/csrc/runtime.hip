@@ -57,9 +57,11 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"flash_kt", "COMAT_FLASH_KT", 3, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,
                                                           // 2 in the forward, 3 (default) + dQ, 4 + dK/dV (loses at head dim
                                                           // 40: 296 registers, one wave per SIMD - profiles/r03_l_mb_flash_kt.txt)
-    {"flash_merge", "COMAT_FLASH_MERGE", 0, 0, false},    // fused attention backward: dQ and dK/dV blocks in ONE launch (after a
-                                                          // D = rowsum(dO . O) launch): 0 never, 1 when both grids together
-                                                          // hold <= 768 blocks, 2 always.  Same bits either way.
+    {"flash_merge", "COMAT_FLASH_MERGE", 1, 0, false},    // fused attention backward: dQ and dK/dV blocks in ONE launch (after a
+                                                          // D = rowsum(dO . O) launch): 0 never, 1 (default) when both grids
+                                                          // together hold <= 768 blocks, 2 always.  Same bits either way;
+                                                          // 256^2 d=160: 70.6 -> 48.9 us, 2 x 8 x 4096^2 d=40 (1024 blocks):
+                                                          // 395 -> 470 us (profiles/r03_m_mb_flash_merge.txt)
 };
 }  // namespace
 

@@ -72,7 +72,7 @@ def merge_table(k, dev):
         blocks = ((Nq + 127) // 128 + (Nk + 127) // 128) * B * H
         print(f"flash merge B={B} H={H:2d} Nq={Nq:4d} Nk={Nk:4d} d={d:3d}  separate {row[0]:7.1f} us   one launch {row[1]:7.1f} us   "
               f"({(Nq + 127) // 128 * B * H} dQ blocks + {(Nk + 127) // 128 * B * H} x qsplit dK/dV blocks, {blocks} unsplit)", flush=True)
-    _hip.set_option("flash_merge", 0)
+    _hip.set_option("flash_merge", 1)
 
 
 def main():
