@@ -82,6 +82,8 @@ def main():
     T = torch.bfloat16
     if "merge" in sys.argv[1:]:
         return merge_table(k, dev)
+    if "kt" in sys.argv[1:]:
+        return kt_table(k, dev)
     for (B, H, Nq, Nk, d) in SHAPES:
         HD = H * d
         q = torch.randn(B * Nq, HD, device=dev).to(T)
@@ -104,10 +106,14 @@ def main():
                       f"bwd {tb:8.1f} us {2.5 * fl / tb / 1e6:7.1f} TF/s", flush=True)
     _hip.set_option("flash_trim", 1)
     _hip.set_option("flash_tr", 1)
+    kt_table(k, dev)
+
+
+def kt_table(k, dev):
+    T = torch.bfloat16
+    _hip.set_option("flash_merge", 0)
     print("# two 32-row tiles per iteration (flash_kt: 2 forward, 3 + dQ, 4 + dK/dV) against one, default trim / tr")
-    for (B, H, Nq, Nk, d) in SHAPES:
-        if d > 96:
-            continue
+    for (B, H, Nq, Nk, d) in SHAPES:  # (head dims above 96 have one-tile kernels only: their columns repeat)
         HD = H * d
         q = torch.randn(B * Nq, HD, device=dev).to(T)
         kk = torch.randn(B * Nk, HD, device=dev).to(T)
@@ -125,7 +131,8 @@ def main():
             row.append((tf, tb))
         print(f"flash kt B={B} H={H} Nq={Nq} Nk={Nk} d={d:3d}  fwd {row[0][0]:7.1f} -> {row[1][0]:7.1f} us   "
               f"bwd kt=1 {row[0][1]:7.1f}  kt=3 (dQ) {row[2][1]:7.1f}  kt=4 (dQ + dK/dV) {row[3][1]:7.1f} us", flush=True)
-    _hip.set_option("flash_kt", 1)
+    _hip.set_option("flash_kt", 3)
+    _hip.set_option("flash_merge", 1)
 
 
 if __name__ == "__main__":
