@@ -1155,15 +1155,19 @@ void launch_fwd(const FlashArgs& a, hipStream_t st) {
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_bwd(const FlashArgs& a, hipStream_t st) {
-    // option flash_kt: 1 = one 32-row tile per iteration everywhere, 2 = two in the forward, 3 = + dQ, 4 = + dK/dV
-    // option flash_merge: dQ and dK/dV in one launch (flash_bwd_kernel) - 0 never, 1 when the two grids together hold at
-    // most 768 blocks (neither fills 256 CUs x 2 resident blocks alone), 2 always
+    // option flash_kt: 1 = one 32-row tile per iteration everywhere, 2 = two in the forward, 3 = + dQ, 4 = + dK/dV for head
+    // dims <= 64 (two waves per SIMD there; at 80 the one-tile kernel is faster: profiles/r03_n_mb_flash_kt_vgpr.txt),
+    // 5 = + dK/dV for every head dim <= 96
+    // option flash_merge: dQ and dK/dV in one launch (flash_bwd_kernel, one-tile dK/dV body) - 0 never, 1 when the two
+    // grids together hold at most 768 blocks (neither fills 256 CUs x 2 resident blocks alone), 2 always
     const dim3 gq((a.Nq + 127) / 128, a.B * a.H), gk((a.Nk + 127) / 128, a.B * a.H, a.qsplit);
     const int kt = comat_option(COMAT_OPT_FLASH_KT), mg = comat_option(COMAT_OPT_FLASH_MERGE);
     constexpr bool TWO = sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES + 1024 <= 65536;
-    const bool dq2 = TWO && kt >= 3 && a.Nk > 64, dkdv2 = TWO && kt >= 4 && a.Nq > 64;
     const int64_t blocks = ((int64_t)gq.x + (int64_t)gk.x * gk.z) * gq.y;
-    if (!dkdv2 && (mg == 2 || (mg == 1 && blocks <= 768)) && (int64_t)gq.x + (int64_t)gk.x * gk.z <= 65535) {
+    const bool merge = (mg == 2 || (mg == 1 && blocks <= 768)) && (int64_t)gq.x + (int64_t)gk.x * gk.z <= 65535;
+    const bool dq2 = TWO && kt >= 3 && a.Nk > 64;
+    const bool dkdv2 = TWO && !merge && a.Nq > 64 && (kt >= 5 || (kt == 4 && DMAX <= 64));
+    if (merge) {
         hipLaunchKernelGGL((flash_delta_kernel<T, DMAX, NK>), gq, dim3(NT), 0, st, a);
         const dim3 g(gq.x + gk.x * gk.z, gq.y);
         if constexpr (TWO) {

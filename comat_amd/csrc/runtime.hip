@@ -54,9 +54,9 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // by the last-arriving block / by the apply kernel's prologue)
     {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
                                                           // kernel with hardware transpose reads
-    {"flash_kt", "COMAT_FLASH_KT", 3, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,
-                                                          // 2 in the forward, 3 (default) + dQ, 4 + dK/dV (loses at head dim
-                                                          // 40: 296 registers, one wave per SIMD - profiles/r03_l_mb_flash_kt.txt)
+    {"flash_kt", "COMAT_FLASH_KT", 4, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,
+                                                          // 2 in the forward, 3 + dQ, 4 (default) + dK/dV for head dims <= 64,
+                                                          // 5 + dK/dV up to head dim 96 (profiles/r03_n_mb_flash_kt_vgpr.txt)
     {"flash_merge", "COMAT_FLASH_MERGE", 1, 0, false},    // fused attention backward: dQ and dK/dV blocks in ONE launch (after a
                                                           // D = rowsum(dO . O) launch): 0 never, 1 (default) when both grids
                                                           // together hold <= 768 blocks, 2 always.  Same bits either way;

@@ -748,7 +748,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=3, flash_merge=1, norm_fused=3)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, norm_fused=3)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1011,7 +1011,7 @@ def test_workspaces_are_created_before_a_capture_not_inside_it(hip):
 @pytest.mark.parametrize("cfg", [(2, 1024, 1024, 8, 40), (1, 300, 200, 8, 80), (2, 70, 130, 2, 40), (1, 577, 577, 3, 64),
                                  (1, 130, 65, 1, 48), (2, 1024, 77, 8, 80), (1, 96, 4096, 2, 40), (1, 4096, 100, 2, 40)])
 def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
-    """option flash_kt = 4 (2: forward only, 3: + dQ): the bf16 fused attention kernels with two 32-row tiles per iteration (one barrier per 64 keys /
+    """option flash_kt = 5 (2: forward only, 3: + dQ, 4: + dK/dV up to head dim 64, 5: up to 96): the bf16 fused attention kernels with two 32-row tiles per iteration (one barrier per 64 keys /
     queries; forward: one rescale decision per 64 keys) against the one-tile kernels - same arithmetic per element, other
     summation order / max granularity: equal to bf16 rounding (log-sum-exp to fp32 rounding) - and against a materialised
     fp32 reference.  Ragged tile counts (a masked second tile), the query-split dK/dV path (77 keys) included."""
@@ -1021,8 +1021,8 @@ def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
     g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
     K = ops.kernels()
     outs = []
-    for kt in (1, 4):
-        _set_opts(flash_kt=kt)
+    for kt in (1, 5):
+        _set_opts(flash_kt=kt, flash_merge=0)
         qd, kd, vd, gd = (dv(t, hip, dtype) for t in (q, k_, v, g))
         o = torch.empty_like(qd)
         lse, dbuf = torch.empty(B, H, Nq, device=hip), torch.empty(B, H, Nq, device=hip)
@@ -1065,7 +1065,7 @@ def test_flash_backward_in_one_launch_is_bit_identical(hip, cfg, dtype, default_
     o = torch.empty_like(qd)
     lse = torch.empty(B, H, Nq, device=hip)
     K.flash_attn_fwd(qd, kd, vd, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
-    for kt in (1, 3):
+    for kt in (1, 3):  # (4 / 5 pick the two-tile dK/dV body for the separate launch only: another summation order)
         got = []
         for merge in (0, 2, 1):
             _set_opts(flash_kt=kt, flash_merge=merge)

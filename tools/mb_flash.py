@@ -112,7 +112,7 @@ def main():
 def kt_table(k, dev):
     T = torch.bfloat16
     _hip.set_option("flash_merge", 0)
-    print("# two 32-row tiles per iteration (flash_kt: 2 forward, 3 + dQ, 4 + dK/dV) against one, default trim / tr")
+    print("# two 32-row tiles per iteration (flash_kt: 2 forward, 3 + dQ, 5 + dK/dV) against one, default trim / tr")
     for (B, H, Nq, Nk, d) in SHAPES:  # (head dims above 96 have one-tile kernels only: their columns repeat)
         HD = H * d
         q = torch.randn(B * Nq, HD, device=dev).to(T)
@@ -124,14 +124,14 @@ def kt_table(k, dev):
         dbuf = torch.empty(B, H, Nq, device=dev)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
         row = []
-        for kt in (1, 2, 3, 4):
+        for kt in (1, 2, 3, 5):
             _hip.set_option("flash_kt", kt)
             tf = timeit(lambda: k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5))
             tb = timeit(lambda: k.flash_attn_bwd(q, kk, v, o, g, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5))
             row.append((tf, tb))
         print(f"flash kt B={B} H={H} Nq={Nq} Nk={Nk} d={d:3d}  fwd {row[0][0]:7.1f} -> {row[1][0]:7.1f} us   "
-              f"bwd kt=1 {row[0][1]:7.1f}  kt=3 (dQ) {row[2][1]:7.1f}  kt=4 (dQ + dK/dV) {row[3][1]:7.1f} us", flush=True)
-    _hip.set_option("flash_kt", 3)
+              f"bwd kt=1 {row[0][1]:7.1f}  kt=3 (dQ) {row[2][1]:7.1f}  kt=5 (dQ + dK/dV) {row[3][1]:7.1f} us", flush=True)
+    _hip.set_option("flash_kt", 4)
     _hip.set_option("flash_merge", 1)
 
 
