@@ -55,6 +55,13 @@ __device__ __forceinline__ float half_sum(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// two fp32 values in a register pair: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 do two lanes' worth of the softmax / dS
+// arithmetic per instruction (the loops are VALU-bound: tools/isa_loop.py).  Component-wise IEEE, i.e. the same bits as the
+// scalar forms.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t pair_of(const f32x16_t& v, int i) { return f32x2_t{v[i], v[i + 1]}; }
+__device__ __forceinline__ f32x2_t splat2(float x) { return f32x2_t{x, x}; }
+__device__ __forceinline__ f32x2_t exp2_fast2(f32x2_t x) { return f32x2_t{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // exp(x) for x given in log2 units (v_exp_f32 is 2^x: no multiply in front of it)
 __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -448,18 +455,21 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
         }
         float mt = fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mt = fmaxf(mt, fmaxf(s0[i], s1[i]));
+        for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, s0[i]), s1[i]);  // one v_max3_f32 each (max is exact: any order)
         mt = half_max(mt);
         const float m_new = fmaxf(m, mt);
         const float neg = -m_new * c2;
+        const f32x2_t c2v = splat2(c2), negv = splat2(neg);
         float ps = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p0 = exp2_fast(__builtin_fmaf(s0[i], c2, neg));
-            const float p1 = exp2_fast(__builtin_fmaf(s1[i], c2, neg));
-            s0[i] = p0;
-            s1[i] = p1;
-            ps += p0 + p1;
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2_t p0 = exp2_fast2(__builtin_elementwise_fma(pair_of(s0, i), c2v, negv));
+            const f32x2_t p1 = exp2_fast2(__builtin_elementwise_fma(pair_of(s1, i), c2v, negv));
+            s0[i] = p0.x; s0[i + 1] = p0.y;
+            s1[i] = p1.x; s1[i + 1] = p1.y;
+            const f32x2_t t = p0 + p1;  // the pair sums of rows i, i + 1; added to the running sum in row order, as before
+            ps += t.x;
+            ps += t.y;
         }
         ps = half_sum(ps);
         if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
@@ -714,15 +724,18 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
             mma(sc, frag_kc<T, DMAX>(Qt, r, s, hh), kf[s]);
             mma(dp, frag_kc<T, DMAX>(Gt, r, s, hh), vf[s]);
         }
-        const bool edge = (t + 1) * 32 > a.Nq || key >= a.Nk;  // rows beyond Nq: last tile only; keys beyond Nk: last block
+        // rows beyond Nq: last tile only; keys beyond Nk: last key block only - a BLOCK-uniform condition (full tiles skip
+        // the compare / select instructions)
+        const bool edge = (t + 1) * 32 > a.Nq || bx * 128 + 128 > a.Nk;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int qr = crow(i, hh);
-            float p = exp2_fast(__builtin_fmaf(sc[i], c2, -lse_s[qr]));
-            if (edge && !((t * 32 + qr < a.Nq) && (key < a.Nk))) p = 0.f;
-            sc[i] = p;
-            dp[i] = p * a.scale * (dp[i] - D_s[qr]);
+        for (int i = 0; i < 16; ++i) sc[i] = exp2_fast(__builtin_fmaf(sc[i], c2, -lse_s[crow(i, hh)]));
+        if (edge) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!((t * 32 + crow(i, hh) < a.Nq) && (key < a.Nk))) sc[i] = 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] = sc[i] * a.scale * (dp[i] - D_s[crow(i, hh)]);
         if constexpr (HW) {
             const unsigned qa = lds_addr32(Qt) + tr_off, ga = lds_addr32(Gt) + tr_off;
             auto step = [&](auto jc) {
@@ -881,12 +894,16 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
             mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
             mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), gf[s]);
         }
+        {
+            const f32x2_t c2v = splat2(c2), nl = splat2(-lse_q), nD = splat2(-D_q), scv = splat2(a.scale);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p0 = exp2_fast(__builtin_fmaf(s0[i], c2, -lse_q));
-            const float p1 = exp2_fast(__builtin_fmaf(s1[i], c2, -lse_q));
-            s0[i] = p0 * a.scale * (d0[i] - D_q);
-            s1[i] = p1 * a.scale * (d1[i] - D_q);
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2_t p0 = exp2_fast2(__builtin_elementwise_fma(pair_of(s0, i), c2v, nl));
+                const f32x2_t p1 = exp2_fast2(__builtin_elementwise_fma(pair_of(s1, i), c2v, nl));
+                const f32x2_t e0 = (p0 * scv) * (pair_of(d0, i) + nD), e1 = (p1 * scv) * (pair_of(d1, i) + nD);
+                s0[i] = e0.x; s0[i + 1] = e0.y;
+                s1[i] = e1.x; s1[i + 1] = e1.y;
+            }
         }
         if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
 #pragma unroll
@@ -1009,20 +1026,34 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
         }
         const float* st0 = (const float*)(cur + 2 * G::TILE_BYTES);
         const float* st1 = (const float*)(cur + ONE + 2 * G::TILE_BYTES);
-        const bool edge = (t + 2) * 32 > a.Nq || key >= a.Nk || !has1;
+        // rows beyond Nq / a missing second tile: last pair only; keys beyond Nk: last key block only - a BLOCK-uniform
+        // condition, so full tiles skip the 3 x 32 compare / select instructions altogether
+        const bool edge = (t + 2) * 32 > a.Nq || bx * 128 + 128 > a.Nk || !has1;
+        const f32x2_t c2v = splat2(c2), scv = splat2(a.scale);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 16; i += 2) {  // rows crow(i), crow(i) + 1 sit side by side in the staged lse / D arrays
             const int qr = crow(i, hh);
-            float p0 = exp2_fast(__builtin_fmaf(c0[i], c2, -st0[qr]));
-            float p1 = exp2_fast(__builtin_fmaf(c1[i], c2, -st1[qr]));
-            if (edge) {
-                if (!((t * 32 + qr < a.Nq) && (key < a.Nk))) p0 = 0.f;
-                if (!(has1 && ((t + 1) * 32 + qr < a.Nq) && (key < a.Nk))) p1 = 0.f;
+            const f32x2_t l0 = *(const f32x2_t*)(st0 + qr), l1 = *(const f32x2_t*)(st1 + qr);
+            const f32x2_t p0 = exp2_fast2(__builtin_elementwise_fma(pair_of(c0, i), c2v, -l0));
+            const f32x2_t p1 = exp2_fast2(__builtin_elementwise_fma(pair_of(c1, i), c2v, -l1));
+            c0[i] = p0.x; c0[i + 1] = p0.y;
+            c1[i] = p1.x; c1[i + 1] = p1.y;
+        }
+        if (edge) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qr = crow(i, hh);
+                if (!((t * 32 + qr < a.Nq) && (key < a.Nk))) c0[i] = 0.f;
+                if (!(has1 && ((t + 1) * 32 + qr < a.Nq) && (key < a.Nk))) c1[i] = 0.f;
             }
-            c0[i] = p0;
-            c1[i] = p1;
-            d0[i] = p0 * a.scale * (d0[i] - st0[32 + qr]);
-            d1[i] = p1 * a.scale * (d1[i] - st1[32 + qr]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const int qr = crow(i, hh);
+            const f32x2_t D0 = *(const f32x2_t*)(st0 + 32 + qr), D1 = *(const f32x2_t*)(st1 + 32 + qr);
+            const f32x2_t e0 = (pair_of(c0, i) * scv) * (pair_of(d0, i) - D0), e1 = (pair_of(c1, i) * scv) * (pair_of(d1, i) - D1);
+            d0[i] = e0.x; d0[i + 1] = e0.y;
+            d1[i] = e1.x; d1[i + 1] = e1.y;
         }
         const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
         const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
