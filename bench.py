@@ -592,25 +592,54 @@ def main():
         torch.distributed.all_reduce(t, op=op)
         return float(t)
 
-    def try_stepper(make, label):
-        """build a stepper and run its first (capturing) steps; on any failure fall back - loudly - to eager launches"""
-        ok, err, cand = 1, "", None
+    def drop_graph_hooks():
+        trainer.blip.static_tables = None
+        trainer.pipe.trained_runner = trainer.head_runner = trainer.d_runner = None
+        ops.reset_capture_stream(device)  # a failed capture may leave its streams in capture mode
+        ops.drop_side_stream_state()
+        trainer._d_stream = None
+        trainer._d_pending, trainer._d_keep = False, None
         try:
-            cand = make()
-        except Exception as e:  # noqa: BLE001 - stay measurable
-            ok, err = 0, f"{type(e).__name__}: {e}"
-            print(f"[bench] {label} failed ({err}); falling back", file=sys.stderr)
+            sync()
+        except Exception:  # noqa: BLE001 - the pending error of the failed capture
+            pass
+
+    fail_at = os.environ.get("COMAT_SELFTEST_FAIL", "")  # "<rank>:<label>:<call index>": fault injection (--selftest only)
+
+    def try_stepper(build, calls, label):
+        """build() -> stepper; `calls` = keyword sets of the REAL optimisation steps to run through it (its capturing
+        steps).  Every rank runs len(calls) optimisation steps whatever happens: a stepper call that raises is re-run
+        eagerly, and so are the calls after it.  That keeps the collectives matched: every capture of a SegmentedStep call
+        precedes that step's gradient exchange (sampler / head / D captures, then `_apply_updates`), so when one fails the
+        other ranks are waiting in exactly the two all-reduces the eager re-run issues; GraphedStep captures AFTER an eager
+        step of the same call and reports a failed capture through `.failed` instead of raising (that call was a whole
+        step already).  Only then is the outcome agreed (MIN over ranks): one failing rank sends every rank to eager
+        launches - loudly."""
+        ok, err, cand = 1, "", None
+        for i, kw in enumerate([None] + list(calls)):
+            if ok:
+                try:
+                    if args.selftest and fail_at == f"{rank}:{label.split()[0]}:{i}":
+                        raise RuntimeError("injected failure (COMAT_SELFTEST_FAIL)")
+                    if kw is None:
+                        cand = build()
+                    else:
+                        cand(batch, **kw)
+                    continue
+                except Exception as e:  # noqa: BLE001 - stay measurable
+                    ok, err = 0, f"{type(e).__name__}: {e}"
+                    print(f"[bench] rank {rank}: {label} failed ({err}); falling back to eager launches", file=sys.stderr)
+                    drop_graph_hooks()
+            if kw is not None:
+                trainer.train_step(batch, **{k: v for k, v in kw.items() if v is not None})
+        sync()
+        if ok and getattr(cand, "failed", None):  # GraphedStep keeps a failed capture to itself (its call was one whole step)
+            ok, err = 0, cand.failed
+            print(f"[bench] rank {rank}: {label} failed ({err}); falling back to eager launches", file=sys.stderr)
         ok = agree(ok, torch.distributed.ReduceOp.MIN) if world > 1 else ok
         if not ok:
-            trainer.blip.static_tables = None
-            trainer.pipe.trained_runner = trainer.head_runner = trainer.d_runner = None
-            ops.reset_capture_stream(device)  # a failed capture may leave its streams in capture mode
-            trainer._d_stream = None
-            try:
-                sync()
-            except Exception:  # noqa: BLE001 - the pending error of the failed capture
-                pass
-        return (cand if ok else None), err
+            drop_graph_hooks()
+        return (cand if ok else None), (err or "another rank failed")
 
     def probe(fn, n=3):
         fn()
@@ -627,14 +656,9 @@ def main():
     if mode in ("auto", "segments"):
         from comat_amd.segments import SegmentedStep
 
-        def make_segments():
-            st = SegmentedStep(trainer, dry=args.selftest)  # selftest: the same hooks, segments run eagerly (no GPU)
-            for kw in precapture_plan(scfg, fixed):  # real optimisation steps that visit every (slot, variant) once
-                st(batch, **kw)
-            st(batch, **fixed)
-            sync()
-            return st
-        seg_stepper, err = try_stepper(make_segments, "segment capture")
+        seg_stepper, err = try_stepper(lambda: SegmentedStep(trainer, dry=args.selftest),  # selftest: the same hooks, run
+                                       list(precapture_plan(scfg, fixed)) + [fixed],          # eagerly (no GPU)
+                                       "segments capture")  # real optimisation steps that visit every (slot, variant) once
         if seg_stepper is not None:
             stepper, graph_note = seg_stepper, "segments: trained UNet calls, head and D step replayed from hipGraphs"
         else:
@@ -646,13 +670,8 @@ def main():
     if not args.selftest and static_topology and mode in ("graph", "auto"):
         from comat_amd.step import GraphedStep
 
-        def make_graph():
-            st = GraphedStep(trainer)
-            st(batch, **fixed)  # one eager step (with its all-reduces), then the capture (no collective inside)
-            st(batch, **fixed)  # first replay
-            sync()
-            return st
-        graph_stepper, err = try_stepper(make_graph, "step-graph capture")
+        # first call = one eager step (with its all-reduces), then the capture (no collective inside); second = first replay
+        graph_stepper, err = try_stepper(lambda: GraphedStep(trainer), [fixed, fixed], "graph capture")
         if graph_stepper is not None and mode == "graph":
             stepper, graph_note = graph_stepper, ("whole step replayed from one hipGraph" if not graph_stepper.split() else
                                                   "forward + backward replayed from one hipGraph, gradient exchange and optimizer eager")

@@ -117,6 +117,8 @@ def reset_capture_stream(dev):
     """after a FAILED capture: the capture stream (and streams forked from it) may be left in capture mode by the runtime -
     forget it, the next capture_stream() call makes a fresh one"""
     dev = torch.device(dev)
+    if dev.type != "cuda":
+        return  # (the CPU simulator has no streams)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     st = _capture.pop(dev, None)
@@ -193,6 +195,16 @@ def reset_side_stream_state():
         join_side_streams()
     _join_queued = False
     _side_keep.clear()
+
+
+def drop_side_stream_state():
+    """After a FAILED graph capture: forget the weight gradients the aborted pass queued and the side streams it marked
+    (their operands belong to the dead capture - they must not be launched), without joining anything."""
+    global _join_queued
+    _ttq.clear()
+    _side_dirty.clear()
+    _side_keep.clear()
+    _join_queued = False
 
 
 # ---- deferred, grouped LoRA weight gradients -----------------------------------------------------------------------

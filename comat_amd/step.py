@@ -361,6 +361,7 @@ class GraphedStep:
         self.static = None      # fixed-address copies of the batch
         self.static_key = None  # shapes / dtypes they were built for
         self.pool = None
+        self.failed = None      # message of a failed capture: from then on every call is an eager step
 
     def supported(self, batch):
         return (self.tr.device.type == "cuda" and not self.tr.cfg.attrcon
@@ -398,7 +399,7 @@ class GraphedStep:
     def __call__(self, batch, training_steps=None, crop=None):
         tr = self.tr
         cfg = tr.cfg
-        if not self.supported(batch):
+        if self.failed is not None or not self.supported(batch):
             return tr.train_step(batch, **{k: v for k, v in (("training_steps", training_steps), ("crop", crop))
                                             if v is not None})
         if training_steps is None:
@@ -440,11 +441,27 @@ class GraphedStep:
                 cap = ops.capture_stream(tr.device)
                 if tr._d_stream is not None:
                     ops.prepare_capture_stream(tr.device, tr._d_stream)
-                with ops.graph_capture(g, pool=self.pool, stream=cap, **mode):
-                    if split:
-                        out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
-                    else:
-                        out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+                try:
+                    with ops.graph_capture(g, pool=self.pool, stream=cap, **mode):
+                        if split:
+                            out = tr._forward_backward_joined(sb, dict(training_steps=list(training_steps), crop=crop))
+                        else:
+                            out = tr.train_step(sb, training_steps=list(training_steps), crop=crop)
+                except Exception as e:  # noqa: BLE001 - see `failed`
+                    # A call of this object is ONE optimisation step with ONE gradient exchange, whatever happens: the eager
+                    # step above was it (its all-reduces are matched on every rank), so a failed capture must not surface
+                    # as an exception a caller would answer by stepping again.  From here on every call steps eagerly.
+                    self.failed = f"{type(e).__name__}: {e}"
+                    tr.blip.static_tables = None
+                    ops.reset_capture_stream(tr.device)
+                    tr._d_stream = None
+                    tr._d_pending, tr._d_keep = False, None
+                    ops.drop_side_stream_state()  # weight gradients queued by the aborted capture
+                    try:
+                        torch.cuda.synchronize()
+                    except Exception:  # noqa: BLE001 - the pending error of the failed capture
+                        pass
+                    return logs
                 if self.pool is None:
                     self.pool = g.pool()
                 self.graphs[key] = (g, out)

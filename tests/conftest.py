@@ -40,10 +40,7 @@ def _reset_stream_state():
         except Exception:  # noqa: BLE001 - a pending error of the test that just failed
             pass
         ops.reset_capture_stream(torch.device("cuda:0"))
-    ops._ttq.clear()
-    ops._side_dirty.clear()
-    ops._side_keep.clear()
-    ops._join_queued = False
+    ops.drop_side_stream_state()
 
 
 @pytest.fixture(params=["sim", pytest.param("hip", marks=pytest.mark.gpu)])
