@@ -3,7 +3,7 @@
     python tools/isa_loop.py attention 'flash_dq2_kernel<64, 3>' [extra hipcc flags ...]
 
 Compiles comat_amd/csrc/<file>.hip to assembly with the Makefile's flags (plus the per-file FLAGS_<file> and whatever is given
-on the command line), finds the kernel whose demangled name contains the pattern, and prints, for its three longest loops,
+on the command line), finds the kernel whose demangled name contains the pattern, and prints, for the three innermost loops with the most MFMAs,
 the instruction count per class (MFMA, VALU, packed VALU, transcendental, AGPR moves, LDS, global, waits) and the VALU
 opcodes by frequency.  A loop's count covers every line between its head label and its backward branch, i.e. including
 blocks the hardware skips (masked tail tiles) - read it as an upper bound per iteration.
@@ -75,7 +75,9 @@ def main():
         m = re.search(r"s_c?branch\w* (\.LBB\d+_\d+)", l)
         if m and labels.get(m.group(1), len(body)) < i:
             loops.append((labels[m.group(1)], i))
-    for a, b in sorted(loops, key=lambda ab: ab[0] - ab[1])[:3]:
+    n_mfma = lambda ab: sum(1 for l in body[ab[0]:ab[1] + 1] if l.strip().startswith("v_mfma"))
+    inner = [ab for ab in loops if not any(o != ab and ab[0] <= o[0] and o[1] <= ab[1] and n_mfma(o) for o in loops)]
+    for a, b in sorted(inner, key=lambda ab: (-n_mfma(ab), ab[0] - ab[1]))[:3]:  # innermost loops, most MFMAs first
         c, ops = collections.Counter(), collections.Counter()
         for l in body[a:b + 1]:
             l = l.strip()
