@@ -593,7 +593,8 @@ def main():
         return float(t)
 
     def drop_graph_hooks():
-        trainer.blip.static_tables = None
+        # (the fixed-address crop tables of the BLIP preprocessing stay installed: segment graphs that survive a failed
+        # whole-step capture read them, and Blip.tables() loads them with whatever crop an eager call asks for)
         trainer.pipe.trained_runner = trainer.head_runner = trainer.d_runner = None
         ops.reset_capture_stream(device)  # a failed capture may leave its streams in capture mode
         ops.drop_side_stream_state()

@@ -452,7 +452,8 @@ class GraphedStep:
                     # step above was it (its all-reduces are matched on every rank), so a failed capture must not surface
                     # as an exception a caller would answer by stepping again.  From here on every call steps eagerly.
                     self.failed = f"{type(e).__name__}: {e}"
-                    tr.blip.static_tables = None
+                    # (the fixed-address crop tables stay installed: segment graphs captured earlier read them, and
+                    # Blip.tables() loads them with whatever crop an eager call asks for)
                     ops.reset_capture_stream(tr.device)
                     tr._d_stream = None
                     tr._d_pending, tr._d_keep = False, None
