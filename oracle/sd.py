@@ -13,8 +13,10 @@ sites:
   - VAE decode of latents / scaling_factor, then /2 + 0.5: TrainableSDPipeline.py:219-223
 The scheduler constants are pinned by the known answers of SURVEY.md §8(c) (tests/test_oracle.py); the layer set,
 state-dict names and shapes this file consumes are pinned by public totals (SD1.5 UNet 859,520,964 parameters in 686
-tensors, SDXL UNet 2,567,463,684 in 1,680, VAE decoder 49,490,179: tests/test_architectures.py).  The arithmetic of
-each layer is what remains unpinned.
+tensors, SDXL UNet 2,567,463,684 in 1,680, VAE decoder 49,490,179: tests/test_architectures.py).  The VAE decoder's
+arithmetic and wiring are pinned by an independent implementation of the same architecture (the latent-diffusion decoder
+inside transformers' Janus VQ-VAE: tests/test_oracle.py::test_vae_decoder_matches_a_third_party_ldm_decoder); the
+arithmetic of the UNet's layers is what remains unpinned.
 Weights arrive as a flat dict with diffusers state-dict names (conv weights OIHW, linear weights [out, in]).
 """
 from __future__ import annotations
