@@ -225,3 +225,41 @@ def test_nograd_merged_lora_weights_in_the_sampler(sim, dtype, monkeypatch):
     check(res[1][0], res[0][0], dtype, "image", factor=f)
     check(res[1][1], res[0][1], dtype, "latents", factor=f)
     assert rel_l2(res[1][2], res[0][2]) < (1e-4 if dtype == torch.float32 else 0.15)
+
+
+def test_vae_decoder_against_third_party_ldm_decoder(sim):
+    """the PRODUCT's VAE decoder (host code over the C ABI, here on the CPU simulator of the ABI) against the decoder of
+    transformers' Janus VQ-VAE - an independent implementation of the latent-diffusion decoder AutoencoderKL ports - on the
+    same weights under diffusers' names (see tests/test_oracle.py::test_vae_decoder_matches_a_third_party_ldm_decoder for
+    the mapping and what is switched off): image and latent gradient."""
+    from test_oracle import _ldm_decoder_to_oracle_names
+    from transformers.models.janus.configuration_janus import JanusVQVAEConfig
+    from transformers.models.janus.modeling_janus import JanusVQVAEDecoder
+
+    torch.manual_seed(12)
+    mult, n_blocks = (1, 2, 2), 1
+    dec = JanusVQVAEDecoder(JanusVQVAEConfig(base_channels=32, channel_multiplier=list(mult), num_res_blocks=n_blocks,
+                                             latent_channels=4, out_channels=3, dropout=0.0)).eval().float()
+    with torch.no_grad():
+        for name, p in dec.named_parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() > 1 else 0.5) + (1.0 if "norm" in name and name.endswith("weight") else 0.0))
+        for blk in dec.up[0].attn:
+            blk.proj_out.weight.zero_()
+            blk.proj_out.bias.zero_()
+    vsd = {k: v.detach().clone() for k, v in _ldm_decoder_to_oracle_names(dec.state_dict(), len(mult), n_blocks).items()}
+    vsd["post_quant_conv.weight"] = torch.eye(4).reshape(4, 4, 1, 1)
+    vsd["post_quant_conv.bias"] = torch.zeros(4)
+    vcfg = config.VAEConfig(block_out_channels=tuple(32 * m for m in mult), layers_per_block=n_blocks, norm_groups=32)
+    B, h, w = 2, 6, 5
+    z = torch.randn(B, 4, h, w)
+    g = torch.randn(B, 3, 4 * h, 4 * w)
+    z1 = z.clone().requires_grad_(True)
+    want = dec(z1 * 1.0)
+    (want * g).sum().backward()
+    vae = VAEDecoder(vcfg, vsd, torch.float32, sim)
+    zd = tok(z).to(sim).requires_grad_(True)
+    img, H, W = vae(zd, B, h, w)
+    assert (H, W) == (4 * h, 4 * w)
+    (img * tok(g)).sum().backward()
+    check(img, tok(want), torch.float32, "product VAE decoder vs transformers' LDM decoder")
+    check(zd.grad, tok(z1.grad), torch.float32, "latent gradient", factor=3)
