@@ -44,14 +44,18 @@ def test_two_rank_launch_like_the_driver():
     _check(_json_line(p.stdout), 2, 2, 1)
 
 
-def test_a_capture_failure_on_one_rank_sends_every_rank_to_eager_launches():
-    """fault injection: rank 1's first capturing step raises.  The failing rank re-runs that step eagerly (the other rank
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("fail, port", [("1:segments:1", 29733), ("0:segments:1", 29741), ("1:segments:0", 29743)])
+def test_a_capture_failure_on_one_rank_sends_every_rank_to_eager_launches(fail, port):
+    """fault injection (rank : stepper : call index; call 0 = building the stepper): rank 1's first capturing step raises.  The failing rank re-runs that step eagerly (the other rank
     is waiting in the step's two all-reduces), the outcome is agreed afterwards, and BOTH ranks time eager launches - no
     deadlock, no unmatched collective, one JSON line that says what happened."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    env["COMAT_SELFTEST_FAIL"] = "1:segments:1"
+    env["COMAT_SELFTEST_FAIL"] = fail
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--selftest"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
