@@ -63,3 +63,30 @@ def test_a_capture_failure_on_one_rank_sends_every_rank_to_eager_launches(fail, 
     _check(d, 2, 2, 1)
     assert "eager launches" in d["config"]["launch_mode"] and "failed" in d["config"]["launch_mode"], d["config"]["launch_mode"]
     assert "injected failure" in p.stderr
+
+
+def test_precapture_plan_visits_every_segment_variant():
+    """with attribute concentration every trained-call slot has two graph variants (attention maps captured or not) and the
+    reference draws the capturing steps at random each optimisation step (training_script.py:589-590): the steps bench.py
+    runs BEFORE its timed region must leave no variant to be captured inside it, whatever is drawn later."""
+    import random
+    sys.path.insert(0, ROOT)
+    import bench
+    from comat_amd.step import StepConfig, sample_training_steps
+
+    scfg = StepConfig(total_step=50, K=5, attrcon=True, attrcon_train_steps=2)
+    fixed = dict(crop=(1, 1, 510, 510))
+    visited = set()
+    for kw in list(bench.precapture_plan(scfg, fixed)) + [fixed]:
+        ts = kw.get("training_steps")
+        if ts is None:  # the stepper draws them itself: any draw visits the non-capturing variant of slots it does not pick
+            continue
+        order = sorted(ts)
+        for slot, t in enumerate(order):
+            visited.add((slot, t in kw.get("attrcon_steps", ())))
+    assert visited == {(slot, cap) for slot in range(scfg.K) for cap in (False, True)}, sorted(visited)
+    rng = random.Random(3)
+    for _ in range(200):  # every later draw only needs variants that exist
+        ts = sample_training_steps(scfg.total_step, scfg.K, rng)
+        caps = rng.sample(ts, scfg.attrcon_train_steps)
+        assert {(slot, t in caps) for slot, t in enumerate(sorted(ts))} <= visited
