@@ -4,9 +4,11 @@
     PINNED by tests/golden/grounding_loss.npz (outputs of the reference function itself, torchvision Resize shimmed —
     parity unpinned at that torchvision boundary: bool masks become `bilinear-antialias(mask) > 0`);
   - per-sample / per-timestep / per-layer assembly: attr_concen_utils/gsam_interface.py:140-228 (`get_mask_loss`),
-    with the object masks (FastSAM + GroundingDINO, out of scope) and the attribute token lists as inputs;
+    with the object masks (FastSAM + GroundingDINO, out of scope) and the attribute token lists as inputs; PINNED by
+    tests/golden/mask_loss.npz (totals of the reference method itself, detector call replaced by prepared masks);
   - GAN fidelity discriminator: training_utils/gan_sdxl.py:50-132 (`D_sd.D_sd_pipeline_forward`, G and D sides),
-    head `nn.Linear(4, 1)` on the NHWC-permuted UNet output + BCEWithLogitsLoss (:32-35).
+    head `nn.Linear(4, 1)` on the NHWC-permuted UNet output + BCEWithLogitsLoss (:32-35); PINNED by
+    tests/golden/gan_losses.npz (losses and gradients of the reference method itself on a stand-in UNet).
 """
 from __future__ import annotations
 

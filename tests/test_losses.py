@@ -81,3 +81,31 @@ def test_resize_masks_matches_dense_operator():
         ref = np.einsum("oh,nhw,pw->nop", dense_from_taps(ys, yw, 96), m.astype(np.float64), dense_from_taps(xs, xw, 72),
                         optimize=True)
         assert np.array_equal(losses.resize_masks(m, res), (ref > 0).astype(np.float32).reshape(3, -1))
+
+
+def test_mask_loss_against_the_reference_assembly(sim):
+    """the PRODUCT's attribute-concentration loss (gather kernel of the C ABI on its CPU simulator, host assembly of
+    comat_amd/losses.py, noun / attribute lists of comat_amd/attr_index.py) against tests/golden/mask_loss.npz = the totals of
+    the reference's own `get_mask_loss` (see tests/test_oracle.py::test_mask_loss_assembly_matches_reference)."""
+    import os
+
+    import numpy as np
+
+    from comat_amd import attr_index
+    from comat_amd.losses import mask_loss
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "mask_loss.npz"))
+    bs, layers = int(d["bs"]), [str(s) for s in d["layers"]]
+    subtrees = [[[2, 3], [6, 7]], [[2, 3]], [[1, 2], [4, 5], [8], [10, [11, 12]]]]
+    pieces = [{1: "a", 2: "red", 3: "car", 4: "and", 5: "a", 6: "blue", 7: "dog"},
+              {1: "a", 2: "tall", 3: "tree"},
+              {1: "a", 2: "cat", 3: "a", 4: "big", 5: "cat", 6: "and", 7: "the", 8: "sky", 9: "a", 10: "green", 11: "skate", 12: "board"}]
+    got = [attr_index.nouns_and_attributes(st, pc) for st, pc in zip(subtrees, pieces)]
+    attn_dict = {}
+    for key in d.files:
+        if key.startswith("map:"):
+            _, ts, place = key.split(":")
+            attn_dict.setdefault(ts, {})[place] = [torch.from_numpy(m).to(sim) for m in d[key]]
+    masks = [np.concatenate([d[f"mask:{n}"][0] for n in nouns]) if "tree" not in nouns else None for nouns, _ in got]
+    tl, pl = mask_loss(attn_dict, masks, [a for _, a in got], layers, bs, sim)
+    assert abs(float(tl) - float(d["token_loss"])) < 2e-5 * max(1.0, abs(float(d["token_loss"])))
+    assert abs(float(pl) - float(d["pixel_loss"])) < 2e-5 * max(1.0, abs(float(d["pixel_loss"])))
