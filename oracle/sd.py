@@ -11,6 +11,9 @@ sites:
     controller when they require grad): attn_utils/tc_attn_utils.py:104-161
   - LoRA on to_q/to_k/to_v/to_out[0] of every attention, scale 1: training_utils/pipeline.py:84-115
   - VAE decode of latents / scaling_factor, then /2 + 0.5: TrainableSDPipeline.py:219-223
+The sampler LOOP (gradient gates, detach rule, CFG, latents chain, image / 2 + 0.5) is pinned by the reference's own
+`TrainableSDPipeline.forward` executed on stand-in UNet / VAE / scheduler objects (tests/golden/sampler_loop.npz,
+tests/test_oracle.py::test_sampler_loop_matches_reference).
 The scheduler constants are pinned by the known answers of SURVEY.md §8(c) (tests/test_oracle.py); the layer set,
 state-dict names and shapes this file consumes are pinned by public totals (SD1.5 UNet 859,520,964 parameters in 686
 tensors, SDXL UNet 2,567,463,684 in 1,680, VAE decoder 49,490,179: tests/test_architectures.py).  The VAE decoder's

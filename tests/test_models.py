@@ -1,6 +1,8 @@
 """UNet / VAE / sampler parity on the tiny configuration: comat_amd (HIP kernels, or the ABI simulator for the
 host-logic run) against the CPU oracle (oracle/sd.py) on the same seeded inputs.  fp32: gradients of the LoRA
 parameters within 1e-3 relative; bf16: within the bf16 tolerance of helpers.tol."""
+import os
+
 import pytest
 import torch
 
@@ -263,3 +265,50 @@ def test_vae_decoder_against_third_party_ldm_decoder(sim):
     (img * tok(g)).sum().backward()
     check(img, tok(want), torch.float32, "product VAE decoder vs transformers' LDM decoder")
     check(zd.grad, tok(z1.grad), torch.float32, "latent gradient", factor=3)
+
+
+def test_sampler_loop_against_the_reference_loop(sim):
+    """the PRODUCT's K-of-N sampler (comat_amd/pipeline.py over the fused CFG + DDPM step of the C ABI, here on its CPU
+    simulator) against tests/golden/sampler_loop.npz = the reference's own `TrainableSDPipeline.forward` run on stand-ins
+    (tests/test_oracle.py::test_sampler_loop_matches_reference): the same stand-in 'UNet' / 'VAE' in the product's
+    channels-last token layout; image, final latents, the gradients with respect to the stand-in's trainable matrix and
+    the initial latents, and the gradient mode / input-requires-grad of every UNet call."""
+    import types
+
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_loop.npz"))
+    T = lambda k: torch.from_numpy(gold[k])
+    V, n = T("V"), int(gold["n_steps"])
+    bs, _, h, w = gold["latents"].shape
+    L = gold["cond"].shape[1]
+    calls = []
+    state = {}
+
+    def unet(x, B, H, W_, t, ctx, L_, capture_places=(), added=None, kv_cache=None):
+        calls.append((int(t), bool(torch.is_grad_enabled()), bool(x.requires_grad)))
+        xn, c = untok(x, B, H, W_), ctx.reshape(B, L_, -1)
+        shift = c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
+        y = torch.tanh(torch.einsum("oc,bchw->bohw", state["W"], xn)) * (1.0 + 1e-3 * float(t)) + 0.3 * shift + 0.1 * xn.roll(1, dims=3)
+        return tok(y), {}
+    unet.dtype, unet.device = torch.float32, sim
+    unet.cfg = types.SimpleNamespace(addition_embed=False)
+
+    def vae(z, B, H, W_):
+        return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
+    vae.cfg = types.SimpleNamespace(scaling_factor=float(gold["scaling_factor"]))
+    pipe = TrainableSDPipeline(unet, vae)
+    for name in "abc":
+        calls.clear()
+        state["W"] = T("W").clone().requires_grad_(True)
+        x0 = T("latents").clone().requires_grad_(True)
+        image, latents = pipe.forward(T("cond"), T("uncond"), height=8 * h, width=8 * w,
+                                      training_timesteps=[int(i) for i in gold[f"{name}:train"]], num_inference_steps=n,
+                                      guidance_scale=7.5, latents=x0 * 1.0, noises=list(T("noises")), return_latents=True)
+        ((image * T("gimg")).sum() + (latents * T("glat")).sum()).backward()
+        check(image, T(f"{name}:image"), torch.float32, f"{name}: image")
+        check(latents, T(f"{name}:latents"), torch.float32, f"{name}: latents")
+        check(state["W"].grad, T(f"{name}:dW"), torch.float32, f"{name}: dW", factor=3)
+        check(x0.grad if x0.grad is not None else torch.zeros_like(x0), T(f"{name}:dx0"), torch.float32, f"{name}: dx0", factor=3)
+        assert [c[0] for c in calls] == list(gold[f"{name}:t"])
+        assert [c[1] for c in calls] == list(gold[f"{name}:unet_grad_mode"]), name
+        assert [c[2] for c in calls] == list(gold[f"{name}:unet_input_requires_grad"]), name
