@@ -364,3 +364,50 @@ def test_graphed_step_matches_eager(hip, dtype, split, monkeypatch):
         assert torch.equal(tr_e.D.head, tr_g.D.head)
         assert torch.equal(tr_e.opt.m[0], tr_g.opt.m[0]) and torch.equal(tr_e.opt.v[0], tr_g.opt.v[0])
     assert len(gs.graphs) == 2 and tr_g.opt.t == 6 and tr_g.opt_D.t == 6
+
+
+def test_step_sampling_matches_the_reference_statements():
+    """tests/golden/step_sampling.json = what the reference's own statements draw (training_script.py:563-566 trained denoise
+    steps, :589-590 attribute-concentration steps - WITH replacement -, :606-609 crop; executed by
+    tests/golden/make_step_sampling_golden.py) for 20 seeds x 3 configurations.  The trainer's samplers, fed the same
+    seeded generator in the same order, must draw the same values."""
+    import json
+    import random
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "step_sampling.json")))["sampling"]
+    assert len(cases) == 60
+    for c in cases:
+        rng = random.Random(c["seed"])
+        ts = sample_training_steps(c["total_step"], c["K"], rng)
+        ac = rng.choices(ts, k=min(c["attrcon_train_steps"], len(ts)))  # CoMatTrainer.compute_losses, the same call
+        crop = sample_crop(c["resolution"], rng)
+        assert ts == c["training_steps"] and ac == c["attrcon_steps"], c
+        assert crop == (c["offset_x"], c["offset_y"], c["size"], c["size"]), (crop, c)
+
+
+@pytest.mark.parametrize("gan, attrcon", [(False, False), (True, False), (False, True), (True, True)])
+def test_loss_composition_matches_the_reference_statements(sim, monkeypatch, gan, attrcon):
+    """tests/golden/step_sampling.json["loss"] = the generator's loss as the reference's own statements compose it
+    (training_script.py:618 `-reward`, :625 GAN term, :639-640 token / pixel terms; executed by
+    tests/golden/make_step_sampling_golden.py) from fixed scalar terms and the weights of scripts/sd15.sh.  The trainer's
+    `compute_losses`, with its sampler, head and mask loss replaced by the same scalars, must compose the same number - with
+    the weights its StepConfig holds by default."""
+    import json
+
+    import comat_amd.step as step_mod
+    case = next(c for c in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "step_sampling.json")))["loss"]
+                if c["gan"] == gan and c["attrcon"] == attrcon)
+    cfg, batch, W, tr = make_world(torch.float32, sim, attrcon, gan=gan)
+    ref = StepConfig()  # the defaults ARE the recipe's weights (test_step_config_defaults_follow_the_reference_recipe)
+    assert (ref.gan_loss_weight, ref.mask_token_loss_weight, ref.mask_pixel_loss_weight) == \
+        (case["gan_loss_weight"], case["mask_token_loss_weight"], case["mask_pixel_loss_weight"])
+    tr.cfg = dataclasses.replace(tr.cfg, gan_loss_weight=ref.gan_loss_weight, mask_token_loss_weight=ref.mask_token_loss_weight,
+                                 mask_pixel_loss_weight=ref.mask_pixel_loss_weight)
+    t = case["terms"]
+    lat = torch.zeros(2 * 8 * 8, 4, requires_grad=True)
+    monkeypatch.setattr(tr.pipe, "forward", lambda *a, **k: lat)
+    tr.head_runner = lambda lat_, b, crop, bs, h, w: dict(
+        reward=torch.tensor(t["reward"]).mean(), logp=torch.zeros(1), image=(torch.zeros(1, 3), 64, 64),
+        **({"G_loss": torch.tensor(t["G_loss"])} if gan else {}))
+    monkeypatch.setattr(step_mod, "mask_loss", lambda *a, **k: (torch.tensor(t["token_loss"]), torch.tensor(t["pixel_loss"])))
+    out = tr.compute_losses(batch, training_steps=[1, 2], crop=(0, 0, 63, 63))
+    assert abs(float(out["loss"]) - case["loss"]) < 1e-6, (float(out["loss"]), case)
