@@ -20,7 +20,7 @@ import os
 import sys
 import textwrap
 import types
-from typing import Any, Callable, Dict, List, Optional, Union
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -31,13 +31,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import sd as O  # noqa: E402
 
 
-def reference_forward():
+def reference_forward(cls_name="TrainableSDPipeline"):
     src = open(os.path.join(REF, "TrainableSDPipeline.py")).read()
     tree = ast.parse(src)
-    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TrainableSDPipeline")
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name)
     fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "forward")
-    ns = {"torch": torch, "Union": Union, "List": List, "Optional": Optional, "Callable": Callable, "Dict": Dict, "Any": Any}
-    exec(compile(textwrap.dedent(ast.get_source_segment(src, fn)), "TrainableSDPipeline.py:forward", "exec"), ns)
+    ns = {"torch": torch, "Union": Union, "List": List, "Optional": Optional, "Callable": Callable, "Dict": Dict, "Any": Any,
+          "Tuple": Tuple}
+    exec(compile(textwrap.dedent(ast.get_source_segment(src, fn)), f"TrainableSDPipeline.py:{cls_name}.forward", "exec"), ns)
     return ns["forward"]
 
 
@@ -64,7 +65,8 @@ class StubScheduler:
     def step(self, eps, t, x, return_dict=True, **kw):
         z = self.noises[self.i]
         self.i += 1
-        return types.SimpleNamespace(prev_sample=self.ddpm.step(eps, int(t), x, z))
+        prev = self.ddpm.step(eps, int(t), x, z)
+        return types.SimpleNamespace(prev_sample=prev) if return_dict else (prev,)
 
 
 def main():
@@ -112,6 +114,49 @@ def main():
         out[f"{name}:t"] = np.array([c[0] for c in calls])
         print(name, train, "t", [c[0] for c in calls], "grad mode", [int(c[1]) for c in calls], "input grad", [int(c[2]) for c in calls],
               "|dW|", float(Wp.grad.norm()), "|dx0|", float(out[f"{name}:dx0"].norm()))
+    # ---- SDXL (TrainableSDPipeline.py:657-846): pooled text embedding + size / crop ids as added conditioning, the UNet
+    # input detached on EVERY step, latents.half() decoded and returned raw (no / 2 + 0.5) with return_latents
+    forward_xl = reference_forward("TrainableSDXLPipeline")
+    pooled, npooled = torch.randn(bs, 5, generator=g), torch.randn(bs, 5, generator=g)
+    out.update(pooled=pooled, npooled=npooled)
+
+    def stub_unet_xl(W, x, t, ctx, text_embeds, time_ids):
+        extra = (text_embeds.mean(dim=1) + 1e-3 * time_ids.float().sum(dim=1)).reshape(-1, 1, 1, 1)
+        return stub_unet(W, x, t, ctx) + 0.2 * extra
+    for name, train in (("xa", [1, 3]), ("xb", [0, 1, 2, 3, 4])):
+        Wp = W0.clone().requires_grad_(True)
+        x0 = lat0.clone().requires_grad_(True)
+        calls = []
+
+        def unet(x, t, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None, return_dict=False):
+            calls.append((int(t), bool(torch.is_grad_enabled()), bool(x.requires_grad)))
+            return (stub_unet_xl(Wp, x, int(t), encoder_hidden_states, added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"]),)
+        self = types.SimpleNamespace(_execution_device=torch.device("cpu"), unet=unet, scheduler=StubScheduler(noises))
+        self.encode_prompt = lambda **kw: (kw["prompt_embeds"], kw["negative_prompt_embeds"], kw["pooled_prompt_embeds"],
+                                           kw["negative_pooled_prompt_embeds"])
+        self.prepare_latents = lambda b, c, hh, ww, dtype, device, generator, latents: latents
+        self.prepare_extra_step_kwargs = lambda generator, eta: {}
+        self._get_add_time_ids = lambda osz, crop, tsz, dtype=None: torch.tensor([list(osz) + list(crop) + list(tsz)], dtype=dtype)
+        self.vae = types.SimpleNamespace(config=types.SimpleNamespace(scaling_factor=0.13025),
+                                         decode=lambda z, return_dict=False: (torch.einsum("oc,bchw->bohw", V.to(z.dtype), z),))
+        prev = torch.is_grad_enabled()
+        image, latents = forward_xl(self, height=8 * h, width=8 * w, training_timesteps=list(train), detach_gradient=True,
+                                    num_inference_steps=N, guidance_scale=7.5, latents=x0 * 1.0, prompt_embeds=cond,
+                                    negative_prompt_embeds=uncond, pooled_prompt_embeds=pooled,
+                                    negative_pooled_prompt_embeds=npooled, return_latents=True)
+        torch.set_grad_enabled(prev)
+        ((image.float() * gimg).sum() + (latents.float() * glat).sum()).backward()
+        out[f"{name}:train"] = np.array(train)
+        out[f"{name}:image"] = image.detach().float()
+        out[f"{name}:latents"] = latents.detach().float()
+        out[f"{name}:dW"] = Wp.grad.clone()
+        out[f"{name}:dx0"] = x0.grad.clone() if x0.grad is not None else torch.zeros_like(x0)
+        out[f"{name}:unet_grad_mode"] = np.array([c[1] for c in calls])
+        out[f"{name}:unet_input_requires_grad"] = np.array([c[2] for c in calls])
+        out[f"{name}:t"] = np.array([c[0] for c in calls])
+        print(name, train, "grad mode", [int(c[1]) for c in calls], "input grad", [int(c[2]) for c in calls], "image dtype", image.dtype,
+              "|dW|", float(Wp.grad.norm()), "|dx0|", float(out[f"{name}:dx0"].norm()))
+    out["xl_scaling_factor"] = np.float64(0.13025)
     np.savez_compressed(os.path.join(HERE, "sampler_loop.npz"), **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()})
 
 

@@ -312,3 +312,52 @@ def test_sampler_loop_against_the_reference_loop(sim):
         assert [c[0] for c in calls] == list(gold[f"{name}:t"])
         assert [c[1] for c in calls] == list(gold[f"{name}:unet_grad_mode"]), name
         assert [c[2] for c in calls] == list(gold[f"{name}:unet_input_requires_grad"]), name
+
+
+def test_sdxl_sampler_loop_against_the_reference_loop(sim):
+    """the product's SDXL sampler against the reference's own `TrainableSDXLPipeline.forward` run on stand-ins
+    (tests/golden/sampler_loop.npz cases xa / xb; see tests/test_oracle.py::test_sdxl_sampler_loop_matches_reference for what
+    they pin and why the bounds are 2e-3 / 2e-2: the reference runs its tail in fp16)."""
+    import types
+
+    import numpy as np
+
+    from comat_amd.pipeline import TrainableSDXLPipeline
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_loop.npz"))
+    T = lambda k: torch.from_numpy(gold[k])
+    V, n = T("V"), int(gold["n_steps"])
+    bs, _, h, w = gold["latents"].shape
+    calls, state = [], {}
+
+    def unet(x, B, H, W_, t, ctx, L_, capture_places=(), added=None, kv_cache=None):
+        calls.append((bool(torch.is_grad_enabled()), bool(x.requires_grad)))
+        xn, c = untok(x, B, H, W_), ctx.reshape(B, L_, -1)
+        text_embeds, time_ids = added
+        shift = c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
+        extra = (text_embeds.mean(dim=1) + 1e-3 * time_ids.float().sum(dim=1)).reshape(-1, 1, 1, 1)
+        y = (torch.tanh(torch.einsum("oc,bchw->bohw", state["W"], xn)) * (1.0 + 1e-3 * float(t)) + 0.3 * shift
+             + 0.1 * xn.roll(1, dims=3) + 0.2 * extra)
+        return tok(y), {}
+    unet.dtype, unet.device = torch.float32, sim
+    unet.cfg = types.SimpleNamespace(addition_embed=True)
+    unet.added_embedding = lambda text_embeds, ids: (text_embeds, torch.tensor(ids, dtype=torch.float32))
+
+    def vae(z, B, H, W_):
+        return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
+    vae.cfg = types.SimpleNamespace(scaling_factor=float(gold["xl_scaling_factor"]))
+    pipe = TrainableSDXLPipeline(unet, vae)
+    for name in ("xa", "xb"):
+        calls.clear()
+        state["W"] = T("W").clone().requires_grad_(True)
+        x0 = T("latents").clone().requires_grad_(True)
+        image, latents = pipe.forward(T("cond"), T("uncond"), height=8 * h, width=8 * w,
+                                      training_timesteps=[int(i) for i in gold[f"{name}:train"]], num_inference_steps=n,
+                                      guidance_scale=7.5, latents=x0 * 1.0, noises=list(T("noises")), return_latents=True,
+                                      pooled_prompt_embeds=T("pooled"), negative_pooled_prompt_embeds=T("npooled"))
+        ((image * T("gimg")).sum() + (latents * T("glat")).sum()).backward()
+        for got, key, tol in ((image, "image", 2e-3), (latents, "latents", 2e-3), (state["W"].grad, "dW", 2e-2),
+                              (x0.grad if x0.grad is not None else torch.zeros_like(x0), "dx0", 2e-2)):
+            ref = T(f"{name}:{key}")
+            assert (got - ref).abs().max() <= tol * (ref.abs().max() + 1e-6), (name, key, float((got - ref).abs().max()))
+        assert [c[0] for c in calls] == list(gold[f"{name}:unet_grad_mode"]), name
+        assert [c[1] for c in calls] == [False] * n, name
