@@ -88,3 +88,22 @@ def test_fused_qkv_vit_matches_split_projections(dev, dtype):
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     for a, b, name in zip(outs[0], outs[1], ("reward", "token log-probs", "d reward / d image")):
         assert (a - b).abs().max() <= tol * max(float(a.abs().max()), 1e-6), name
+
+
+def test_caption_labels_match_the_reference_score():
+    """tests/golden/blip_labels.json = the labels the reference's own `Blip.score` (concept_mat_utils/caption_blip.py:43-59,
+    executed by tests/golden/make_blip_labels_golden.py with the processor / model calls recorded) hands to the captioner
+    for given token ids: pads and the 'a photography of' prefix ignored; reward = -loss.  Product and oracle build the same."""
+    import json
+    import os
+
+    from comat_amd.blip import Blip
+    from oracle import blip as OBL
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "blip_labels.json")))
+    ids = torch.tensor(g["input_ids"])
+    want = torch.tensor(g["labels"])
+    assert torch.equal(Blip.make_labels(ids, g["pad_token_id"], g["prompt_length"]), want)
+    assert torch.equal(OBL.make_labels(ids, g["pad_token_id"], g["prompt_length"]), want)
+    assert torch.equal(ids, torch.tensor(g["input_ids"]))  # the ids themselves stay untouched
+    assert g["reward"] == -g["loss"] and g["text"][0] == "a photography of a red car"
+    assert g["model_inputs"] == ["attention_mask", "input_ids", "labels", "pixel_values"]
