@@ -259,11 +259,10 @@ def build_world(device, dtype, rank, cfg_name):
         from comat_amd.pipeline import TrainableSDXLPipeline
         ucfg, vcfg = config.SDXL_UNET, config.SDXL_VAE
         if cfg_name == "c5":
-            scfg = StepConfig(resolution=1024, total_step=50, K=5, gan_loss=True, attrcon=True,
-                              train_layer_ls=("mid_32", "up_32", "up_64"), attn_reses=(64, 32))
+            scfg = StepConfig.sdxl(resolution=1024, total_step=50, K=5, gan_loss=True, attrcon=True,
+                                   train_layer_ls=("mid_32", "up_32", "up_64"), attn_reses=(64, 32))
         else:
-            scfg = StepConfig(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True,
-                              train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
+            scfg = StepConfig.sdxl(resolution=512, total_step=50, K=5, gan_loss=True, attrcon=True)
     elif tiny:
         scfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=True, attrcon=False)
     elif cfg_name == "c2":

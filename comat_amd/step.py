@@ -55,6 +55,14 @@ class StepConfig:
     max_grad_norm_D: float = 1.0
     label_smoothing: float = 0.1
 
+    @classmethod
+    def sdxl(cls, **kw):
+        """the values of scripts/sdxl.sh where they differ from scripts/sd15.sh (--learning_rate 2e-5 --learning_rate_D 5e-5
+        --gan_loss_weight 0.5) and the SDXL layer list of training_script.py:312 (at 512 x 512)"""
+        base = dict(lr=2e-5, lr_D=5e-5, gan_loss_weight=0.5, train_layer_ls=("mid_16", "up_16", "up_32"), attn_reses=(32, 16))
+        base.update(kw)
+        return cls(**base)
+
 
 def _dbg(tag):
     """COMAT_DEBUG_SYNC=1: synchronise and print a phase marker (locates asynchronous device faults)."""

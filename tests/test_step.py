@@ -314,6 +314,20 @@ def test_step_config_defaults_follow_the_reference_recipe():
     assert (c.lr, c.max_grad_norm, c.K, c.total_step, c.resolution) == (5e-5, 0.1, 5, 50, 512)
     assert (c.gan_loss, c.gan_loss_weight, c.lr_D, c.adam_beta1_D, c.max_grad_norm_D) == (True, 1.0, 2e-5, 0.0, 1.0)
     assert (c.mask_token_loss_weight, c.mask_pixel_loss_weight, c.attrcon_train_steps) == (1e-3, 5e-5, 2)
+    # ... and, field by field, what the reference's OWN argument parser makes of its two scripts (script values and parser
+    # defaults: tests/golden/recipes.json, written by tests/golden/make_recipe_golden.py)
+    import json
+    recipes = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "recipes.json")))
+    names = dict(lr="learning_rate", lr_D="learning_rate_D", resolution="resolution", total_step="total_step", K="K",
+                 cfg_scale="cfg_scale", gan_loss="gan_loss", gan_loss_weight="gan_loss_weight",
+                 attrcon_train_steps="attrcon_train_steps", mask_token_loss_weight="mask_token_loss_weight",
+                 mask_pixel_loss_weight="mask_pixel_loss_weight", adam_beta1="adam_beta1", adam_beta2="adam_beta2",
+                 adam_beta1_D="adam_beta1_D", adam_beta2_D="adam_beta2_D", adam_weight_decay="adam_weight_decay",
+                 adam_epsilon="adam_epsilon", max_grad_norm="max_grad_norm", max_grad_norm_D="max_grad_norm_D")
+    for cfg, recipe in ((StepConfig(), recipes["sd15"]), (StepConfig.sdxl(), recipes["sdxl"])):
+        for field, arg in names.items():
+            assert getattr(cfg, field) == recipe[arg], (field, getattr(cfg, field), recipe[arg])
+    assert recipes["sd15"]["lora_rank"] == recipes["sdxl"]["lora_rank"] == 128 and recipes["sd15"]["scheduler"] == "DDPM"
 
 
 def test_graphed_step_wrapper_runs_eager_without_a_gpu(sim):
