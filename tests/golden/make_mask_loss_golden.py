@@ -40,7 +40,7 @@ def reference_methods(*names):
 def main():
     get_mask_loss, update_nouns_attributes = reference_methods("get_mask_loss", "update_nouns_attributes")
     g = torch.Generator().manual_seed(9)
-    bs, heads, L, H = 3, 2, 77, 32
+    bs, heads, L, H = 3, 2, 16, 32
     layers = ["mid_4", "up_8"]
     attn_map = {}
     for ts in ("801", "401"):
