@@ -361,3 +361,60 @@ def test_sdxl_sampler_loop_against_the_reference_loop(sim):
             assert (got - ref).abs().max() <= tol * (ref.abs().max() + 1e-6), (name, key, float((got - ref).abs().max()))
         assert [c[0] for c in calls] == list(gold[f"{name}:unet_grad_mode"]), name
         assert [c[1] for c in calls] == [False] * n, name
+
+
+def test_attrcon_sampler_branch_against_the_reference(sim):
+    """the product's sampler with attribute-concentration steps against the reference's own
+    `AttrConcenTrainableSDPipeline.forward` + `_attrcon_forward` run on a toy UNet (tests/golden/attrcon_sampler.npz; see
+    tests/test_oracle.py::test_attrcon_sampler_branch_matches_reference).  The product sends the joint CFG batch through
+    the UNet ONCE and keeps the conditional half of the captured probabilities, the reference runs the two halves
+    separately: same maps under the same `attn_dict[str(t)][place_res]` keys, same image / latents / gradients."""
+    import types
+
+    import numpy as np
+
+    from test_oracle import _toy_latent_unet
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "attrcon_sampler.npz"))
+    T = lambda k: torch.from_numpy(gold[k])
+    V, n, layers, heads = T("V"), int(gold["n_steps"]), [str(s) for s in gold["layers"]], int(gold["heads"])
+    bs, _, h, w = gold["latents"].shape
+    state = {}
+
+    def unet(x, B, H, W_, t, ctx, L_, capture_places=(), added=None, kv_cache=None):
+        got = {p: [] for p in capture_places}
+
+        def capture(probs, is_cross, place):
+            if is_cross and place in got:
+                got[place].append(probs.reshape(B, heads, probs.shape[1], probs.shape[2]))
+            return probs
+        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None)
+        return tok(y), got
+    unet.dtype, unet.device = torch.float32, sim
+    unet.cfg = types.SimpleNamespace(addition_embed=False)
+
+    def vae(z, B, H, W_):
+        return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
+    vae.cfg = types.SimpleNamespace(scaling_factor=float(gold["scaling_factor"]))
+    pipe = TrainableSDPipeline(unet, vae)
+    for name in "abc":
+        state["sd"] = {k[2:]: T(k).clone().requires_grad_(True) for k in gold.files if k.startswith("w:")}
+        x0 = T("latents").clone().requires_grad_(True)
+        image, latents = pipe.forward(T("cond"), T("uncond"), height=8 * h, width=8 * w,
+                                      training_timesteps=[int(i) for i in gold[f"{name}:train"]], num_inference_steps=n,
+                                      guidance_scale=7.5, latents=x0 * 1.0, noises=list(T("noises")), return_latents=True,
+                                      attrcon_train_steps=[int(i) for i in gold[f"{name}:attr"]], train_layer_ls=layers)
+        loss = (image * T("gimg")).sum() + (latents * T("glat")).sum()
+        keys = []
+        for ts in sorted(pipe.attn_dict):
+            for place in sorted(pipe.attn_dict[ts]):
+                for i, m in enumerate(pipe.attn_dict[ts][place]):
+                    keys.append(f"{ts}:{place}:{i}")
+                    check(m, T(f"{name}:map:{ts}:{place}:{i}"), torch.float32, f"{name}: map {keys[-1]}")
+                    loss = loss + 3.0 * (m ** 2).sum()
+        assert keys == [str(k) for k in gold[f"{name}:map_keys"]], (name, keys)
+        loss.backward()
+        check(image, T(f"{name}:image"), torch.float32, f"{name}: image")
+        check(latents, T(f"{name}:latents"), torch.float32, f"{name}: latents")
+        for key in [k for k in gold.files if k.startswith(f"{name}:d:")]:
+            check(state["sd"][key.split(":d:")[1]].grad, T(key), torch.float32, key, factor=3)
+        check(x0.grad if x0.grad is not None else torch.zeros_like(x0), T(f"{name}:dx0"), torch.float32, f"{name}: dx0", factor=3)
