@@ -1,5 +1,7 @@
 """ORACLE (test infrastructure, never imported by the product): CPU fp32 restatement of one CoMat optimisation step,
-`training_script.py:556-694`, composed from oracle/sd.py, oracle/blip.py and oracle/losses.py.  This is also the
+`training_script.py:556-694`, composed from oracle/sd.py, oracle/blip.py and oracle/losses.py.  PINNED by the reference's own
+loop body executed on stand-in networks (tests/golden/step_body.npz, tests/test_oracle.py::
+test_whole_step_matches_the_reference_loop_body): gradients, both parameter updates, logged loss terms.  This is also the
 "reference CPU path" timed by bench.py's `cpu_baseline` leg (kind "port": the reference's own Python cannot run here —
 diffusers / torchvision / weights are absent)."""
 from __future__ import annotations
