@@ -40,9 +40,12 @@ class ToyLatentUNet(nn.Module):
         self.mid_block = toy.Block(dim, ctx_dim, heads, 1)
         self.up_blocks = toy.Block(dim, ctx_dim, heads, 1)
 
-    def forward(self, latents, t, encoder_hidden_states=None, cross_attention_kwargs=None, return_dict=False):
+    def forward(self, latents, t, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                return_dict=False):
         B, C, h, w = latents.shape
         x = self.inp(latents.permute(0, 2, 3, 1).reshape(B, h * w, C)) * (1.0 + 1e-3 * float(t))
+        if added_cond_kwargs is not None:  # SDXL: a per-sample shift from the pooled embedding and the size / crop ids
+            x = x + (added_cond_kwargs["text_embeds"].mean(dim=1) + 1e-3 * added_cond_kwargs["time_ids"].float().sum(dim=1)).reshape(B, 1, 1)
         a = self.down_blocks(x, encoder_hidden_states)
         m = a.reshape(B, h // 2, 2, w // 2, 2, -1).mean(dim=(2, 4)).reshape(B, (h // 2) * (w // 2), -1)
         m = self.mid_block(m, encoder_hidden_states)
@@ -51,14 +54,14 @@ class ToyLatentUNet(nn.Module):
         return (self.outp(c).reshape(B, h, w, C).permute(0, 3, 1, 2),)
 
 
-def reference_methods():
-    src = open(os.path.join(REF, "AttrConcenTrainableSDPipeline.py")).read()
-    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == "AttrConcenTrainableSDPipeline")
+def reference_methods(file="AttrConcenTrainableSDPipeline.py", cls_name="AttrConcenTrainableSDPipeline"):
+    src = open(os.path.join(REF, file)).read()
+    cls = next(n for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == cls_name)
     ns = {"torch": torch, "Union": Union, "List": List, "Optional": Optional, "Callable": Callable, "Dict": Dict, "Any": Any,
           "Tuple": Tuple, "get_cross_attn_map_from_unet": toy.ref_attn.get_cross_attn_map_from_unet}
     for name in ("forward", "_attrcon_forward"):
         fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == name)
-        exec(compile(textwrap.dedent(ast.get_source_segment(src, fn)), f"AttrConcenTrainableSDPipeline.py:{name}", "exec"), ns)
+        exec(compile(textwrap.dedent(ast.get_source_segment(src, fn)), f"{file}:{name}", "exec"), ns)
     return ns["forward"], ns["_attrcon_forward"]
 
 
@@ -113,6 +116,45 @@ def main():
         loss.backward()
         out[f"{name}:train"], out[f"{name}:attr"], out[f"{name}:map_keys"] = np.array(train), np.array(attr), np.array(keys)
         out[f"{name}:image"], out[f"{name}:latents"] = image.detach(), latents.detach()
+        out[f"{name}:dx0"] = x0.grad.clone() if x0.grad is not None else torch.zeros_like(x0)
+        for wname in watch:
+            out[f"{name}:d:{wname}"] = dict(net.named_parameters())[wname].grad.clone()
+        print(name, "trained", train, "drawn", attr, "-> captured", keys)
+    # ---- SDXL (AttrConcenTrainableSDXLPipeline.py:234-496): the added conditioning is cut in halves with the batch, the UNet
+    # input is detached on every step, latents.half() are decoded and returned raw
+    forward_xl, attrcon_forward_xl = reference_methods("AttrConcenTrainableSDXLPipeline.py", "AttrConcenTrainableSDXLPipeline")
+    pooled, npooled = torch.randn(bs, 5, generator=g), torch.randn(bs, 5, generator=g)
+    out.update(pooled=pooled, npooled=npooled, xl_scaling_factor=np.float64(0.13025))
+    for name, train, attr in (("xa", [1, 3], [3]), ("xb", [0, 2, 4], [2, 0])):
+        net.zero_grad()
+        x0 = lat0.clone().requires_grad_(True)
+        self = types.SimpleNamespace(_execution_device=torch.device("cpu"), unet=net, scheduler=base.StubScheduler(noises),
+                                     controller=store, attn_dict={}, parser=lambda p: None)
+        self._attrcon_forward = lambda *a, **k: attrcon_forward_xl(self, *a, **k)
+        self.encode_prompt = lambda **kw: (kw["prompt_embeds"], kw["negative_prompt_embeds"], kw["pooled_prompt_embeds"],
+                                           kw["negative_pooled_prompt_embeds"])
+        self.prepare_latents = lambda b, c, hh, ww, dtype, device, generator, latents: latents
+        self.prepare_extra_step_kwargs = lambda generator, eta: {}
+        self._get_add_time_ids = lambda osz, crop, tsz, dtype=None: torch.tensor([list(osz) + list(crop) + list(tsz)], dtype=dtype)
+        self.vae = types.SimpleNamespace(config=types.SimpleNamespace(scaling_factor=0.13025),
+                                         decode=lambda z, return_dict=False: (torch.einsum("oc,bchw->bohw", V.to(z.dtype), z),))
+        prev = torch.is_grad_enabled()
+        image, latents = forward_xl(self, prompt=["p0", "p1"], height=8 * h, width=8 * w, training_timesteps=list(train),
+                                    detach_gradient=True, num_inference_steps=N, guidance_scale=7.5, latents=x0 * 1.0,
+                                    prompt_embeds=cond, negative_prompt_embeds=uncond, pooled_prompt_embeds=pooled,
+                                    negative_pooled_prompt_embeds=npooled, return_latents=True, attrcon_train_steps=list(attr))
+        torch.set_grad_enabled(prev)
+        loss = (image.float() * gimg).sum() + (latents.float() * glat).sum()
+        keys = []
+        for ts in sorted(self.attn_dict):
+            for place in sorted(self.attn_dict[ts]):
+                for i, m in enumerate(self.attn_dict[ts][place]):
+                    keys.append(f"{ts}:{place}:{i}")
+                    out[f"{name}:map:{ts}:{place}:{i}"] = m.detach().clone()
+                    loss = loss + 3.0 * (m ** 2).sum()
+        loss.backward()
+        out[f"{name}:train"], out[f"{name}:attr"], out[f"{name}:map_keys"] = np.array(train), np.array(attr), np.array(keys)
+        out[f"{name}:image"], out[f"{name}:latents"] = image.detach().float(), latents.detach().float()
         out[f"{name}:dx0"] = x0.grad.clone() if x0.grad is not None else torch.zeros_like(x0)
         for wname in watch:
             out[f"{name}:d:{wname}"] = dict(net.named_parameters())[wname].grad.clone()

@@ -418,3 +418,60 @@ def test_attrcon_sampler_branch_against_the_reference(sim):
         for key in [k for k in gold.files if k.startswith(f"{name}:d:")]:
             check(state["sd"][key.split(":d:")[1]].grad, T(key), torch.float32, key, factor=3)
         check(x0.grad if x0.grad is not None else torch.zeros_like(x0), T(f"{name}:dx0"), torch.float32, f"{name}: dx0", factor=3)
+
+
+def test_sdxl_attrcon_sampler_branch_against_the_reference(sim):
+    """the product's SDXL sampler with attribute-concentration steps against cases xa / xb of
+    tests/golden/attrcon_sampler.npz (the reference's own `AttrConcenTrainableSDXLPipeline.forward` + `_attrcon_forward`)."""
+    import types
+
+    import numpy as np
+
+    from comat_amd.pipeline import TrainableSDXLPipeline
+    from test_oracle import _toy_latent_unet
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "attrcon_sampler.npz"))
+    T = lambda k: torch.from_numpy(gold[k])
+    V, n, layers, heads = T("V"), int(gold["n_steps"]), [str(s) for s in gold["layers"]], int(gold["heads"])
+    bs, _, h, w = gold["latents"].shape
+    state = {}
+
+    def unet(x, B, H, W_, t, ctx, L_, capture_places=(), added=None, kv_cache=None):
+        got = {p: [] for p in capture_places}
+
+        def capture(probs, is_cross, place):
+            if is_cross and place in got:
+                got[place].append(probs.reshape(B, heads, probs.shape[1], probs.shape[2]))
+            return probs
+        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None, added)
+        return tok(y), got
+    unet.dtype, unet.device = torch.float32, sim
+    unet.cfg = types.SimpleNamespace(addition_embed=True)
+    unet.added_embedding = lambda text_embeds, ids: (text_embeds, torch.tensor(ids, dtype=torch.float32))
+
+    def vae(z, B, H, W_):
+        return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
+    vae.cfg = types.SimpleNamespace(scaling_factor=float(gold["xl_scaling_factor"]))
+    pipe = TrainableSDXLPipeline(unet, vae)
+    for name in ("xa", "xb"):
+        state["sd"] = {k[2:]: T(k).clone().requires_grad_(True) for k in gold.files if k.startswith("w:")}
+        x0 = T("latents").clone().requires_grad_(True)
+        image, latents = pipe.forward(T("cond"), T("uncond"), height=8 * h, width=8 * w,
+                                      training_timesteps=[int(i) for i in gold[f"{name}:train"]], num_inference_steps=n,
+                                      guidance_scale=7.5, latents=x0 * 1.0, noises=list(T("noises")), return_latents=True,
+                                      attrcon_train_steps=[int(i) for i in gold[f"{name}:attr"]], train_layer_ls=layers,
+                                      pooled_prompt_embeds=T("pooled"), negative_pooled_prompt_embeds=T("npooled"))
+        loss = (image * T("gimg")).sum() + (latents * T("glat")).sum()
+        keys = []
+        for ts in sorted(pipe.attn_dict):
+            for place in sorted(pipe.attn_dict[ts]):
+                for i, m in enumerate(pipe.attn_dict[ts][place]):
+                    keys.append(f"{ts}:{place}:{i}")
+                    check(m, T(f"{name}:map:{ts}:{place}:{i}"), torch.float32, f"{name}: map {keys[-1]}")
+                    loss = loss + 3.0 * (m ** 2).sum()
+        assert keys == [str(k) for k in gold[f"{name}:map_keys"]], (name, keys)
+        loss.backward()
+        for got, key, tol in [(image, "image", 2e-3), (latents, "latents", 2e-3),
+                              (x0.grad if x0.grad is not None else torch.zeros_like(x0), "dx0", 2e-2)] + \
+                             [(state["sd"][k.split(":d:")[1]].grad, k.split(":", 1)[1], 2e-2) for k in gold.files if k.startswith(f"{name}:d:")]:
+            ref = T(f"{name}:{key}")
+            assert (got - ref).abs().max() <= tol * (ref.abs().max() + 1e-6), (name, key, float((got - ref).abs().max()))
