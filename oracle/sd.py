@@ -1,11 +1,11 @@
 """ORACLE (test infrastructure, never imported by the product): CPU fp32 restatement of the Stable-Diffusion part of
 the CoMat hot path in plain PyTorch ops, NCHW like the reference stack.
 
-PARITY UNPINNED at the diffusers boundary: the arithmetic below (UNet2DConditionModel, AutoencoderKL.decode,
-DDPMScheduler, LoRALinearLayer, Attention) lives in `diffusers>=0.22.1` (requirements.txt:6), which is neither
-vendored under /root/reference nor installable here, and no reference test pins its outputs.  The restatement
-follows the published architecture and is anchored on the reference's own call
-sites:
+PARITY UNPINNED FOR THE UNET'S LAYER ARITHMETIC (everything else in this file is pinned, see below): the arithmetic of
+UNet2DConditionModel, AutoencoderKL.decode, DDPMScheduler, LoRALinearLayer and Attention lives in `diffusers>=0.22.1`
+(requirements.txt:6), which is neither vendored under /root/reference nor installable here, and no reference test pins
+its outputs.  The restatement follows the published architecture and is anchored on the
+reference's own call sites:
   - UNet call + CFG + scheduler step: TrainableSDPipeline.py:132-167
   - attention math as patched by the reference (naive softmax(scale QK^T) V, no mask, probs exposed to a
     controller when they require grad): attn_utils/tc_attn_utils.py:104-161
