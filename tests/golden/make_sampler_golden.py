@@ -81,7 +81,7 @@ def main():
     gimg, glat = torch.randn(bs, 3, h, w, generator=g), torch.randn(bs, 4, h, w, generator=g)
     out = dict(W=W0, V=V, latents=lat0, noises=torch.stack(noises), cond=cond, uncond=uncond, gimg=gimg, glat=glat,
                n_steps=np.int64(N), scaling_factor=np.float64(0.18215))
-    cases = {"a": [1, 3], "b": [0, 1, 2, 3, 4], "c": [4]}
+    cases = {"a": [1, 3], "b": [0, 1, 2, 3, 4], "c": [4], "d": []}  # d: no trained step (sampling only: validation, GT latents)
     for name, train in cases.items():
         Wp = W0.clone().requires_grad_(True)
         x0 = lat0.clone().requires_grad_(True)
@@ -107,13 +107,13 @@ def main():
         out[f"{name}:train"] = np.array(train)
         out[f"{name}:image"] = image.detach()
         out[f"{name}:latents"] = latents.detach()
-        out[f"{name}:dW"] = Wp.grad.clone()
+        out[f"{name}:dW"] = Wp.grad.clone() if Wp.grad is not None else torch.zeros_like(Wp)
         out[f"{name}:dx0"] = x0.grad.clone() if x0.grad is not None else torch.zeros_like(x0)
         out[f"{name}:unet_grad_mode"] = np.array([c[1] for c in calls])
         out[f"{name}:unet_input_requires_grad"] = np.array([c[2] for c in calls])
         out[f"{name}:t"] = np.array([c[0] for c in calls])
         print(name, train, "t", [c[0] for c in calls], "grad mode", [int(c[1]) for c in calls], "input grad", [int(c[2]) for c in calls],
-              "|dW|", float(Wp.grad.norm()), "|dx0|", float(out[f"{name}:dx0"].norm()))
+              "|dW|", float(out[f"{name}:dW"].norm()), "|dx0|", float(out[f"{name}:dx0"].norm()))
     # ---- SDXL (TrainableSDPipeline.py:657-846): pooled text embedding + size / crop ids as added conditioning, the UNet
     # input detached on EVERY step, latents.half() decoded and returned raw (no / 2 + 0.5) with return_latents
     forward_xl = reference_forward("TrainableSDXLPipeline")

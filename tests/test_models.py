@@ -297,7 +297,7 @@ def test_sampler_loop_against_the_reference_loop(sim):
         return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
     vae.cfg = types.SimpleNamespace(scaling_factor=float(gold["scaling_factor"]))
     pipe = TrainableSDPipeline(unet, vae)
-    for name in "abc":
+    for name in "abcd":
         calls.clear()
         state["W"] = T("W").clone().requires_grad_(True)
         x0 = T("latents").clone().requires_grad_(True)
@@ -307,7 +307,8 @@ def test_sampler_loop_against_the_reference_loop(sim):
         ((image * T("gimg")).sum() + (latents * T("glat")).sum()).backward()
         check(image, T(f"{name}:image"), torch.float32, f"{name}: image")
         check(latents, T(f"{name}:latents"), torch.float32, f"{name}: latents")
-        check(state["W"].grad, T(f"{name}:dW"), torch.float32, f"{name}: dW", factor=3)
+        check(state["W"].grad if state["W"].grad is not None else torch.zeros_like(state["W"]), T(f"{name}:dW"), torch.float32,
+              f"{name}: dW", factor=3)
         check(x0.grad if x0.grad is not None else torch.zeros_like(x0), T(f"{name}:dx0"), torch.float32, f"{name}: dx0", factor=3)
         assert [c[0] for c in calls] == list(gold[f"{name}:t"])
         assert [c[1] for c in calls] == list(gold[f"{name}:unet_grad_mode"]), name
