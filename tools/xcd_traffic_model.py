@@ -119,5 +119,25 @@ def main():
               f"{r['best'] / 1e6:12.1f}   {r['sig'][:110]}")
 
 
+def validate():
+    """the model against the two GEMM-family probes of the counter passes (profiles/r03_pmc_kernels.json, tools/pmc_targets.py)"""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_kernels.json")
+    if not os.path.exists(path):
+        return
+    d = json.load(open(path))
+    probes = {"conv 3x3 B=2 64x64 320->320": (8192, 320, 2880, ("conv", 320, 3)),
+              "GEGLU projection 8192x2560x320": (8192, 2560, 320, None)}
+    print("# model against measured FETCH_SIZE x 2 of the counter probes (reads only):")
+    for k, v in d.items():
+        if isinstance(v, dict) and v.get("probe") in probes:
+            M, N, K, conv = probes[v["probe"]]
+            mod = traffic(M, N, K, conv, "n")
+            print(f"#   {v['probe']:34s} measured {v['hbm_read_bytes'] / 1e6:6.1f} MB   modelled {mod / 1e6:6.1f} MB   "
+                  f"algorithmic reads {((M * (conv[1] if conv else K)) + N * K) * 2 / 1e6:6.1f} MB")
+
+
 if __name__ == "__main__":
     main()
+    validate()
