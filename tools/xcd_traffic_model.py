@@ -15,13 +15,13 @@ conv problem of a step (128 x 128 tiles, or 64 x 64 where a dimension is below 1
 operands' rows / columns but not their k-range, so they do not add re-reads) for the kernel's order and for the
 column-block-major order, and reports what a per-problem choice of the better one would save.
 
-Round 3 reading (profiles/r03_z_xcd_traffic_model.txt): the model gives 31.7 MB per launch for the kernel's order against 40.4
+Round 3 reading (profiles/r03_z_xcd_traffic_model.txt): the model gives 31.4 MB per launch for the kernel's order against 40.4
 MB measured and 14.2 MB algorithmic, i.e. it accounts for two thirds of the excess (the rest: 64-wide tiles where the plan
 table picks them, conv halos, evictions).  The modelled excess is overwhelmingly WEIGHT panels fetched by several XCDs in the
 short, wide problems of the deep UNet levels and of the feed-forward projections (M = 512 .. 2048 rows against N = 1280 ..
 10240 columns: a 16 x 16-level 3x3 conv moves 123 MB for 32 MB of operands, its 29.5 MB of weights four times), where
 row-block-major order gives every XCD a slice of ALL columns.  Column-block-major order for those problems (each XCD: all row
-blocks of its share of the columns) halves their traffic (modelled average 31.7 -> 24.9 MB; 834 launches, 23.8 ms of the
+blocks of its share of the columns) halves their traffic (modelled average 31.4 -> 24.6 MB; 834 launches, 23.8 ms of the
 step); it is a 3-line change of the index decode with bit-identical results - the next round's first kernel experiment
 (DESIGN.md section 9)."""
 import re
@@ -62,8 +62,9 @@ def traffic(M, N, K, conv, tiles_first):
     BM = 128 if M >= 128 else 64
     BN = 128 if N >= 128 else 64
     tm, tn = -(-M // BM), -(-N // BN)
-    a_block = (BM * conv[1] * 2 * (1.25 if conv[2] == 3 else 1.0)) if conv else BM * K * 2
-    b_block = BN * K * 2
+    a_row = (conv[1] * 2 * (1.25 if conv[2] == 3 else 1.0)) if conv else K * 2   # bytes of one A row
+    b_col = K * 2                                                                  # bytes of one B column (a weight row)
+    span = lambda lo, hi, blk, n: min(n, (hi + 1) * blk) - lo * blk                # real rows / columns of blocks lo..hi
     items = tm * tn
     q, r = divmod(items, 8)
     total, start = 0.0, 0
@@ -74,12 +75,12 @@ def traffic(M, N, K, conv, tiles_first):
         lo, hi = start, start + n_items - 1
         start += n_items
         if tiles_first == "n":  # lin = tm_i * tn + tn_i
-            rows = hi // tn - lo // tn + 1
-            cols = tn if rows > 1 else (hi % tn - lo % tn + 1)
+            rows = span(lo // tn, hi // tn, BM, M)
+            cols = N if hi // tn > lo // tn else span(lo % tn, hi % tn, BN, N)
         else:                   # lin = tn_i * tm + tm_i
-            cols = hi // tm - lo // tm + 1
-            rows = tm if cols > 1 else (hi % tm - lo % tm + 1)
-        total += rows * a_block + cols * b_block
+            cols = span(lo // tm, hi // tm, BN, N)
+            rows = M if hi // tm > lo // tm else span(lo % tm, hi % tm, BM, M)
+        total += rows * a_row + cols * b_col
     return total
 
 
