@@ -83,7 +83,7 @@ def test_resize_masks_matches_dense_operator():
         assert np.array_equal(losses.resize_masks(m, res), (ref > 0).astype(np.float32).reshape(3, -1))
 
 
-def test_mask_loss_against_the_reference_assembly(sim):
+def test_mask_loss_against_the_reference_assembly(dev):
     """the PRODUCT's attribute-concentration loss (gather kernel of the C ABI on its CPU simulator, host assembly of
     comat_amd/losses.py, noun / attribute lists of comat_amd/attr_index.py) against tests/golden/mask_loss.npz = the totals of
     the reference's own `get_mask_loss` (see tests/test_oracle.py::test_mask_loss_assembly_matches_reference)."""
@@ -104,8 +104,8 @@ def test_mask_loss_against_the_reference_assembly(sim):
     for key in d.files:
         if key.startswith("map:"):
             _, ts, place = key.split(":")
-            attn_dict.setdefault(ts, {})[place] = [torch.from_numpy(m).to(sim) for m in d[key]]
+            attn_dict.setdefault(ts, {})[place] = [torch.from_numpy(m).to(dev) for m in d[key]]
     masks = [np.concatenate([d[f"mask:{n}"][0] for n in nouns]) if "tree" not in nouns else None for nouns, _ in got]
-    tl, pl = mask_loss(attn_dict, masks, [a for _, a in got], layers, bs, sim)
+    tl, pl = mask_loss(attn_dict, masks, [a for _, a in got], layers, bs, dev)
     assert abs(float(tl) - float(d["token_loss"])) < 2e-5 * max(1.0, abs(float(d["token_loss"])))
     assert abs(float(pl) - float(d["pixel_loss"])) < 2e-5 * max(1.0, abs(float(d["pixel_loss"])))

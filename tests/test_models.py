@@ -229,7 +229,7 @@ def test_nograd_merged_lora_weights_in_the_sampler(sim, dtype, monkeypatch):
     assert rel_l2(res[1][2], res[0][2]) < (1e-4 if dtype == torch.float32 else 0.15)
 
 
-def test_vae_decoder_against_third_party_ldm_decoder(sim):
+def test_vae_decoder_against_third_party_ldm_decoder(dev):
     """the PRODUCT's VAE decoder (host code over the C ABI, here on the CPU simulator of the ABI) against the decoder of
     transformers' Janus VQ-VAE - an independent implementation of the latent-diffusion decoder AutoencoderKL ports - on the
     same weights under diffusers' names (see tests/test_oracle.py::test_vae_decoder_matches_a_third_party_ldm_decoder for
@@ -258,16 +258,16 @@ def test_vae_decoder_against_third_party_ldm_decoder(sim):
     z1 = z.clone().requires_grad_(True)
     want = dec(z1 * 1.0)
     (want * g).sum().backward()
-    vae = VAEDecoder(vcfg, vsd, torch.float32, sim)
-    zd = tok(z).to(sim).requires_grad_(True)
+    vae = VAEDecoder(vcfg, vsd, torch.float32, dev)
+    zd = tok(z).to(dev).requires_grad_(True)
     img, H, W = vae(zd, B, h, w)
     assert (H, W) == (4 * h, 4 * w)
-    (img * tok(g)).sum().backward()
+    (img * tok(g).to(dev)).sum().backward()
     check(img, tok(want), torch.float32, "product VAE decoder vs transformers' LDM decoder")
     check(zd.grad, tok(z1.grad), torch.float32, "latent gradient", factor=3)
 
 
-def test_sampler_loop_against_the_reference_loop(sim):
+def test_sampler_loop_against_the_reference_loop(dev):
     """the PRODUCT's K-of-N sampler (comat_amd/pipeline.py over the fused CFG + DDPM step of the C ABI, here on its CPU
     simulator) against tests/golden/sampler_loop.npz = the reference's own `TrainableSDPipeline.forward` run on stand-ins
     (tests/test_oracle.py::test_sampler_loop_matches_reference): the same stand-in 'UNet' / 'VAE' in the product's
@@ -277,7 +277,7 @@ def test_sampler_loop_against_the_reference_loop(sim):
 
     import numpy as np
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_loop.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
     V, n = T("V"), int(gold["n_steps"])
     bs, _, h, w = gold["latents"].shape
     L = gold["cond"].shape[1]
@@ -290,7 +290,7 @@ def test_sampler_loop_against_the_reference_loop(sim):
         shift = c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
         y = torch.tanh(torch.einsum("oc,bchw->bohw", state["W"], xn)) * (1.0 + 1e-3 * float(t)) + 0.3 * shift + 0.1 * xn.roll(1, dims=3)
         return tok(y), {}
-    unet.dtype, unet.device = torch.float32, sim
+    unet.dtype, unet.device = torch.float32, dev
     unet.cfg = types.SimpleNamespace(addition_embed=False)
 
     def vae(z, B, H, W_):
@@ -315,7 +315,7 @@ def test_sampler_loop_against_the_reference_loop(sim):
         assert [c[2] for c in calls] == list(gold[f"{name}:unet_input_requires_grad"]), name
 
 
-def test_sdxl_sampler_loop_against_the_reference_loop(sim):
+def test_sdxl_sampler_loop_against_the_reference_loop(dev):
     """the product's SDXL sampler against the reference's own `TrainableSDXLPipeline.forward` run on stand-ins
     (tests/golden/sampler_loop.npz cases xa / xb; see tests/test_oracle.py::test_sdxl_sampler_loop_matches_reference for what
     they pin and why the bounds are 2e-3 / 2e-2: the reference runs its tail in fp16)."""
@@ -325,7 +325,7 @@ def test_sdxl_sampler_loop_against_the_reference_loop(sim):
 
     from comat_amd.pipeline import TrainableSDXLPipeline
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampler_loop.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
     V, n = T("V"), int(gold["n_steps"])
     bs, _, h, w = gold["latents"].shape
     calls, state = [], {}
@@ -339,9 +339,9 @@ def test_sdxl_sampler_loop_against_the_reference_loop(sim):
         y = (torch.tanh(torch.einsum("oc,bchw->bohw", state["W"], xn)) * (1.0 + 1e-3 * float(t)) + 0.3 * shift
              + 0.1 * xn.roll(1, dims=3) + 0.2 * extra)
         return tok(y), {}
-    unet.dtype, unet.device = torch.float32, sim
+    unet.dtype, unet.device = torch.float32, dev
     unet.cfg = types.SimpleNamespace(addition_embed=True)
-    unet.added_embedding = lambda text_embeds, ids: (text_embeds, torch.tensor(ids, dtype=torch.float32))
+    unet.added_embedding = lambda text_embeds, ids: (text_embeds.to(dev), torch.tensor(ids, dtype=torch.float32, device=dev))
 
     def vae(z, B, H, W_):
         return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_
@@ -364,7 +364,7 @@ def test_sdxl_sampler_loop_against_the_reference_loop(sim):
         assert [c[1] for c in calls] == [False] * n, name
 
 
-def test_attrcon_sampler_branch_against_the_reference(sim):
+def test_attrcon_sampler_branch_against_the_reference(dev):
     """the product's sampler with attribute-concentration steps against the reference's own
     `AttrConcenTrainableSDPipeline.forward` + `_attrcon_forward` run on a toy UNet (tests/golden/attrcon_sampler.npz; see
     tests/test_oracle.py::test_attrcon_sampler_branch_matches_reference).  The product sends the joint CFG batch through
@@ -374,9 +374,9 @@ def test_attrcon_sampler_branch_against_the_reference(sim):
 
     import numpy as np
 
-    from test_oracle import _toy_latent_unet
+    from test_oracle import _plain_attention, _toy_latent_unet
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "attrcon_sampler.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
     V, n, layers, heads = T("V"), int(gold["n_steps"]), [str(s) for s in gold["layers"]], int(gold["heads"])
     bs, _, h, w = gold["latents"].shape
     state = {}
@@ -388,9 +388,10 @@ def test_attrcon_sampler_branch_against_the_reference(sim):
             if is_cross and place in got:
                 got[place].append(probs.reshape(B, heads, probs.shape[1], probs.shape[2]))
             return probs
-        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None)
+        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None,
+                             attention=_plain_attention)
         return tok(y), got
-    unet.dtype, unet.device = torch.float32, sim
+    unet.dtype, unet.device = torch.float32, dev
     unet.cfg = types.SimpleNamespace(addition_embed=False)
 
     def vae(z, B, H, W_):
@@ -421,7 +422,7 @@ def test_attrcon_sampler_branch_against_the_reference(sim):
         check(x0.grad if x0.grad is not None else torch.zeros_like(x0), T(f"{name}:dx0"), torch.float32, f"{name}: dx0", factor=3)
 
 
-def test_sdxl_attrcon_sampler_branch_against_the_reference(sim):
+def test_sdxl_attrcon_sampler_branch_against_the_reference(dev):
     """the product's SDXL sampler with attribute-concentration steps against cases xa / xb of
     tests/golden/attrcon_sampler.npz (the reference's own `AttrConcenTrainableSDXLPipeline.forward` + `_attrcon_forward`)."""
     import types
@@ -429,9 +430,9 @@ def test_sdxl_attrcon_sampler_branch_against_the_reference(sim):
     import numpy as np
 
     from comat_amd.pipeline import TrainableSDXLPipeline
-    from test_oracle import _toy_latent_unet
+    from test_oracle import _plain_attention, _toy_latent_unet
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "attrcon_sampler.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
     V, n, layers, heads = T("V"), int(gold["n_steps"]), [str(s) for s in gold["layers"]], int(gold["heads"])
     bs, _, h, w = gold["latents"].shape
     state = {}
@@ -443,11 +444,12 @@ def test_sdxl_attrcon_sampler_branch_against_the_reference(sim):
             if is_cross and place in got:
                 got[place].append(probs.reshape(B, heads, probs.shape[1], probs.shape[2]))
             return probs
-        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None, added)
+        y = _toy_latent_unet(state["sd"], untok(x, B, H, W_), t, ctx.reshape(B, L_, -1), capture if capture_places else None, added,
+                             attention=_plain_attention)
         return tok(y), got
-    unet.dtype, unet.device = torch.float32, sim
+    unet.dtype, unet.device = torch.float32, dev
     unet.cfg = types.SimpleNamespace(addition_embed=True)
-    unet.added_embedding = lambda text_embeds, ids: (text_embeds, torch.tensor(ids, dtype=torch.float32))
+    unet.added_embedding = lambda text_embeds, ids: (text_embeds.to(dev), torch.tensor(ids, dtype=torch.float32, device=dev))
 
     def vae(z, B, H, W_):
         return tok(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_))), H, W_

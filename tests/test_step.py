@@ -427,7 +427,7 @@ def test_loss_composition_matches_the_reference_statements(sim, monkeypatch, gan
     assert abs(float(out["loss"]) - case["loss"]) < 1e-6, (float(out["loss"]), case)
 
 
-def test_trainer_step_against_the_reference_loop_body(sim):
+def test_trainer_step_against_the_reference_loop_body(dev):
     """the PRODUCT's `CoMatTrainer.train_step` (host orchestration, fused CFG + DDPM op, discriminator head kernel, clip +
     AdamW kernel - here on the CPU simulator of the C ABI) against tests/golden/step_body.npz = one optimisation step as the
     reference's OWN loop body runs it (training_script.py:553-694 executed on stand-in networks, see
@@ -439,13 +439,13 @@ def test_trainer_step_against_the_reference_loop_body(sim):
     from comat_amd.gan import D_sd
     from helpers import tok, untok
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "step_body.npz"))
-    T = lambda k: torch.from_numpy(gold[k])
+    T = lambda k: torch.from_numpy(gold[k]).to(dev)
     V, n = T("V"), int(gold["n_steps"])
     up = torch.nn.Upsample(scale_factor=8, mode="nearest")
 
     class FlatBank:  # one flat fp32 parameter buffer with a preallocated gradient buffer, as LoRABank exposes them
         def __init__(self, init):
-            self.flat = init.reshape(-1).clone()          # what the optimizer kernel updates in place
+            self.flat = init.reshape(-1).clone().to(dev)  # what the optimizer kernel updates in place
             self.flat_grad = torch.zeros_like(self.flat)
             self.w = self.flat.view(4, 4).requires_grad_(True)   # the leaf the network reads: a view of the buffer whose
             self.w.grad = self.flat_grad.view(4, 4)               # gradient accumulates into the flat gradient buffer
@@ -472,7 +472,7 @@ def test_trainer_step_against_the_reference_loop_body(sim):
         shift = c.mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
         return tok(torch.einsum("oc,bchw->bohw", dbank.w, xn) + shift + 0.01 * float(t) * xn.flip(1)), {}
     for f in (unet, d_unet):
-        f.dtype, f.device, f.cfg = torch.float32, sim, types.SimpleNamespace(addition_embed=False)
+        f.dtype, f.device, f.cfg = torch.float32, dev, types.SimpleNamespace(addition_embed=False)
 
     def vae(z, B, H, W_):
         return tok(up(torch.einsum("oc,bchw->bohw", V, untok(z, B, H, W_)))), 8 * H, 8 * W_
@@ -481,26 +481,27 @@ def test_trainer_step_against_the_reference_loop_body(sim):
     def score(img, B, H, W_, ids, mask, crop=None, label_smoothing=None):
         y0, x0, ch, cw = crop
         c = untok(img, B, H, W_)[:, :, y0:y0 + ch, x0:x0 + cw]
-        ramp = torch.linspace(0.5, 1.5, cw).reshape(1, 1, 1, -1) * torch.linspace(1.2, 0.8, ch).reshape(1, 1, -1, 1)
-        return (-((c * ramp) ** 2).mean(dim=(1, 2, 3))).mean(), torch.zeros(B, 1)
+        ramp = (torch.linspace(0.5, 1.5, cw).reshape(1, 1, 1, -1) * torch.linspace(1.2, 0.8, ch).reshape(1, 1, -1, 1)).to(dev)
+        return (-((c * ramp) ** 2).mean(dim=(1, 2, 3))).mean(), torch.zeros(B, 1, device=dev)
     cfg = StepConfig(resolution=int(gold["resolution"]), total_step=n, K=int(gold["K"]), gan_loss=True, attrcon=False)
     disc = D_sd(d_unet, dbank, T("head_w0"), T("head_b0"))
     tr = CoMatTrainer(TrainableSDPipeline(unet, vae), bank, types.SimpleNamespace(score=score), disc, cfg)
     batch = dict(prompt_embeds=T("cond"), negative_prompt_embeds=T("null"), gan_null_embeds=T("gan_null"), latents=T("latents"),
                  noises=list(T("noises")), real_latents=T("real"), blip_input_ids=torch.zeros(2, 3, dtype=torch.long),
                  blip_attention_mask=torch.ones(2, 3, dtype=torch.long))
+    to_cpu = lambda t: t.detach().float().cpu()
     ox, oy, size = (int(v) for v in gold["crop"])
     logs = tr.train_step(batch, training_steps=[int(i) for i in gold["training_steps"]], crop=(ox, oy, size, size))
-    clipped = lambda g, mx: g * min(1.0, mx / (float(g.norm()) + 1e-6))
-    close = lambda a, b, tol: (a - b).abs().max() <= tol * (b.abs().max() + 1e-12)
+    clipped = lambda g, mx: to_cpu(g) * min(1.0, mx / (float(g.norm()) + 1e-6))
+    close = lambda a, b, tol: (to_cpu(a) - to_cpu(b)).abs().max() <= tol * (to_cpu(b).abs().max() + 1e-12)
     assert close(clipped(bank.flat_grad, cfg.max_grad_norm).view(4, 4), T("gW"), 1e-3)
-    d_all = torch.cat([dbank.flat_grad, disc.head_grad])
+    d_all = torch.cat([dbank.flat_grad, disc.head_grad])  # (one clip norm over the discriminator's LoRA + head)
     d_clip = clipped(d_all, cfg.max_grad_norm_D)
     assert close(d_clip[:16].view(4, 4), T("gmix"), 1e-3) and close(d_clip[16:20].view(1, 4), T("ghead_w"), 1e-3)
     assert close(d_clip[20:], T("ghead_b"), 1e-3)
     for got, key, start in ((bank.flat.detach().view(4, 4), "W1", "W0"), (dbank.flat.detach().view(4, 4), "mix1", "mix0"),
                             (disc.head[:4].detach().view(1, 4), "head_w1", "head_w0"), (disc.head[4:].detach(), "head_b1", "head_b0")):
         step = (T(key) - T(start)).abs().max()
-        assert (got - T(key)).abs().max() <= 2e-3 * step, (key, float((got - T(key)).abs().max()), float(step))
+        assert (got.to(dev) - T(key)).abs().max() <= 2e-3 * step, (key, float((got - T(key)).abs().max()), float(step))
     assert abs(float(logs["step_loss"]) - float(gold["log:step_loss"])) < 1e-4 * abs(float(gold["log:step_loss"]))
     assert abs(float(logs["G_loss"]) - float(gold["log:G_loss"])) < 1e-4 and abs(float(logs["D_loss"]) - float(gold["log:D_loss"])) < 1e-4
