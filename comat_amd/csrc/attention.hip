@@ -17,6 +17,7 @@
 //   flash_dq    : same geometry as forward; D[q] = sum_d dO[q,d] O[q,d] (stored for flash_dkdv), dQ^T += K^T dS^T
 //   flash_dkdv  : block = 4 waves x 32 keys, loops over 32-query tiles; dV^T += dO^T P, dK^T += Q^T dS
 #include "common.h"
+#include "gemm_shared.h"
 #include <stdlib.h>
 #include <utility>
 
@@ -252,12 +253,28 @@ struct FlashArgs {
     int B, H, Nq, Nk, d;
     int64_t ldq, ldk, ldv, ldo;
     float scale;
+    int xcd;       // option flash_xcd: renumber the workgroups so that the blocks of one (batch, head) share an XCD
     int qsplit;    // dK/dV: number of query ranges (blockIdx.z) whose fp32 partials are summed by flash_kv_reduce
     float* part;   // [2][qsplit][B*H][Nk][d] fp32 partial dK / dV (qsplit > 1)
 };
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 // TR: the k-major operand (V here) is staged as a TRANSPOSED LDS image and read with aligned 8 / 16-byte loads
+// Hardware hands consecutive workgroups (x fastest, then y) to the 8 XCDs round-robin, so the blocks of one (batch, head)
+// - which all stream that head's K and V (Q and dO in dK/dV) - land on all 8 private L2s and each fetches the operands once:
+// 84 MB modelled, 89 MB measured for 2 x 8 heads 4 096^2 d = 40 against 21 MB algorithmic.  With
+// option flash_xcd the linear workgroup id goes through the chunk map of the GEMM kernels (gemm_shared.h): an XCD then owns a
+// contiguous, head-major range of blocks.  Which block computes which tile changes, nothing else: bit-identical.
+__device__ __forceinline__ void flash_block_xy(int xcd, int& bx, int& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    if (xcd) {
+        const int64_t lin = xcd_chunk_map((int64_t)blockIdx.y * gridDim.x + blockIdx.x, (int64_t)gridDim.x * gridDim.y);
+        bx = (int)(lin % gridDim.x);
+        by = (int)(lin / gridDim.x);
+    }
+}
+
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
@@ -269,15 +286,17 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     constexpr int ONE = G::TILE_BYTES + (SWT ? G::TT_BYTES : G::TILE_BYTES);
     constexpr bool DB = 2 * ONE <= 65536;
     __shared__ __attribute__((aligned(16))) char smem[DB ? 2 * ONE : ONE];
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
     char* Kt = smem;
     char* Vt = smem + G::TILE_BYTES;  // SWT: the transposed image of the V tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
-    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const int q = bx * 128 + wave * 32 + r;
 
     F qf[NK];
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
             }
-        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * a.scale + __logf(l);  // natural-log units
+        if (hh == 0) a.lse[((int64_t)by) * a.Nq + q] = m * a.scale + __logf(l);  // natural-log units
     }
 }
 
@@ -400,14 +419,16 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
     constexpr int PAIR = 2 * ONE;
     static_assert(2 * PAIR <= 65536, "two double-buffered tile pairs must fit the static LDS limit");
     __shared__ __attribute__((aligned(16))) char smem[2 * PAIR];
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
     char* cur = smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = blockIdx.y / a.H, h = blockIdx.y % a.H;
+    const int b = by / a.H, h = by % a.H;
     const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
     const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
     const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
     T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
-    const int q = blockIdx.x * 128 + wave * 32 + r;
+    const int q = bx * 128 + wave * 32 + r;
     F qf[NK];
     load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
     f32x16_t oT[G::NT32];
@@ -508,7 +529,7 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
             }
-        if (hh == 0) a.lse[((int64_t)blockIdx.y) * a.Nq + q] = m * a.scale + __logf(l);
+        if (hh == 0) a.lse[((int64_t)by) * a.Nq + q] = m * a.scale + __logf(l);
     }
 }
 
@@ -643,7 +664,9 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, in
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DQ];
-    flash_dq_body<T, DMAX, NK, TR>(a, smem, blockIdx.x, blockIdx.y);
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
+    flash_dq_body<T, DMAX, NK, TR>(a, smem, bx, by);
 }
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
@@ -812,7 +835,9 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DKDV];
-    flash_dkdv_body<T, DMAX, NK, TR>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
+    flash_dkdv_body<T, DMAX, NK, TR>(a, smem, bx, by, blockIdx.z);
 }
 
 // ---- backward with TWO 32-row tiles per iteration (bf16, hardware transpose reads; option flash_kt = 2) ---------------------
@@ -942,7 +967,9 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
 template <int DMAX, int NK>
 __global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DQ2];
-    flash_dq2_body<DMAX, NK>(a, smem, blockIdx.x, blockIdx.y);
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
+    flash_dq2_body<DMAX, NK>(a, smem, bx, by);
 }
 
 template <int DMAX, int NK>
@@ -1104,7 +1131,9 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
 template <int DMAX, int NK>
 __global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DKDV2];
-    flash_dkdv2_body<DMAX, NK>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx, by;
+    flash_block_xy(a.xcd, bx, by);
+    flash_dkdv2_body<DMAX, NK>(a, smem, bx, by, blockIdx.z);
 }
 
 // D[q] = sum_d dO[q, d] O[q, d] on its own: the prologue of the dQ bodies, statement for statement (same fragments, same
@@ -1289,6 +1318,7 @@ extern "C" int comat_flash_attn_fwd(const void* Q, const void* K, const void* V,
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.lse = lse;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    a.xcd = comat_option(COMAT_OPT_FLASH_XCD);
     const int rc = dtype == COMAT_BF16 ? dispatch<bf16_t>(a, false, (hipStream_t)stream)
                                        : dispatch<float>(a, false, (hipStream_t)stream);
     COMAT_REQUIRE(rc == 0, "comat_flash_attn_fwd: unsupported head dim");
@@ -1308,6 +1338,7 @@ extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V,
     a.dQ = dQ; a.dK = dK; a.dV = dV;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
+    a.xcd = comat_option(COMAT_OPT_FLASH_XCD);
     // few key blocks (cross-attention): cut the query loop into ranges so that the grid fills the chip
     a.qsplit = 1;
     a.part = ws;

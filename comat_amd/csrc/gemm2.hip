@@ -52,6 +52,8 @@ struct Args2 {
     int64_t M, N;
     int nkt;  // k-tiles in total
     int tiles_m, tiles_n, splits;
+    int order;  // 0: work items run column-block-fastest inside an XCD chunk (row-block-major), 1: row-block-fastest
+                // (column-block-major) - which operand's panels the 8 private L2s share (finish_launch picks per problem)
     int64_t ntiles;
     int64_t sC, sR, sBias;  // batch strides (elements)
     float* ws;
@@ -297,11 +299,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     unsigned lin = (unsigned)xcd_chunk_map(blockIdx.x, gridDim.x);
     const int sp = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.splits));
     lin /= (unsigned)g.splits;
-    const int64_t tile = __builtin_amdgcn_readfirstlane((int)lin);
-    const int tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
-    lin /= (unsigned)g.tiles_n;
-    const int tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
-    const int64_t z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
+    int tm, tn;
+    int64_t z;
+    if (g.order) {  // row blocks fastest: an XCD's chunk holds ALL row blocks of a few column blocks (weights stay put)
+        tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
+        lin /= (unsigned)g.tiles_m;
+        tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
+        z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_n));
+    } else {
+        tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
+        lin /= (unsigned)g.tiles_n;
+        tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
+        z = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
+    }
+    // the tile's slot in the split-K bookkeeping (slabs, ticket counter): the row-block-major number whatever the order
+    const int64_t tile = (z * g.tiles_m + tm) * g.tiles_n + tn;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int nkt_all = g.nkt / KSF;  // k-tiles of THIS kernel's size (the host guarantees divisibility)
     const int per = (nkt_all + g.splits - 1) / g.splits;
@@ -1100,6 +1112,43 @@ static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t 
     return 1;
 }
 
+// Which way should the work items of one XCD chunk run?  Each of the 8 XCDs has a private L2 and gets a contiguous eighth of
+// the items (xcd_chunk_map); an operand panel touched by k chunks is fetched k times.  Modelled L2-miss reads of the two
+// orders (tools/xcd_traffic_model.py; within 3 % of FETCH_SIZE on the counter probes): rows x |A row| + columns x |B column|
+// summed over the chunks.  Option g2_order: 0 = always row-block-major (rounds 1-3), 1 = always column-block-major,
+// 2 = whichever the model prefers by more than 10 %.
+static int tile_order(const Args2& a, bool conv, bool fp8, int bm, int bn) {
+    const int opt = comat_option(COMAT_OPT_G2_ORDER);
+    if (opt != 2) return opt == 1;
+    const int64_t tm = a.tiles_m, tn = a.tiles_n, items = tm * tn;
+    const double eb = fp8 ? 1.0 : 2.0;
+    const double a_row = conv ? a.Cin * eb * (a.KW == 3 ? 1.25 : 1.0) : (double)a.nkt * 64.0;  // bytes of one A row
+    const double b_col = (double)a.nkt * 64.0;                                               // bytes of one B column
+    double cost[2] = {0.0, 0.0};
+    const int64_t q = items / 8, r = items % 8;
+    int64_t start = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int64_t n = q + (x < r ? 1 : 0);
+        if (n == 0) continue;
+        const int64_t lo = start, hi = start + n - 1;
+        start += n;
+        auto span = [](int64_t l, int64_t h, int64_t blk, int64_t tot) {
+            return (h + 1) * blk < tot ? (h + 1) * blk - l * blk : tot - l * blk;
+        };
+        {   // order 0: lin = tm_i * tn + tn_i
+            const double rows = (double)span(lo / tn, hi / tn, bm, a.M);
+            const double cols = hi / tn > lo / tn ? (double)a.N : (double)span(lo % tn, hi % tn, bn, a.N);
+            cost[0] += rows * a_row + cols * b_col;
+        }
+        {   // order 1: lin = tn_i * tm + tm_i
+            const double cols = (double)span(lo / tm, hi / tm, bn, a.N);
+            const double rows = hi / tm > lo / tm ? (double)a.M : (double)span(lo % tm, hi % tm, bm, a.M);
+            cost[1] += rows * a_row + cols * b_col;
+        }
+    }
+    return cost[1] < 0.9 * cost[0];
+}
+
 static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws, int64_t ws_bytes, void* stream) {
     int c, s;
     plan2(conv, fp8, a.M, a.N, a.nkt, batch, ws ? ws_bytes : 0, &c, &s);
@@ -1118,6 +1167,7 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
     a.tiles_n = (int)cdiv64(a.N, d.bn);
     a.ntiles = (int64_t)a.tiles_m * a.tiles_n * batch;
     a.splits = s;
+    a.order = tile_order(a, conv, fp8, d.bm, d.bn);
     a.ws = (float*)ws;
     const int64_t blocks = a.ntiles * s;
     if (blocks >= (1ll << 31)) return 0;

@@ -62,6 +62,14 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // together hold <= 768 blocks, 2 always.  Same bits either way;
                                                           // 256^2 d=160: 70.6 -> 48.9 us, 2 x 8 x 4096^2 d=40 (1024 blocks):
                                                           // 395 -> 470 us (profiles/r03_m_mb_flash_merge.txt)
+    {"g2_order", "COMAT_G2_ORDER", 0, 0, false},          // pipelined GEMM / conv: order of the output tiles inside an XCD's
+                                                          // chunk: 0 row-block-major (rounds 1-3), 1 column-block-major,
+                                                          // 2 per problem by the L2-miss model (tools/xcd_traffic_model.py).
+                                                          // Same tiles, same arithmetic: bit-identical.  UNMEASURED (written
+                                                          // after round 3's GPU budget was spent).
+    {"flash_xcd", "COMAT_FLASH_XCD", 0, 0, false},        // fused attention: 1 = workgroups renumbered so that the blocks of one
+                                                          // (batch, head) run on ONE XCD (its K / V - Q / dO in dK/dV - are
+                                                          // fetched into one L2 instead of eight).  Bit-identical.  UNMEASURED.
 };
 }  // namespace
 

@@ -748,7 +748,7 @@ def _set_opts(**kw):
 def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
-    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, norm_fused=3)
+    _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=0, g2_order=0, norm_fused=3)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1044,6 +1044,66 @@ def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
     check(outs[1][2], back(qr, Nq), dtype, "flash dQ, two tiles per iteration", factor=3)
     check(outs[1][3], back(kr, Nk), dtype, "flash dK, two tiles per iteration", factor=3)
     check(outs[1][4], back(vr, Nk), dtype, "flash dV, two tiles per iteration", factor=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("splits", [0, 3])
+def test_gemm2_tile_order_is_bit_identical(hip, splits, default_opts):
+    """option g2_order: the output tiles of the pipelined kernel walked row-block-major (0), column-block-major (1) or as the
+    L2-miss model of the launcher prefers per problem (2) inside each XCD's chunk - which block computes which tile changes,
+    the arithmetic of a tile (and the slice order of its split-K combine) does not: same bits, for plain / batched /
+    K-segmented GEMMs, convs, ragged edges and forced split counts."""
+    dtype = torch.bfloat16
+    k = ops.kernels()
+    outs = {}
+    for order in (0, 1, 2):
+        _set_opts(gemm2=1, g2_order=order, g2_splits=splits)
+        res = []
+        for (M, N, K_, nb) in ((512, 1280, 1280, 1), (300, 200, 320, 1), (8192, 320, 320, 1), (577, 1024, 4096, 1),
+                               (2048, 384, 640, 3), (512, 10240, 1280, 1), (130, 96, 64, 2)):
+            A = dv(rnd(nb, M, K_, dtype=dtype, seed=1, scale=0.5), hip, dtype)
+            B = dv(rnd(nb, N, K_, dtype=dtype, seed=2, scale=0.5), hip, dtype)
+            out = torch.full((nb, M, N), float("nan"), dtype=dtype, device=hip)
+            k.gemm(A, B, out, M, N, K_, K_, K_, N, batch=(nb, 1), sA=(M * K_, 0), sB=(N * K_, 0), sC=(M * N, 0))
+            res.append(out)
+        x = dv(rnd(2 * 16 * 16, 1280, dtype=dtype, seed=3, scale=0.3), hip, dtype)
+        conv = ops.FrozenConv(rnd(1280, 1280, 3, 3, seed=4, scale=0.02), None, dtype, hip)
+        res.append(ops.conv2d(x, conv, 2, 16, 16))
+        A1, H_ = dv(rnd(512, 1280, dtype=dtype, seed=5, scale=0.3), hip, dtype), dv(rnd(512, 128, dtype=dtype, seed=6, scale=0.3), hip, dtype)
+        W, U = dv(rnd(1280, 1280, dtype=dtype, seed=7, scale=0.3), hip, dtype), dv(rnd(1280, 128, dtype=dtype, seed=8, scale=0.3), hip, dtype)
+        out = torch.full((512, 1280), float("nan"), dtype=dtype, device=hip)
+        k.gemm_segments([(A1, W, 1280, 1280, 1280), (H_, U, 128, 128, 128)], out, 512, 1280, 1280)
+        res.append(out)
+        outs[order] = res
+    for order in (1, 2):
+        for i, (a, b) in enumerate(zip(outs[0], outs[order])):
+            assert torch.isfinite(a.float()).all() and torch.equal(a, b), f"g2_order={order}: result {i} differs from row-block-major order"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(2, 4096, 4096, 8, 40), (2, 1024, 1024, 8, 80), (1, 577, 577, 16, 64), (2, 1024, 77, 8, 80),
+                                 (1, 300, 200, 3, 40), (2, 256, 256, 8, 160)])
+def test_flash_xcd_renumbering_is_bit_identical(hip, cfg, default_opts):
+    """option flash_xcd: the fused attention's workgroups renumbered so that one (batch, head) runs on one XCD - forward,
+    dQ, dK/dV (separate launches; the one-launch backward ignores the option) give the same bits."""
+    dtype = torch.bfloat16
+    B, Nq, Nk, H, d = cfg
+    q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
+    g = rnd(B * Nq, H * d, dtype=dtype, seed=4)
+    K = ops.kernels()
+    HD = H * d
+    got = []
+    for xcd in (0, 1):
+        _set_opts(flash_xcd=xcd, flash_merge=0)
+        qd, kd, vd, gd = (dv(t, hip, dtype) for t in (q, k_, v, g))
+        o = torch.full_like(qd, float("nan"))
+        lse, dbuf = torch.empty(B, H, Nq, device=hip), torch.empty(B, H, Nq, device=hip)
+        K.flash_attn_fwd(qd, kd, vd, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        dq, dk, dvv = torch.full_like(qd, float("nan")), torch.full_like(kd, float("nan")), torch.full_like(vd, float("nan"))
+        K.flash_attn_bwd(qd, kd, vd, o, gd, lse, dbuf, dq, dk, dvv, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        got.append((o, lse, dq, dk, dvv))
+    for name, a, b in zip(("O", "lse", "dQ", "dK", "dV"), *got):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b), f"{name}: flash_xcd = 1 differs"
 
 
 @pytest.mark.gpu
