@@ -224,6 +224,8 @@ class HipKernels:
             ws[: WS_COUNTER_BYTES // 4].zero_()  # the ABI asks for zeroed ticket counters before the first use
         return ws
 
+    GN_WS_MIN = 1 << 22
+
     def prepare_stream(self, dev, gn_groups=64):
         """create (and zero) every per-stream workspace of the CURRENT stream now, outside any capture; idempotent.
         -> True if something had to be created (the caller then synchronises before it starts a capture)"""
@@ -377,8 +379,12 @@ class HipKernels:
         key = ("gn", dev, _stream())
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            # GN_WS_MIN doubles (32 MiB) hold B * G <= 2045 (sample, group) pairs - a per-GPU batch of 31 under CFG doubling
+            # with 32 groups - so that a stream prepared for capture (prepare_stream) never has to grow inside one: only
+            # the default stream's workspace is ever warmed up by eager calls, the capture stream's is created before any
+            # launch ran on it (the former 2 MiB floor made every capture with B >= 4 raise)
             self._no_capture("the GroupNorm workspace")
-            ws = self._ws[key] = torch.zeros(max(need, 1 << 18), dtype=torch.float64, device=dev)
+            ws = self._ws[key] = torch.zeros(max(need, self.GN_WS_MIN), dtype=torch.float64, device=dev)
         return ws
 
     def groupnorm_fwd(self, x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu):

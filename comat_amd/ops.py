@@ -233,11 +233,15 @@ class _TTQueue:
         self.items, self.outs, self.keep = [], set(), []
 
     def add(self, prob, keep):
-        cptr = prob[2].data_ptr()
-        if len(self.items) >= TT_GROUP or cptr in self.outs:
+        # the byte range the problem accumulates into: [C, C + ((M - 1) ldc + N) * 4).  A problem whose output OVERLAPS one
+        # the group already holds (the same factor at another denoise step, or any partially overlapping view) must not
+        # share its launch: the two read-modify-write passes would race
+        lo = prob[2].data_ptr()
+        hi = lo + ((prob[3] - 1) * prob[8] + prob[4]) * 4
+        if len(self.items) >= TT_GROUP or any(lo < h and l < hi for l, h in self.outs):
             self.flush()
         self.items.append(prob)
-        self.outs.add(cptr)
+        self.outs.add((lo, hi))
         self.keep.append(keep)
 
     def flush(self):

@@ -184,6 +184,28 @@ class SegmentedStep:
         self.use_head, self.use_d = use_head, (use_d if use_head or use_d != "head" else "own")
         self.static = {}
         self.enabled = trainer.device.type == "cuda"
+        self.failed = None  # message of a failed capture: from then on every call (and the rest of that step) runs eagerly
+
+    def _capture(self, seg, inputs, **kw):
+        """seg.capture(...) -> True; a capture that raises is turned into a STATE, as step.GraphedStep does: the eager run
+        that preceded it was this step's real work, so the step goes on eagerly (its gradient exchange stays matched on
+        every rank) and the segment is never registered - a half-built one (fg = None, no `si`) would be taken for
+        replayable by the next call.  The capture stream, the streams forked from it and the weight gradients the aborted
+        pass queued are dropped."""
+        try:
+            seg.capture(inputs, **kw)
+            return True
+        except Exception as e:  # noqa: BLE001 - see `failed`
+            self.failed = f"{seg.name}: {type(e).__name__}: {e}"
+            dev = self.tr.device
+            ops.reset_capture_stream(dev)
+            self.tr.drop_forked_streams()
+            ops.drop_side_stream_state()
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001 - the pending error of the failed capture
+                pass
+            return False
 
     # ---- batch staging: every tensor of the batch at a fixed device address ------------------------------------------
     def _stage(self, batch):
@@ -227,16 +249,18 @@ class SegmentedStep:
 
         self._map_counts = getattr(self, "_map_counts", {})
         inputs = (xin, te, ctx) + ((added,) if added is not None else ())
-        seg = None if self.dry else self.unet_segs.get(key)
-        if self.dry:
+        eager = self.dry or self.failed is not None
+        seg = None if eager else self.unet_segs.get(key)
+        if eager:
             outs = fn(*inputs)
         elif seg is None:
             pool = self.slot_pools.get(slot)
             if pool is None:
                 pool = self.slot_pools[slot] = torch.cuda.graph_pool_handle()
-            seg = self.unet_segs[key] = GraphedSegment(fn, f"unet slot {slot} capture={cap}", pool=pool)
+            seg = GraphedSegment(fn, f"unet slot {slot} capture={cap}", pool=pool)
             outs = fn(*inputs)          # eager: this call's real work (and the memo / workspace warm-up of the capture)
-            seg.capture(inputs)
+            if self._capture(seg, inputs):
+                self.unet_segs[key] = seg
         else:
             outs = seg(*inputs)
         eps, flat = outs[0], list(outs[1:])
@@ -265,12 +289,12 @@ class SegmentedStep:
         d_in_head = self.use_d == "head" and cfg.gan_loss and tr.D is not None
         if d_in_head:
             inputs = inputs + (batch["real_latents"],)  # staged with the head's inputs, read by the D branch
-        if self.dry:
+        if self.dry or self.failed is not None:
             outs = fn(*inputs)
             self._img_hw = tr._last_image_hw
         elif self.head_seg is None:
             tr.blip.install_static_tables(res, res, crop)
-            seg = self.head_seg = GraphedSegment(fn, "head")
+            seg = GraphedSegment(fn, "head")
             outs = fn(*inputs)
             self._img_hw = tr._last_image_hw
             side = None
@@ -296,7 +320,8 @@ class SegmentedStep:
                 with torch.cuda.stream(tr._d_stream), ops.no_side_streams():
                     tr._d_step_eager(dict(training_latents=lat.detach()), batch)
                 cur.wait_stream(tr._d_stream)
-            seg.capture(inputs, bwd_side=side)
+            if self._capture(seg, inputs, bwd_side=side):
+                self.head_seg = seg
         else:
             outs = self.head_seg(*inputs)
         o = dict(reward=outs[0], logp=outs[1], image=(outs[-1],) + tuple(self._img_hw))
@@ -314,7 +339,7 @@ class SegmentedStep:
         dev = tr.device
         real = batch["real_latents"]
         inputs = (out["training_latents"].detach(), real, batch["gan_null_embeds"])
-        if self.dry:
+        if self.dry or self.failed is not None:
             return fn(*inputs)
         if self.use_d == "head":
             # replayed inside the head's backward graph; until that graph exists (first step) the step runs eagerly here
@@ -325,11 +350,12 @@ class SegmentedStep:
             st = torch.cuda.current_stream(dev)  # the discriminator's stream (step.CoMatTrainer forks it) or the main one
             if st.cuda_stream != torch.cuda.default_stream(dev).cuda_stream:
                 ops.prepare_capture_stream(dev, st)
-                self.d_seg = GraphedSegment(fn, "discriminator step", stream=st)
+                seg = GraphedSegment(fn, "discriminator step", stream=st)
             else:
-                self.d_seg = GraphedSegment(fn, "discriminator step")
+                seg = GraphedSegment(fn, "discriminator step")
             loss = fn(*inputs)
-            self.d_seg.capture(inputs)
+            if self._capture(seg, inputs):
+                self.d_seg = seg
             return loss
         return self.d_seg(*inputs)[0]
 
@@ -338,7 +364,7 @@ class SegmentedStep:
         tr = self.tr
         fixed = {k: v for k, v in (("training_steps", training_steps), ("crop", crop), ("attrcon_steps", attrcon_steps))
                  if v is not None}
-        if not self.enabled and not self.dry:
+        if (not self.enabled and not self.dry) or self.failed is not None:
             return tr.train_step(batch, **fixed)
         sb = self._stage(batch)
         # the derived LoRA copies are refreshed HERE, eagerly: inside a capture the refresh would be baked into that one

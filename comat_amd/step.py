@@ -146,6 +146,20 @@ class CoMatTrainer:
         self.head_runner = None
         self.d_runner = None
         self._last_image_hw = None
+        self.grad_scale = 1.0
+
+    def drop_forked_streams(self):
+        """After a FAILED graph capture: forget every stream this trainer forks from the capturing stream (the D step's,
+        the generator-side D loss's).  The runtime may leave them in capture mode or invalidated; the next eager step
+        makes fresh ones.  Per-stream workspaces keyed on the dead streams are dropped with them."""
+        dead = [st.cuda_stream for st in (self._d_stream, self._g_stream) if st is not None]
+        self._d_stream = self._g_stream = None
+        self._d_pending, self._d_keep = False, None
+        k = ops.kernels()
+        ws = getattr(k, "_ws", None)
+        if ws and dead:
+            for key in [key for key in ws if isinstance(key, tuple) and any(h in key for h in dead)]:
+                ws.pop(key, None)
 
     def head_losses(self, lat, batch, crop, bs, h, w):
         """final latents (channels-last tokens, fp32) -> VAE decode -> crop + BLIP caption reward [-> generator-side
@@ -319,6 +333,10 @@ class CoMatTrainer:
         if self.cfg.gan_loss:
             self.reducer.start(self.D.bank.flat_grad, self.D.head_grad)
         scale = self.reducer.finish()  # 1 / world: the mean is taken inside the clip + AdamW pass
+        # NOTE for readers of the buffers after this point: with more than one rank `flat_grad` / `head_grad` hold the SUM
+        # over ranks and `opt.gnorm_sq` its squared norm; only comat_adamw applies `scale` (to the gradient and to the norm
+        # it clips by).  The logs carry `grad_scale`: |mean gradient|^2 = grad_norm_sq * grad_scale^2.
+        self.grad_scale = scale
         self.opt.step(scale)
         self.bank.mark_updated()
         if self.cfg.gan_loss:
@@ -332,6 +350,7 @@ class CoMatTrainer:
         logs = self._forward_backward(batch, fixed)
         self._apply_updates()
         logs["grad_norm_sq"] = self.opt.gnorm_sq  # non-finite => the generator update of this step was skipped
+        logs["grad_scale"] = self.grad_scale      # 1 / world: grad_norm_sq is the norm of the SUM over ranks
         logs["training_steps"], logs["crop"] = self._last
         return logs
 
@@ -463,8 +482,7 @@ class GraphedStep:
                     # (the fixed-address crop tables stay installed: segment graphs captured earlier read them, and
                     # Blip.tables() loads them with whatever crop an eager call asks for)
                     ops.reset_capture_stream(tr.device)
-                    tr._d_stream = None
-                    tr._d_pending, tr._d_keep = False, None
+                    tr.drop_forked_streams()  # _d_stream, _g_stream: forked inside the capture, possibly left capturing
                     ops.drop_side_stream_state()  # weight gradients queued by the aborted capture
                     try:
                         torch.cuda.synchronize()

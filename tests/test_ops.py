@@ -226,6 +226,36 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
     assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])  # run-to-run bit-identical
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [4, 12])
+def test_groupnorm_capture_with_a_real_batch(hip, B):
+    """a capture on the package's capture stream with B >= 4 samples (per-GPU batch >= 2 under CFG
+    doubling, the reference's train_batch_size 4 / 6) and the UNet's 32 groups.  Nothing ever runs eagerly on that stream,
+    so its GroupNorm workspace is the one prepare_stream() made: it must hold B * G pairs without growing inside the
+    capture (the former 2 MiB floor held 127).  Replay equals the eager launch bit for bit, forward and backward, for the
+    three-launch form (HW = 1024) and the one-launch form (HW = 64)."""
+    dtype = torch.bfloat16
+    G = 32
+    for HW, Cc in ((1024, 320), (64, 640)):
+        x = dv(rnd(B * HW, Cc, dtype=dtype, seed=B), hip, dtype)
+        gy = dv(rnd(B * HW, Cc, dtype=dtype, seed=B + 1), hip, dtype)
+        gam, bet = dv(rnd(Cc, seed=3), hip, torch.float32), dv(rnd(Cc, seed=4), hip, torch.float32)
+
+        def run(xin):
+            y = ops.group_norm(xin, gam, bet, B, HW, G=G, eps=1e-5, silu=True)
+            (dx,) = torch.autograd.grad(y, xin, gy)
+            return y, dx
+        ye, dxe = run(x.clone().requires_grad_(True))
+        torch.cuda.synchronize()
+        xs = x.clone().requires_grad_(True)
+        g = torch.cuda.CUDAGraph()
+        with ops.graph_capture(g, stream=ops.capture_stream(hip)):
+            yg, dxg = run(xs)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ye, yg) and torch.equal(dxe, dxg), f"B={B} HW={HW}: replayed GroupNorm differs from eager"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(37, 96), (8, 1280), (5, 70)])
 def test_layernorm(dev, dtype, shape):
