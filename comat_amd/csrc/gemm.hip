@@ -713,6 +713,14 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
+    if (p->in_dtype == COMAT_BF16 && !p->transA && !p->transB && p->batch2 == 1) {  // lean kernel first (option gemm3)
+        const comat_gemm_segment one = {p->A, p->B, p->K, p->lda, p->ldb, p->sA1, p->sB1};
+        const int rc3 = comat_gemm3_try(p, &one, 1, false, stream);
+        if (rc3 > 0) {
+            comat_note_gemm_kernel(rc3);
+            return comat_check_launch("comat_gemm");
+        }
+    }
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
@@ -765,6 +773,11 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
         COMAT_REQUIRE(segs[s].lda >= segs[s].K && segs[s].ldb >= segs[s].K,
                       "comat_gemm_segments: leading dimension of segment %d too small", s);
     }
+    const int rc3 = comat_gemm3_try(p, segs, nseg, true, stream);  // lean kernel first (option gemm3)
+    if (rc3 > 0) {
+        comat_note_gemm_kernel(rc3);
+        return comat_check_launch("comat_gemm_segments");
+    }
     const int rc2 = comat_gemm2_try_segments(p, segs, nseg, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm_segments");
@@ -801,6 +814,28 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     if (p->in_dtype == COMAT_BF16) hipLaunchKernelGGL((gemm_seg_kernel<bf16_t>), dim3((unsigned)blocks), dim3(NT), 0, st, g);
     else hipLaunchKernelGGL((gemm_seg_kernel<float>), dim3((unsigned)blocks), dim3(NT), 0, st, g);
     return comat_check_launch("comat_gemm_segments");
+}
+
+// Two dependent K-segmented GEMMs in stream order - as ONE launch when the lean kernel takes both (include/comat_hip.h)
+extern "C" int comat_gemm_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int32_t nseg0,
+                                const comat_gemm_params* p1, const comat_gemm_segment* segs1, int32_t nseg1, void* stream) {
+    COMAT_REQUIRE(p0 && p1 && segs0 && segs1 && nseg0 >= 1 && nseg1 >= 1, "comat_gemm_chain: null params");
+    COMAT_REQUIRE(segs1[nseg1 - 1].A != nullptr && p0->C != nullptr, "comat_gemm_chain: null operand");
+    {   // the consumer's last segment must read the producer's output buffer: [C0, C0 + M ldc) in elements
+        const char* c0 = (const char*)p0->C;
+        const char* a1 = (const char*)segs1[nseg1 - 1].A;
+        const int64_t esz = p0->out_dtype == COMAT_F32 ? 4 : 2;
+        const int64_t span = ((p0->batch1 > 1 ? p0->batch1 - 1 : 0) * p0->sC1 + p0->M * p0->ldc) * esz;
+        COMAT_REQUIRE(a1 >= c0 && a1 < c0 + span, "comat_gemm_chain: the consumer's last segment does not read the producer's output");
+    }
+    const int rc3 = comat_gemm3_try_chain(p0, segs0, nseg0, p1, segs1, nseg1, stream);
+    if (rc3 > 0) {
+        comat_note_gemm_kernel(rc3);
+        return comat_check_launch("comat_gemm_chain");
+    }
+    const int rc = comat_gemm_segments(p0, segs0, nseg0, stream);
+    if (rc != COMAT_OK) return rc;
+    return comat_gemm_segments(p1, segs1, nseg1, stream);
 }
 
 extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {

@@ -75,12 +75,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ void mma_t(f32x16_t& acc, const short8_t& wfrag, const short8_t& xfrag) {
-    // D[n][m] += W[n][k] X[m][k]: A operand = weight fragment (lane&31 = n), B operand = activation fragment (lane&31 = m)
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfrag), __builtin_bit_cast(bf16x8_t, xfrag),
-                                                  acc, 0, 0, 0);
-}
-
 // fp8 (OCP e4m3): one 32x32x64 MFMA consumes the whole 64-byte k-tile; lane (r, h) supplies the two 16-byte chunks it
 // would read for bf16 k-steps 0 and 1 (chunks h and 2 + h of row r) as ONE 32-byte operand.  The instruction's own
 // lane -> k assignment is the same for A and B, so - as for bf16 - the k-permutation cancels.  Block scales are unused
@@ -94,82 +88,6 @@ __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, con
     const v8i wv = {wa[0], wa[1], wa[2], wa[3], wb[0], wb[1], wb[2], wb[3]};
     const v8i xv = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wv, xv, acc, 0 /* A: fp8 e4m3 */, 0 /* B: fp8 e4m3 */, 0, 0, 0, 0);
-}
-
-// lanes 32..63 of `lo` <-> lanes 0..31 of `hi`
-__device__ __forceinline__ void half_swap(float& lo, float& hi) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-    lo = __uint_as_float(r[0]);
-    hi = __uint_as_float(r[1]);
-}
-
-union Pack16 {
-    uint4 u;
-    bf16_t h[8];
-    float f[4];
-};
-
-// 8 consecutive output columns n .. n+7 of output row m
-__device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m, int64_t n, int64_t N, bool vec) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
-    if (vec) {
-        if (ep.bias) {
-            const float4 b0 = *(const float4*)(ep.bias + n), b1 = *(const float4*)(ep.bias + n + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (ep.bias2) {
-            const float* p2 = ep.bias2 + (int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + n;
-            const float4 b0 = *(const float4*)p2, b1 = *(const float4*)(p2 + 4);
-            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
-        if (ep.act == COMAT_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        } else if (ep.act == COMAT_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        }
-        if (ep.R) {
-            if (ep.r_dt == COMAT_F32) {
-                const float* pr = (const float*)ep.R + m * ep.ldr + n;
-                const float4 r0 = *(const float4*)pr, r1 = *(const float4*)(pr + 4);
-                v[0] += ep.beta * r0.x; v[1] += ep.beta * r0.y; v[2] += ep.beta * r0.z; v[3] += ep.beta * r0.w;
-                v[4] += ep.beta * r1.x; v[5] += ep.beta * r1.y; v[6] += ep.beta * r1.z; v[7] += ep.beta * r1.w;
-            } else {
-                Pack16 pk;
-                pk.u = *(const uint4*)((const bf16_t*)ep.R + m * ep.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += ep.beta * bf16_to_f32(pk.h[e]);
-            }
-        }
-        if (ep.out_dt == COMAT_F32) {
-            float* pc = (float*)ep.C + m * ep.ldc + n;
-            *(float4*)pc = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(pc + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-            Pack16 pk;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pk.h[e] = f32_to_bf16(v[e]);
-            *(uint4*)((bf16_t*)ep.C + m * ep.ldc + n) = pk.u;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t col = n + e;
-            if (col < N) {
-                float x = v[e];
-                if (ep.bias) x += ep.bias[col];
-                if (ep.bias2) x += ep.bias2[(int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + col];
-                if (ep.act == COMAT_ACT_SILU) x = silu_f(x);
-                else if (ep.act == COMAT_ACT_GELU) x = gelu_f(x);
-                if (ep.R) x += ep.beta * ld_dt(ep.R, m * ep.ldr + col, ep.r_dt);
-                st_dt(ep.C, m * ep.ldc + col, x, ep.out_dt);
-            }
-        }
-    }
 }
 
 // split-K combine (inside the launch) + fused epilogue of one block tile; shared by the k-contiguous and the k-major kernel

@@ -67,6 +67,100 @@ __device__ __forceinline__ bool splitk_ticket_is_last(unsigned* counter, int spl
     return *lds_flag != 0u;
 }
 
+// ---- device pieces shared by the MFMA kernels of gemm2.hip and gemm3.hip -------------------------------------------------
+__device__ __forceinline__ void mma_t(f32x16_t& acc, const short8_t& wfrag, const short8_t& xfrag) {
+    // D[n][m] += W[n][k] X[m][k]: A operand = weight fragment (lane&31 = n), B operand = activation fragment (lane&31 = m)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wfrag), __builtin_bit_cast(bf16x8_t, xfrag),
+                                                  acc, 0, 0, 0);
+}
+
+// 16-byte write-through store / L1-bypassing load (sc1): data handed from one workgroup to another inside a launch
+__device__ __forceinline__ void store16_wt(void* p, const uint4& v) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    const u32x4_t w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
+
+// lanes 32..63 of `lo` <-> lanes 0..31 of `hi`
+__device__ __forceinline__ void half_swap(float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
+union Pack16 {
+    uint4 u;
+    bf16_t h[8];
+    float f[4];
+};
+
+// 8 consecutive output columns n .. n+7 of output row m
+// WT: the 16-byte stores are WRITE-THROUGH (sc1): the tile is read by other workgroups of the SAME launch (gemm3.hip: the
+// producer phase of a chained launch), whose sc1 loads then see it without any fence (cdna_hip_programming.md, guideline 16)
+template <bool WT = false>
+__device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m, int64_t n, int64_t N, bool vec) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+    if (vec) {
+        if (ep.bias) {
+            const float4 b0 = *(const float4*)(ep.bias + n), b1 = *(const float4*)(ep.bias + n + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (ep.bias2) {
+            const float* p2 = ep.bias2 + (int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + n;
+            const float4 b0 = *(const float4*)p2, b1 = *(const float4*)(p2 + 4);
+            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+            v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        }
+        if (ep.act == COMAT_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+        } else if (ep.act == COMAT_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        }
+        if (ep.R) {
+            if (ep.r_dt == COMAT_F32) {
+                const float* pr = (const float*)ep.R + m * ep.ldr + n;
+                const float4 r0 = *(const float4*)pr, r1 = *(const float4*)(pr + 4);
+                v[0] += ep.beta * r0.x; v[1] += ep.beta * r0.y; v[2] += ep.beta * r0.z; v[3] += ep.beta * r0.w;
+                v[4] += ep.beta * r1.x; v[5] += ep.beta * r1.y; v[6] += ep.beta * r1.z; v[7] += ep.beta * r1.w;
+            } else {
+                Pack16 pk;
+                pk.u = *(const uint4*)((const bf16_t*)ep.R + m * ep.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += ep.beta * bf16_to_f32(pk.h[e]);
+            }
+        }
+        if (ep.out_dt == COMAT_F32) {
+            float* pc = (float*)ep.C + m * ep.ldc + n;
+            *(float4*)pc = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(pc + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            Pack16 pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.h[e] = f32_to_bf16(v[e]);
+            if (WT) store16_wt((bf16_t*)ep.C + m * ep.ldc + n, pk.u);
+            else *(uint4*)((bf16_t*)ep.C + m * ep.ldc + n) = pk.u;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t col = n + e;
+            if (col < N) {
+                float x = v[e];
+                if (ep.bias) x += ep.bias[col];
+                if (ep.bias2) x += ep.bias2[(int64_t)((unsigned)m / (unsigned)ep.rows_per_b2) * N + col];
+                if (ep.act == COMAT_ACT_SILU) x = silu_f(x);
+                else if (ep.act == COMAT_ACT_GELU) x = gelu_f(x);
+                if (ep.R) x += ep.beta * ld_dt(ep.R, m * ep.ldr + col, ep.r_dt);
+                st_dt(ep.C, m * ep.ldc + col, x, ep.out_dt);
+            }
+        }
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters at the head of the workspace
 
@@ -75,3 +169,7 @@ constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters 
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream);
 int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream);
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream);
+// gemm3.hip: the lean k-parallel-wave kernel (-> 5 when it took the problem, 0 otherwise) and chained launches
+int comat_gemm3_try(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, bool bias_per_batch, void* stream);
+int comat_gemm3_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
+                          const comat_gemm_segment* segs1, int nseg1, void* stream);

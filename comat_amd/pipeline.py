@@ -75,7 +75,10 @@ class TrainableSDPipeline:
         # SDXL: the prompt-dependent half of the time embedding is an extra graph input (validated on MI355X in round 2;
         # COMAT_SDXL_GRAPHS=0 disables).  One graph per timestep: capture them up front with prepare_graphs() — a
         # capture costs ~3 eager forwards, and lazily captured graphs only pay off after every timestep has been seen
+        # (only a real UNet is replayed from graphs: a stand-in callable - the reference-code fixtures of tests/ drive this
+        # class with a small torch "UNet" on the device - has no static launch topology to rely on)
         use_graphs = (torch.device(self.device).type == "cuda" and os.environ.get("COMAT_GRAPHS", "1") != "0"
+                      and isinstance(unet, UNet)
                       and (not unet.cfg.addition_embed or os.environ.get("COMAT_SDXL_GRAPHS", "1") != "0"))
         self.graphed = GraphedUNetForward(unet) if use_graphs else None
         # hook of segments.SegmentedStep: runs a TRAINED UNet call (slot = its rank among the trained steps) from a pair
