@@ -833,6 +833,11 @@ extern "C" int comat_gemm_chain(const comat_gemm_params* p0, const comat_gemm_se
         comat_note_gemm_kernel(rc3);
         return comat_check_launch("comat_gemm_chain");
     }
+    const int rc2 = comat_gemm2_try_chain(p0, segs0, nseg0, p1, segs1, nseg1, stream);
+    if (rc2 > 0) {
+        comat_note_gemm_kernel(6);
+        return comat_check_launch("comat_gemm_chain");
+    }
     const int rc = comat_gemm_segments(p0, segs0, nseg0, stream);
     if (rc != COMAT_OK) return rc;
     return comat_gemm_segments(p1, segs1, nseg1, stream);

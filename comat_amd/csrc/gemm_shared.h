@@ -169,6 +169,8 @@ constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters 
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream);
 int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream);
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream);
+int comat_gemm2_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
+                          const comat_gemm_segment* segs1, int nseg1, void* stream);
 // gemm3.hip: the lean k-parallel-wave kernel (-> 5 when it took the problem, 0 otherwise) and chained launches
 int comat_gemm3_try(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, bool bias_per_batch, void* stream);
 int comat_gemm3_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,

@@ -80,6 +80,8 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // 4 64x64 / 4, 5 64x64 / 8, 6 32x32 / 4, 7 64x32 / 4, 8 32x32 / 16, 9 64x32 / 16
     {"gemm3_chain", "COMAT_GEMM3_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch on the lean kernel: 0 never (two
                                                           // launches), 1 where the lean kernel's rule wants the consumer, 2 always
+    {"gemm2_chain", "COMAT_GEMM2_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch of the pipelined kernel (producer
+                                                          // tiles first, the consumer's last segment waits for its row block)
 };
 }  // namespace
 

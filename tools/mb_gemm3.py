@@ -45,7 +45,7 @@ def timeit(fn, n=20):
 
 
 def opts(**kw):
-    base = dict(gemm3=0, g3_cfg=0, gemm3_chain=0, g2_cfg=0, g2_splits=0)
+    base = dict(gemm3=0, g3_cfg=0, gemm3_chain=0, gemm2_chain=0, g2_cfg=0, g2_splits=0)
     base.update(kw)
     for k_, v_ in base.items():
         _hip.set_option(k_, v_)
@@ -90,7 +90,7 @@ for M, N, K_, r, G in [(512, 1280, 1280, 128, 1), (512, 1280, 1280, 128, 3), (20
     print(f"seg {M}x{N}x({K_}+{r}) b={G:<18d} {t2:9.1f} {ta:5.1f} | " + " ".join(f"{t:8.1f}" for t in row), flush=True)
 
 print("# LoRA pairs (forward: h = s x D^T, y = [x | h][W | U]^T; backward: u = s g U, dx = [g | u][W^T | D^T]^T): us per pair")
-print(f"# {'pair':40s} 2 x pipelined | 2 x lean (auto) | chained (auto) | chained per tile shape: " + " ".join(NAMES))
+print(f"# {'pair':40s} 2 x pipelined | chained pipelined | 2 x lean (auto) | chained lean (auto) | chained lean per tile shape: " + " ".join(NAMES))
 for M, Kd, N, G in [(512, 1280, 1280, 3), (512, 1280, 1280, 1), (2048, 640, 640, 3), (2048, 640, 640, 1), (8192, 320, 320, 3), (8192, 320, 320, 1),
                     (154, 768, 1280, 2), (128, 1280, 1280, 3), (128, 1280, 1280, 1)]:
     r = 128
@@ -107,6 +107,8 @@ for M, Kd, N, G in [(512, 1280, 1280, 3), (512, 1280, 1280, 1), (2048, 640, 640,
         fn = lambda: K.gemm_chain(p0, p1)
         opts()
         t22 = timeit(fn)
+        opts(gemm2_chain=1)
+        t2c = timeit(fn)
         opts(gemm3=2)
         t33 = timeit(fn)
         opts(gemm3=2, gemm3_chain=2)
@@ -115,5 +117,5 @@ for M, Kd, N, G in [(512, 1280, 1280, 3), (512, 1280, 1280, 1), (2048, 640, 640,
         for c in CFGS:
             opts(gemm3=2, gemm3_chain=2, g3_cfg=c)
             row.append(timeit(fn))
-        print(f"{tag} pair M={M} {Kd}->{N} G={G:<20d} {t22:9.1f} | {t33:9.1f} | {tc:9.1f} | " + " ".join(f"{t:8.1f}" for t in row), flush=True)
+        print(f"{tag} pair M={M} {Kd}->{N} G={G:<20d} {t22:9.1f} | {t2c:9.1f} | {t33:9.1f} | {tc:9.1f} | " + " ".join(f"{t:8.1f}" for t in row), flush=True)
 opts()

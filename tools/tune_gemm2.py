@@ -59,7 +59,7 @@ class Recorder:
 _side = None
 
 
-def timeit(fn, n=10):
+def timeit(fn, n=16):
     """microseconds per launch: n back-to-back launches replayed from a hipGraph (an eager loop measures the host's
     ~6 us launch cadence for every kernel shorter than that)"""
     global _side
@@ -75,12 +75,15 @@ def timeit(fn, n=10):
             fn()
     g.replay()
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    g.replay()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e3
+    best = 1e30
+    for _ in range(2):  # best of two replays: a minimum over ~40 noisy variants otherwise picks the luckiest, not the fastest
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / n * 1e3)
+    return best
 
 
 def make_call(k, sig, dev):
@@ -150,8 +153,8 @@ def main():
 
         k2 = {}
         for c in (1, 2, 3, 4, 6, 7):
-            if c == 3 and M < 16384:
-                continue
+            if c == 3 and -(-M // 256) * -(-N // 128) * batch < 64:  # 256 x 128: only with enough tiles (round 4: it wins at
+                continue                                            # 512 x 10240 x 1280, 24.8 vs 32.1 us)
             k2[c] = sweep(c)
         floor = min(k2.values())
         for c4, twin in ((8, 6), (9, 2), (10, 4), (11, 1)):  # 128-byte k-tiles: only where the twin is in the running
