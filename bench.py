@@ -129,9 +129,10 @@ class CallRecorder:
                 shapes[p[3:6]] = shapes.get(p[3:6], 0) + 1
             return f"tt_grouped n={len(a[0])} " + " ".join(f"{m}x{n}x{k}*{c}" for (m, n, k), c in sorted(shapes.items()))
         if name == "gemm":
+            out = a[2] if a[2] is not None else kw["geglu"][0]  # fused GEGLU without stored pre-activations: C is absent
             return (f"gemm M={a[3]} N={a[4]} K={a[5]} ld={a[6]},{a[7]},{a[8]} tA={int(kw.get('transA', False))} "
-                    f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={a[2].dtype} "
-                    + cls._epi(kw))
+                    f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={out.dtype} "
+                    + cls._epi(kw) + (f" geglu={1 if kw['geglu'][1] else 2}" if kw.get("geglu") is not None else ""))
         if name == "gemm_segments":
             return (f"gemm_segments M={a[2]} N={a[3]} K={'+'.join(str(sg[2]) for sg in a[0])} b={kw.get('batch', 1)} "
                     f"in={a[0][0][0].dtype} out={a[1].dtype} " + cls._epi(kw))
@@ -171,6 +172,9 @@ class CallRecorder:
             b = kw.get("batch", (1, 1))
             nb = b[0] * b[1]
             r = M * N * sz(kw["R"]) if kw.get("R") is not None else 0
+            if kw.get("geglu") is not None:  # + the [M, N / 2] product; the pre-activations only when they are stored
+                y, keep = kw["geglu"]
+                return (M * K + N * K) * sz(a[0]) + (M * N * sz(y) if keep else 0) + M * (N // 2) * sz(y)
             return nb * ((M * K + N * K) * sz(a[0]) + M * N * sz(a[2]) + r)
         if name == "gemm_segments":
             M, N, nb = a[2], a[3], kw.get("batch", 1)

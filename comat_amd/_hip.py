@@ -33,6 +33,7 @@ class GemmParams(C.Structure):
         ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
+        ("C2", C.c_void_p), ("ldc2", C.c_int64), ("epi2", C.c_int32),
     ]
 
 
@@ -84,6 +85,8 @@ SIGNATURES = {
     "comat_axpby": [_f, _vp, _f, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "comat_geglu_fwd": [_vp, _vp, _i64, _i32, _i32, _vp],
     "comat_geglu_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_geglu_il_fwd": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "comat_geglu_il_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "comat_copy2d": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
     "comat_add_rowvec": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "comat_sumpool2x2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -142,7 +145,8 @@ def load_library(path: str | None = None):
 GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_kernel (LDS-DMA pipelined)",
                      2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)",
                      4: "gemm2_tt_group_kernel (grouped k-major products)",
-                     5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)"}
+                     5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)",
+                     6: "gemm2_chain_kernel (producer + consumer of a chained call in one launch)"}
 
 
 def last_gemm_kernel() -> int:
@@ -251,9 +255,14 @@ class HipKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
              sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
-             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
-        """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h)"""
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None):
+        """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h);
+        geglu = (C2 [M, N / 2], keep_pre): the GEGLU epilogue over interleaved value / gate columns (comat_gemm_params::epi2):
+        C2 receives value * gelu(gate); Cout receives the pre-activations only when keep_pre (it may be None otherwise)"""
         p = GemmParams()
+        if geglu is not None:
+            p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 1 if geglu[1] else 2
+            assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous()
         p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(Cout)
         p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
         if bias is not None:
@@ -271,7 +280,7 @@ class HipKernels:
         p.alpha, p.beta = alpha, beta
         p.transA, p.transB, p.act = int(transA), int(transB), act
         assert A.dtype == B.dtype
-        p.in_dtype, p.out_dtype = dt(A), dt(Cout)
+        p.in_dtype, p.out_dtype = dt(A), (dt(Cout) if Cout is not None else BF16)
         assert (scales is not None) == (p.in_dtype == FP8), "fp8 operands come with their scales"
         if scales is not None:
             p.scale_a, p.scale_b = _ptr(scales[0]), _ptr(scales[1])
@@ -279,6 +288,12 @@ class HipKernels:
         ws = self._workspace(A.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES
         _check(_lib.comat_gemm(C.byref(p), _stream()), "comat_gemm")
+
+    @staticmethod
+    def geglu_gemm_ok(x, w, M, N, K):
+        """problems the GEGLU epilogue of comat_gemm takes (the pipelined kernel's bf16 / fp8 shapes, whole 32-column tiles)"""
+        return (x.dtype in (torch.bfloat16, torch.uint8) and M >= 16 and N % 32 == 0 and K % (32 if x.dtype == torch.bfloat16 else 64) == 0
+                and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
     def _segments_params(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0, batch=1, sC=0, sR=0):
         n = len(segs)
@@ -457,6 +472,12 @@ class HipKernels:
 
     def geglu_bwd(self, dy, x, dx, M, D):
         _check(_lib.comat_geglu_bwd(_ptr(dy), _ptr(x), _ptr(dx), M, D, dt(x), _stream()), "comat_geglu_bwd")
+
+    def geglu_il_fwd(self, x, y, M, D):
+        _check(_lib.comat_geglu_il_fwd(_ptr(x), _ptr(y), M, D, dt(x), _stream()), "comat_geglu_il_fwd")
+
+    def geglu_il_bwd(self, dy, x, dx, M, D):
+        _check(_lib.comat_geglu_il_bwd(_ptr(dy), _ptr(x), _ptr(dx), M, D, dt(x), _stream()), "comat_geglu_il_bwd")
 
     def copy2d(self, src, ld_src, dst, ld_dst, rows, cols):
         _check(_lib.comat_copy2d(_ptr(src), ld_src, _ptr(dst), ld_dst, rows, cols, dt(src), dt(dst), _stream()),

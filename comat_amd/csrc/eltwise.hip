@@ -63,6 +63,66 @@ __global__ __launch_bounds__(NT) void geglu_bwd_kernel(const void* __restrict__ 
     }
 }
 
+// GEGLU on the INTERLEAVED layout of the fused projection (comat_gemm, epi2): every 32 columns of x [M, 2 D] hold 16 value
+// channels followed by their 16 gate channels, so that one lane of the GEMM epilogue owns both halves of 8 channels.
+// Work item = 8 channels of one row: 16-byte accesses (bf16), 2 x 16 (fp32).
+template <typename T> struct V8;
+template <> struct V8<bf16_t> {
+    uint4 u;
+    __device__ __forceinline__ void load(const bf16_t* p) { u = *(const uint4*)p; }
+    __device__ __forceinline__ void store(bf16_t* p) const { *(uint4*)p = u; }
+    __device__ __forceinline__ float get(int e) const { return bf16_to_f32(((const bf16_t*)&u)[e]); }
+    __device__ __forceinline__ void set(int e, float v) { ((bf16_t*)&u)[e] = f32_to_bf16(v); }
+};
+template <> struct V8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ __forceinline__ void store(float* p) const { *(float4*)p = a; *(float4*)(p + 4) = b; }
+    __device__ __forceinline__ float get(int e) const { return ((const float*)&a)[e]; }
+    __device__ __forceinline__ void set(int e, float v) { ((float*)&a)[e] = v; }
+};
+static_assert(sizeof(V8<float>) == 32, "V8<float>: a and b are adjacent");
+
+template <typename T>
+__global__ __launch_bounds__(NT) void geglu_il_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t M, int D) {
+    const int D8 = D / 8;
+    const int64_t n = M * D8;
+    GRID_STRIDE(i, n) {
+        const int64_t m = i / D8;
+        const int c8 = (int)(i - m * D8);           // channels 8 c8 .. + 8
+        const int col = (c8 >> 1) * 32 + (c8 & 1) * 8;  // their value columns; the gate columns are 16 further
+        V8<T> a, g, o;
+        a.load(x + m * 2 * D + col);
+        g.load(x + m * 2 * D + col + 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, a.get(e) * gelu_f(g.get(e)));
+        o.store(y + m * D + c8 * 8);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void geglu_il_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
+                                                          int64_t M, int D) {
+    const int D8 = D / 8;
+    const int64_t n = M * D8;
+    GRID_STRIDE(i, n) {
+        const int64_t m = i / D8;
+        const int c8 = (int)(i - m * D8);
+        const int col = (c8 >> 1) * 32 + (c8 & 1) * 8;
+        V8<T> a, g, go, da, dg;
+        a.load(x + m * 2 * D + col);
+        g.load(x + m * 2 * D + col + 16);
+        go.load(dy + m * D + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            da.set(e, go.get(e) * gelu_f(g.get(e)));
+            dg.set(e, go.get(e) * a.get(e) * gelu_grad_f(g.get(e)));
+        }
+        da.store(dx + m * 2 * D + col);
+        dg.store(dx + m * 2 * D + col + 16);
+    }
+}
+
 __global__ __launch_bounds__(NT) void copy2d_kernel(const void* __restrict__ src, int64_t lds_, void* __restrict__ dst,
                                                     int64_t ldd, int64_t rows, int64_t cols, int sdt, int ddt) {
     const int64_t n = rows * cols;
@@ -200,6 +260,25 @@ extern "C" int comat_geglu_fwd(const void* x, void* y, int64_t M, int32_t D, int
     COMAT_REQUIRE(x && y && M > 0 && D > 0 && dtype_ok(dtype), "comat_geglu_fwd: bad args");
     hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_1d(M * D, NT)), dim3(NT), 0, ST, x, y, M, D, dtype);
     return comat_check_launch("comat_geglu_fwd");
+}
+
+extern "C" int comat_geglu_il_fwd(const void* x, void* y, int64_t M, int32_t D, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(x && y && M > 0 && D > 0 && D % 16 == 0 && dtype_ok(dtype), "comat_geglu_il_fwd: bad args (D must be a multiple of 16)");
+    COMAT_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "comat_geglu_il_fwd: operands must be 16-byte aligned");
+    const int g = grid_1d(M * (D / 8), NT, 1 << 20);
+    if (dtype == COMAT_BF16) hipLaunchKernelGGL(geglu_il_fwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, ST, (const bf16_t*)x, (bf16_t*)y, M, D);
+    else hipLaunchKernelGGL(geglu_il_fwd_kernel<float>, dim3(g), dim3(NT), 0, ST, (const float*)x, (float*)y, M, D);
+    return comat_check_launch("comat_geglu_il_fwd");
+}
+
+extern "C" int comat_geglu_il_bwd(const void* dy, const void* x, void* dx, int64_t M, int32_t D, int32_t dtype, void* stream) {
+    COMAT_REQUIRE(dy && x && dx && M > 0 && D > 0 && D % 16 == 0 && dtype_ok(dtype), "comat_geglu_il_bwd: bad args (D must be a multiple of 16)");
+    COMAT_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "comat_geglu_il_bwd: operands must be 16-byte aligned");
+    const int g = grid_1d(M * (D / 8), NT, 1 << 20);
+    if (dtype == COMAT_BF16)
+        hipLaunchKernelGGL(geglu_il_bwd_kernel<bf16_t>, dim3(g), dim3(NT), 0, ST, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, M, D);
+    else hipLaunchKernelGGL(geglu_il_bwd_kernel<float>, dim3(g), dim3(NT), 0, ST, (const float*)dy, (const float*)x, (float*)dx, M, D);
+    return comat_check_launch("comat_geglu_il_bwd");
 }
 
 extern "C" int comat_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int32_t D, int32_t dtype,

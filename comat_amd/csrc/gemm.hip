@@ -713,7 +713,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
-    if (p->in_dtype == COMAT_BF16 && !p->transA && !p->transB && p->batch2 == 1) {  // lean kernel first (option gemm3)
+    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && (p->epi2 == 1 || p->epi2 == 2)), "comat_gemm: bad second epilogue");
+    if (p->epi2 == 0 && p->in_dtype == COMAT_BF16 && !p->transA && !p->transB && p->batch2 == 1) {  // lean kernel first (option gemm3)
         const comat_gemm_segment one = {p->A, p->B, p->K, p->lda, p->ldb, p->sA1, p->sB1};
         const int rc3 = comat_gemm3_try(p, &one, 1, false, stream);
         if (rc3 > 0) {
@@ -723,6 +724,9 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     }
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
+    COMAT_REQUIRE(p->epi2 == 0 || rc2 > 0,
+                  "comat_gemm: the GEGLU epilogue needs a problem the pipelined kernel takes (bf16 / fp8 k-contiguous operands, M >= 16, "
+                  "bf16 output, N %% 32 == 0, 16-byte aligned rows, no residual / bias2 / activation / batch)");
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
     COMAT_REQUIRE(p->in_dtype != COMAT_FP8_E4M3,
                   "comat_gemm: fp8 operands need transA = transB = 0, K %% 64 == 0, 16-byte aligned rows, batch2 == 1");

@@ -211,8 +211,10 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                 half_swap(v[j], v[4 + j]);
                 half_swap(v[8 + j], v[12 + j]);
             }
-            const int64_t nb = n0 + wc * WTN + b * 32 + 8 * h;
-            if (m < g.M) {
+            const int64_t nt = n0 + wc * WTN + b * 32, nb = nt + 8 * h;
+            if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
+                if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
+            } else if (m < g.M) {
                 if (nb < g.N) epilogue_run<WT>(ep, v, m, nb, g.N, vec);
                 if (nb + 16 < g.N) epilogue_run<WT>(ep, v + 8, m, nb + 16, g.N, vec);
             }
@@ -1131,6 +1133,7 @@ static void fill_epi(Args2& a, const comat_gemm_params* p) {
     a.ep.ldc = p->ldc; a.ep.ldr = p->ldr; a.ep.rows_per_b2 = p->rows_per_bias2 > 0 ? p->rows_per_bias2 : 1;
     a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
+    a.ep.C2 = p->C2; a.ep.ldc2 = p->ldc2; a.ep.epi2 = p->epi2;
 }
 
 // 16-byte epilogue accesses: 8 columns per lane must stay inside a row and every row start must be 16-byte aligned
@@ -1288,6 +1291,12 @@ int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
     a.scale_a = fp8 ? p->scale_a : nullptr;
     a.scale_b = fp8 ? p->scale_b : nullptr;
     fill_epi(a, p);
+    if (p->epi2) {  // GEGLU epilogue: bf16 output, 16-byte rows, whole 32-column tiles, nothing else fused
+        if ((p->epi2 != 1 && p->epi2 != 2) || p->out_dtype != COMAT_BF16 || p->N % 32 || p->R || p->bias2 || p->act != COMAT_ACT_NONE ||
+            p->batch1 > 1 || !p->C2 || !al16(p->C2) || p->ldc2 % 8 || p->ldc2 < p->N / 2 || (p->bias && !al16(p->bias)))
+            return -1;
+        if (p->epi2 == 1 && (!al16(p->C) || p->ldc % 8)) return -1;
+    }
     return finish_launch(a, false, fp8, p->batch1, p->ws, p->ws_bytes, stream);
 }
 

@@ -385,6 +385,7 @@ int pick_cfg(const Prob3& P) {
     const int64_t b = P.batch;
     const int64_t t64 = cdiv64(P.M, 64) * cdiv64(P.N, 64) * b, t6432 = cdiv64(P.M, 64) * cdiv64(P.N, 32) * b;
     const bool deep = P.nch >= 16;
+    if (P.M <= 32) return G3_32x32x4;  // the shapes the rule of g3_wants takes (best of the nine on all of them)
     if (t64 >= 192) return deep ? G3_64x64x8 : G3_64x64x4;
     if (t6432 >= 192) return deep ? G3_64x32x8 : G3_64x32x4;
     return deep ? G3_32x32x8 : G3_32x32x4;
@@ -395,9 +396,12 @@ bool g3_wants(const Prob3& P) {
     const int opt = comat_option(COMAT_OPT_GEMM3);
     if (opt == 0) return false;
     if (opt >= 2) return true;
-    // latency-bound on the pipelined kernel: few 128 x 128 tiles' worth of output
-    const int64_t out = P.M * P.N * P.batch;
-    return out <= 1280 * 1024;
+    // Measured (profiles/r04_b_mb_gemm3.txt): fragment-shaped register loads lose to the DMA ring almost everywhere - 32
+    // cache lines per wave-instruction keep the texture path busy (gemm 512 x 1280 x 1280: 13 us against 9.1) - and win only
+    // where a 64-row tile of the pipelined kernel would be three quarters padding AND the contraction is short: the BLIP
+    // text decoder at T = 16 (16 x 768 x 768: 5.4 us against 7.2, 16 x 3072 x 768: 5.4 against 7.4; but 16 x 768 x 3072:
+    // 11.7 against 9.9).
+    return P.M <= 32 && P.nch <= 16 && P.batch == 1;
 }
 
 }  // namespace

@@ -13,6 +13,10 @@ struct Epi {
     int64_t ldc, ldr, rows_per_b2;
     float alpha, beta;
     int act, out_dt, r_dt;
+    // second epilogue (comat_gemm_params::epi2, pipelined kernel only): GEGLU over value / gate columns interleaved in 16s
+    void* C2;
+    int64_t ldc2;
+    int epi2;
 };
 
 // XCD-aware workgroup -> work-item map.  Workgroup b is dispatched to XCD b % 8 (MI355X: 8 XCDs, a private 4 MiB L2
@@ -159,6 +163,38 @@ __device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m,
             }
         }
     }
+}
+
+// GEGLU epilogue (comat_gemm_params::epi2): `v` = the lane's 16 values of one output row after the half swaps - v[0..8) are
+// columns nt + 8 h .. (value channels), v[8..16) columns nt + 16 + 8 h .. (their gate channels), nt = first column of the
+// 32-column tile.  out = value * gelu(gate) for 8 channels -> ONE 16-byte store into C2 [M, N / 2]; with epi2 == 1 the
+// pre-activations are stored too (C, same layout as without the fusion: the backward pass reads them).  Both halves are
+// rounded to the storage type BEFORE the product, exactly what the unfused pair of kernels computes.
+__device__ __forceinline__ void epilogue_geglu(const Epi& ep, const float* v, int64_t m, int64_t nb, int64_t nt, int h) {
+    float a[8], g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = v[e] * ep.alpha;
+        g[e] = v[8 + e] * ep.alpha;
+    }
+    if (ep.bias) {
+        const float4 a0 = *(const float4*)(ep.bias + nb), a1 = *(const float4*)(ep.bias + nb + 4);
+        const float4 g0 = *(const float4*)(ep.bias + nb + 16), g1 = *(const float4*)(ep.bias + nb + 20);
+        a[0] += a0.x; a[1] += a0.y; a[2] += a0.z; a[3] += a0.w; a[4] += a1.x; a[5] += a1.y; a[6] += a1.z; a[7] += a1.w;
+        g[0] += g0.x; g[1] += g0.y; g[2] += g0.z; g[3] += g0.w; g[4] += g1.x; g[5] += g1.y; g[6] += g1.z; g[7] += g1.w;
+    }
+    Pack16 pa, pg, po;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        pa.h[e] = f32_to_bf16(a[e]);
+        pg.h[e] = f32_to_bf16(g[e]);
+        po.h[e] = f32_to_bf16(bf16_to_f32(pa.h[e]) * gelu_f(bf16_to_f32(pg.h[e])));
+    }
+    if (ep.epi2 == 1) {
+        *(uint4*)((bf16_t*)ep.C + m * ep.ldc + nb) = pa.u;
+        *(uint4*)((bf16_t*)ep.C + m * ep.ldc + nb + 16) = pg.u;
+    }
+    *(uint4*)((bf16_t*)ep.C2 + m * ep.ldc2 + (nt >> 1) + 8 * h) = po.u;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------

@@ -69,13 +69,14 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // bit-identical.  Round 4, call 1: the step's gemm2_kernel launches
                                                           // read 24.3 MB each instead of 34.6 (FETCH_SIZE), C2 125.3 -> 122.7 ms;
                                                           // per problem 0 - 8 % faster, never slower (profiles/r04_a_g2_diag.txt)
-    {"flash_xcd", "COMAT_FLASH_XCD", 0, 0, false},        // fused attention: 1 = workgroups renumbered so that the blocks of one
+    {"flash_xcd", "COMAT_FLASH_XCD", 1, 0, false},        // fused attention: 1 = workgroups renumbered so that the blocks of one
                                                           // (batch, head) run on ONE XCD (its K / V - Q / dO in dK/dV - are
                                                           // fetched into one L2 instead of eight).  Bit-identical.  Round 4, call 1:
                                                           // reads per launch 29.1 -> 9.7 MB (forward), 58.9 -> 34.1 (dQ), 62.6 ->
                                                           // 26.1 (dK/dV); kernel times unchanged within 2 % (VALU-bound)
-    {"gemm3", "COMAT_GEMM3", 0, 0, false},                // lean k-parallel-wave GEMM (gemm3.hip) for launch-latency-bound
-                                                          // problems: 0 never, 1 where its rule wants them, 2 every eligible
+    {"gemm3", "COMAT_GEMM3", 1, 0, false},                // lean k-parallel-wave GEMM (gemm3.hip): 0 never, 1 (default) where its
+                                                          // rule wants a problem (<= 32 rows, short contraction: the BLIP text
+                                                          // decoder), 2 every eligible problem (tests, microbenchmarks)
     {"g3_cfg", "COMAT_G3_CFG", 0, 0, false},              // force its tile shape: 1 32x32 / 8 waves, 2 64x32 / 8, 3 32x64 / 8,
                                                           // 4 64x64 / 4, 5 64x64 / 8, 6 32x32 / 4, 7 64x32 / 4, 8 32x32 / 16, 9 64x32 / 16
     {"gemm3_chain", "COMAT_GEMM3_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch on the lean kernel: 0 never (two

@@ -354,6 +354,28 @@ class FrozenLinear:
         self.out_features, self.in_features = self.w.shape
 
 
+class FrozenGegluLinear:
+    """`ff.net.0.proj` of a BasicTransformerBlock followed by its GEGLU (3P diffusers GEGLU: `value, gate = proj(x).chunk(2, -1);
+    value * gelu(gate)`): a frozen Linear(in -> 2 D) whose output ROWS are stored interleaved in sixteens - rows 32 t .. 32 t + 15 =
+    value channels 16 t .., rows 32 t + 16 .. 32 t + 31 = their gate channels - so that one lane of the GEMM epilogue owns value
+    and gate of the same 8 channels and the product leaves the GEMM (comat_gemm_params::epi2).  `w` [2 D, in] / `wt` [in, 2 D]
+    / `bias` [2 D] in that order; `out_features` = D."""
+
+    def __init__(self, weight: torch.Tensor, bias, dtype, device):
+        n2, k = weight.shape
+        D = n2 // 2
+        assert n2 % 32 == 0, "GEGLU projection: 2 D must be a multiple of 32"
+        t = torch.arange(n2 // 32).reshape(-1, 1, 1)
+        j = torch.arange(16).reshape(1, 1, -1)
+        half = torch.arange(2).reshape(1, -1, 1)
+        self.perm = (half * D + t * 16 + j).reshape(-1)  # interleaved position -> original row
+        w = weight.to(device=device, dtype=torch.float32)[self.perm.to(device)]
+        self.w = w.to(dtype).contiguous()
+        self.wt = w.t().contiguous().to(dtype)
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32)[self.perm.to(device)].contiguous()
+        self.out_features, self.pre_features, self.in_features = D, n2, k
+
+
 def frozen_linear_group(weights, biases, dtype, device):
     """FrozenLinears of projections that read the same input (same [N, K] each), allocated as ONE [G, N, K] buffer
     (+ one [G, K, N] for the transposes): the group's forward is then a single batched launch."""
@@ -675,6 +697,65 @@ def geglu(x):
     return _Geglu.apply(x)
 
 
+# COMAT_GEGLU_FUSED=0: the projection and the GEGLU as two launches (A/B runs, tests); both forms use the interleaved layout
+_geglu_fused = os.environ.get("COMAT_GEGLU_FUSED", "1") != "0"
+
+
+def set_geglu_fused(flag: bool):
+    global _geglu_fused
+    _geglu_fused = bool(flag)
+
+
+class _GegluLinear(Function):
+    """y = GEGLU(x W^T + b) with the interleaved weight of FrozenGegluLinear: ONE launch (the product leaves the GEMM epilogue;
+    the pre-activations are stored only when a backward pass will read them) where the library's pipelined kernel takes the
+    problem, else the GEMM and the interleaved-layout GEGLU kernel."""
+
+    @staticmethod
+    def forward(ctx, x, lin):
+        x = _c(x)
+        M, Kd = x.shape
+        D, N2 = lin.out_features, lin.pre_features
+        k = kernels()
+        need_pre = ctx.needs_input_grad[0]
+        y = x.new_empty((M, D))
+        use8 = _use_fp8(lin, Kd)
+        if use8:
+            a, (w, sw) = k.fp8_quantize(x), fp8_weight(lin)
+            a, scales = a[0], (a[1], sw)
+        else:
+            a, w, scales = x, lin.w, None
+        pre = None
+        if _geglu_fused and y.dtype == torch.bfloat16 and k.geglu_gemm_ok(a, w, M, N2, Kd):
+            pre = x.new_empty((M, N2)) if need_pre else None
+            k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales, geglu=(y, need_pre))
+        else:
+            pre = x.new_empty((M, N2))
+            k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales)
+            k.geglu_il_fwd(pre, y, M, D)
+        ctx.lin = lin
+        if need_pre:
+            ctx.save_for_backward(pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (pre,) = ctx.saved_tensors
+        lin = ctx.lin
+        M, N2 = pre.shape
+        k = kernels()
+        dpre = torch.empty_like(pre)
+        k.geglu_il_bwd(_c(g), pre, dpre, M, lin.out_features)
+        dx = pre.new_empty((M, lin.in_features))
+        k.gemm(dpre, lin.wt, dx, M, lin.in_features, N2, N2, N2, lin.in_features)
+        return dx, None
+
+
+def geglu_linear(x, lin: "FrozenGegluLinear"):
+    """GEGLU(x W^T + b) - the feed-forward's first projection and its gate in one operator (see _GegluLinear)"""
+    return _GegluLinear.apply(x, lin)
+
+
 class _ConcatCols(Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -813,7 +894,7 @@ def _uniform_stride(ts):
 # The two dependent products of a LoRA projection - h = s x D^T then y = [x | h] [W | U]^T, and in the backward pass u = s g U
 # then dx = [g | u] [W^T | D^T]^T - handed to the library as ONE chained call (comat_gemm_chain: one launch where its lean
 # kernel takes both, else the two launches).  COMAT_LORA_CHAIN=0 keeps the separate calls of rounds 1-3.
-_lora_chain = os.environ.get("COMAT_LORA_CHAIN", "1") != "0"
+_lora_chain = os.environ.get("COMAT_LORA_CHAIN", "0") == "1"
 
 
 def set_lora_chain(flag: bool):

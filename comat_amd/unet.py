@@ -87,6 +87,11 @@ class _Mods:
         return self._tag(ops.FrozenLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device),
                          name)
 
+    def geglu_lin(self, name):
+        """`ff.net.0.proj` with the GEGLU behind it (ops.FrozenGegluLinear: rows interleaved for the fused epilogue)"""
+        return self._tag(ops.FrozenGegluLinear(self.sd[name + ".weight"], self.sd.get(name + ".bias"), self.dtype, self.device),
+                         name)
+
     def lin_group(self, names):
         """projections that read the same input: one co-allocated weight buffer when their shapes agree"""
         ws = [self.sd[n + ".weight"] for n in names]
@@ -152,7 +157,7 @@ class CrossAttnBlock:
                     att[(a, key)] = (m.lin_group([f"{b}.{a}.{p}" for p in projs]),
                                      lora.group[(f"{b}.{a}", key)] if lora is not None else None)
             self.layers.append(dict(ln=[m.norm(f"{b}.norm{i}") for i in (1, 2, 3)], att=att,
-                                    ff1=m.lin(f"{b}.ff.net.0.proj"), ff2=m.lin(f"{b}.ff.net.2")))
+                                    ff1=m.geglu_lin(f"{b}.ff.net.0.proj"), ff2=m.lin(f"{b}.ff.net.2")))
 
     def _self_attn(self, att, x, B, N):
         q, k, v = ops.lora_group_linear(x, *att[("attn1", "qkv")])
@@ -190,7 +195,7 @@ class CrossAttnBlock:
             o, probs = self._cross_attn(att, y, ctx, B, N, L, want_probs, kv_cache)
             h = ops.lora_group_linear(o, *att[("attn2", "out")], residual=h)[0]
             y, h = ops.layer_norm_fork(h, *ln[2])
-            f = ops.geglu(ops.linear(y, Lr["ff1"]))
+            f = ops.geglu_linear(y, Lr["ff1"])  # projection + GEGLU: one launch
             h = ops.linear(f, Lr["ff2"], residual=h)
             if want_probs:
                 probs_all.append(probs)

@@ -77,6 +77,18 @@ typedef struct {
      * need transA == transB == 0, K % 64 == 0, lda/ldb % 16 == 0; anything else is COMAT_EINVAL (no silent fallback). */
     const float* scale_a;
     const float* scale_b;
+    /* Second epilogue (ABI 5; comat_gemm only, problems the pipelined kernel takes - else COMAT_EINVAL):
+     *   epi2 = 1 / 2: GEGLU.  The N = 2 D output columns hold value and gate channels INTERLEAVED in sixteens (columns
+     *   32 t .. 32 t + 15 = value channels 16 t .., columns 32 t + 16 .. 32 t + 31 = their gate channels: the caller permutes
+     *   the rows of B and the bias once); C2 [M, D] (leading dimension ldc2) receives value * gelu(gate), both rounded to bf16
+     *   first.  epi2 = 1 also stores the pre-activations to C (what the backward pass reads), epi2 = 2 does not (C may be
+     *   NULL).  bf16 output, N % 32 == 0, 16-byte aligned rows; no residual, bias2, activation or batch.
+     * Replaces the separate GEGLU kernel behind `ff.net.0.proj` of every BasicTransformerBlock (3P diffusers GEGLU, reached
+     * from TrainableSDPipeline.py:144-150): one launch and one [M, 2 D] read less per block, and no [M, 2 D] write at all in
+     * the no-grad denoise steps. */
+    void* C2;
+    int64_t ldc2;
+    int32_t epi2;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 
@@ -239,6 +251,10 @@ int comat_axpby(float a, const void* x, float b, const void* y, void* out, int64
 /* GEGLU: x [M, 2D] -> y[m, d] = x[m, d] * gelu(x[m, D + d]) */
 int comat_geglu_fwd(const void* x, void* y, int64_t M, int32_t D, int32_t dtype, void* stream);
 int comat_geglu_bwd(const void* dy, const void* x, void* dx, int64_t M, int32_t D, int32_t dtype, void* stream);
+/* The same on the INTERLEAVED layout of the fused projection (comat_gemm_params::epi2): x, dx [M, 2 D] with value / gate
+ * channels interleaved in sixteens, y, dy [M, D]; D % 16 == 0, 16-byte aligned operands.  16-byte accesses. */
+int comat_geglu_il_fwd(const void* x, void* y, int64_t M, int32_t D, int32_t dtype, void* stream);
+int comat_geglu_il_bwd(const void* dy, const void* x, void* dx, int64_t M, int32_t D, int32_t dtype, void* stream);
 /* strided 2-D copy (channel concat / split): dst[r, c] = src[r, c] for r < rows, c < cols */
 int comat_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
                  int32_t src_dtype, int32_t dst_dtype, void* stream);

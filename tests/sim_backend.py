@@ -41,7 +41,7 @@ class SimKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
              sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
-             beta=0.0, act=ACT_NONE, scales=None):
+             beta=0.0, act=ACT_NONE, scales=None, geglu=None):
         b1, b2 = batch
         assert (scales is not None) == (A.dtype == torch.uint8)
         if scales is not None:
@@ -57,7 +57,31 @@ class SimKernels:
         acc = _act(acc, act)
         if R is not None:
             acc = acc + beta * _v(R, (b1, b2, M, N), (sR[0], sR[1], ldr, 1)).float()
+        if geglu is not None:  # comat_gemm_params::epi2: value / gate columns interleaved in sixteens, both rounded first
+            y, keep = geglu
+            assert b1 == b2 == 1 and N % 32 == 0 and R is None and act == ACT_NONE and bias2 is None
+            pre = acc.reshape(M, N).to(y.dtype)
+            if keep:
+                _v(Cout, (M, N), (ldc, 1)).copy_(pre)
+            t = pre.float().reshape(M, N // 32, 2, 16)
+            y.copy_((t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, N // 2).to(y.dtype))
+            return
         _v(Cout, (b1, b2, M, N), (sC[0], sC[1], ldc, 1)).copy_(acc.to(Cout.dtype))
+
+    @staticmethod
+    def geglu_gemm_ok(x, w, M, N, K):
+        return N % 32 == 0 and M >= 1
+
+    def geglu_il_fwd(self, x, y, M, D):
+        t = x.float().reshape(M, D // 16, 2, 16)
+        y.copy_((t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, D).to(y.dtype))
+
+    def geglu_il_bwd(self, dy, x, dx, M, D):
+        t = x.float().detach().reshape(M, D // 16, 2, 16).requires_grad_(True)
+        with torch.enable_grad():
+            out = (t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, D)
+            (g,) = torch.autograd.grad(out, t, dy.float())
+        dx.copy_(g.reshape(M, 2 * D).to(dx.dtype))
 
     def gemm_segments(self, segs, Cout, M, N, ldc, bias=None, R=None, ldr=0, alpha=1.0, beta=0.0, batch=1, sC=0, sR=0):
         acc = torch.zeros((batch, M, N), dtype=torch.float32)

@@ -769,7 +769,7 @@ def test_adamw_with_clip(dev):
 
 
 # the library's defaults for the options whose default moved in round 4 (runtime.hip)
-DEFAULT_OPTS = dict(flash_xcd=0, g2_order=2, gemm3=0, gemm3_chain=0, gemm2_chain=0)
+DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0)
 
 
 def _set_opts(**kw):
@@ -1080,6 +1080,42 @@ def test_flash_two_tiles_per_iteration(hip, cfg, default_opts):
     check(outs[1][2], back(qr, Nq), dtype, "flash dQ, two tiles per iteration", factor=3)
     check(outs[1][3], back(kr, Nk), dtype, "flash dK, two tiles per iteration", factor=3)
     check(outs[1][4], back(vr, Nk), dtype, "flash dV, two tiles per iteration", factor=3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(64, 96, 64), (300, 320, 1280), (16, 64, 32)])
+def test_geglu_linear(dev, dtype, shape):
+    """ops.geglu_linear (the feed-forward's first projection with its GEGLU in the GEMM epilogue, weight rows interleaved in
+    sixteens) against `value, gate = (x W^T + b).chunk(2, -1); value * gelu(gate)` on the ORIGINAL weight: output, input
+    gradient; and the no-grad call (which stores no pre-activations) gives the same output."""
+    M, K, D = shape
+    w, b = rnd(2 * D, K, dtype=dtype, seed=1, scale=K ** -0.5), rnd(2 * D, seed=2)
+    lin = ops.FrozenGegluLinear(w, b, dtype, dev)
+    x = rnd(M, K, dtype=dtype, seed=3)
+    go = rnd(M, D, dtype=dtype, seed=4)
+    xd = dv(x, dev, dtype, grad=True)
+    y = ops.geglu_linear(xd, lin)
+    y.backward(dv(go, dev, dtype))
+    xr = x.clone().requires_grad_(True)
+    pre = (xr @ w.t() + b).to(dtype).float() if dtype != torch.float32 else xr @ w.t() + b
+    pre = xr @ w.t() + b
+    ref = pre[:, :D] * F.gelu(pre[:, D:])
+    ref.backward(go)
+    check(y, ref, dtype, "geglu_linear", factor=2)
+    check(xd.grad, xr.grad, dtype, "geglu_linear dx", factor=3)
+    with torch.no_grad():
+        y2 = ops.geglu_linear(dv(x, dev, dtype), lin)
+    assert torch.equal(y2, y.detach()), "no-grad call differs"
+    # the two-launch form (projection, then the interleaved-layout GEGLU kernel) computes the same bits: both round the
+    # pre-activations to the storage type before the product
+    ops.set_geglu_fused(False)
+    try:
+        xs = dv(x, dev, dtype, grad=True)
+        y3 = ops.geglu_linear(xs, lin)
+        y3.backward(dv(go, dev, dtype))
+    finally:
+        ops.set_geglu_fused(True)
+    assert torch.equal(y3, y) and torch.equal(xs.grad, xd.grad), "fused and two-launch GEGLU differ"
 
 
 G3_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9]

@@ -38,7 +38,7 @@ def graph_time(fn, reps=20):
 print("# B HW C G : fwd us (3 launches -> 1 launch), bwd us (3 launches -> 1 launch), bytes moved fwd")
 for B, HW, C, G in [(2, 4096, 320, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), (2, 1024, 640, 32), (2, 1024, 1280, 32),
                     (2, 1024, 1920, 32), (2, 256, 1280, 32), (2, 256, 2560, 32), (2, 64, 1280, 32), (2, 64, 2560, 32),
-                    (1, 4096, 320, 32), (1, 4096, 512, 32)]:
+                    (1, 4096, 320, 32), (1, 4096, 512, 32), (1, 16384, 512, 32), (1, 65536, 256, 32), (1, 262144, 128, 32)]:
     x = torch.randn(B * HW, C, device=dev).to(T)
     dy = torch.randn(B * HW, C, device=dev).to(T)
     add = torch.randn(B * HW, C, device=dev).to(T)
