@@ -335,7 +335,7 @@ def cpu_baseline(usd, scfg):
     are absent) on a BOUNDED sample of the same workload, per SURVEY.md 8d: one UNet call without grad and one with
     grad (LoRA + input gradients) at the workload's own size (CFG batch 2, 64x64 latents, 77 text tokens), one BLIP
     reward forward + backward at 510^2 -> 384^2, one VAE decode forward + backward on a 32x32 latent (a quarter of the
-    pixels; x4).  Each component: 1 warm-up + 3 timed repetitions, median, on min(host threads, 64) threads (see below).
+    pixels; x4).  Each component: 2 warm-ups (1 for the trained UNet call) + 3 timed repetitions, median, on min(host threads, 64) threads (see below).
     The step time is the medians combined by
     the step's call counts (the discriminator is the same UNet: G side batch 1 = half a trained call, D side batch 2 = one
     trained call)."""
@@ -345,7 +345,7 @@ def cpu_baseline(usd, scfg):
     import dataclasses
     cores = os.cpu_count() or 1
 
-    def timed(fn, reps=3, warm=1):
+    def timed(fn, reps=3, warm=2):
         for _ in range(warm):
             fn()
         ts = []
@@ -378,7 +378,7 @@ def cpu_baseline(usd, scfg):
             p.grad = None
         xg = x.clone().requires_grad_(True)
         O.unet_forward(usd, ocfg, xg, 801, ctx, lora, None).float().square().mean().backward()
-    t["unet_train"], reps_all["unet_train"] = timed(train, warm=0)  # the pool is warm; 13 s per repetition
+    t["unet_train"], reps_all["unet_train"] = timed(train, warm=1)  # (round 3 ran it cold: 13.3 / 10.7 / 10.2 s)
     del lora
     vcfg = O.VAEConfig(**dataclasses.asdict(config.SD15_VAE))
     vsd = weights.make_vae_weights(config.SD15_VAE, seed=2345)
@@ -404,7 +404,7 @@ def cpu_baseline(usd, scfg):
     step_s = (scfg.K * t["unet_train"] + (scfg.total_step - scfg.K) * t["unet_nograd"] + 4 * t["vae_quarter_train"]
               + t["blip_train"] + (1.5 * t["unet_train"] if scfg.gan_loss else 0.0))
     return {"value": 1.0 / step_s, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle/ (CPU fp32) components, median of 3 repetitions after a warm-up, on {threads} of {cores} host "
+            "sample": f"oracle/ (CPU fp32) components, median of 3 repetitions after two warm-ups (one for unet_train), on {threads} of {cores} host "
                       "threads (all 256 threads of an MI355X host measured 32x slower in round 3): " + ", ".join(f"{k} {v:.1f} s" for k, v in t.items())
                       + f"; step = {scfg.K} x unet_train + {scfg.total_step - scfg.K} x unet_nograd + 4 x vae_quarter_train + "
                       f"blip_train + 1.5 x unet_train (discriminator G and D sides) = {step_s:.0f} s",
@@ -413,15 +413,27 @@ def cpu_baseline(usd, scfg):
 
 
 def load_pmc_summary():
-    """HBM traffic / MFMA-busy figures of the dominant kernel from the committed counter pass (separate rocprofv3 --pmc
-    runs of tools/pmc_targets.py, converted by tools/pmc_to_json.py).  Counters cannot be collected inside a timed run."""
-    p = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r03_pmc_kernels.json", "r02_pmc_kernels.json"))
-              if os.path.exists(q)), None)
-    if p is None:
+    """HBM traffic / MFMA-busy figures of the dominant kernel from the newest committed counter pass (separate rocprofv3
+    --pmc runs, converted by tools/pmc_to_json.py - counters cannot be collected inside a timed run).  The pass records the
+    build id of the library it profiled (comat_build_id(): a hash of the kernel sources, plan table and build flags); the
+    figures are quoted only when that is the library loaded NOW, otherwise traffic and mfma_busy_frac are null and the note
+    says why."""
+    import glob
+    from comat_amd import _hip
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_kernels.json")))
+    if not files:
         return None
-    with open(p) as f:
+    with open(files[-1]) as f:
         d = json.load(f)
-    return d.get("bench_roofline")
+    out = dict(d.get("bench_roofline") or {})
+    have, want = d.get("build_id"), _hip.build_id()
+    if have != want:
+        out["traffic_bytes_per_launch"] = out["mfma_busy_frac"] = None
+        out["note"] = (f"{os.path.basename(files[-1])} was measured on build {have or '(not recorded: before round 4)'}, the loaded "
+                       f"library is build {want}: counter figures withheld (re-run tools/calls/r4_final.sh pmc)")
+    else:
+        out["note"] = f"{out.get('note', '')} [{os.path.basename(files[-1])}, build {have}]".strip()
+    return out
 
 
 def attn_map_probe():
@@ -519,6 +531,35 @@ def secondary_c3(trainer, batch, rank, sync, steps=3):
             "gpu_ms_per_step_by_piece": phases}
 
 
+def secondary_c4(device, dtype, rank, sync, steps=2):
+    """BASELINE config C4 (SDXL generator 512^2, SD1.5 discriminator, the full loss set of scripts/sdxl.sh) in the default
+    line, so that the driver's run carries an SDXL number: its own world (random-init SDXL UNet / VAE, ~75 s to build), the 45
+    no-grad UNet graphs, the step segments; `steps` timed steps after the capturing ones.  N = 1 only."""
+    from comat_amd.segments import SegmentedStep
+    t0 = time.time()
+    tr, b, fixed, scfg, _, t_build = build_world(device, dtype, rank, "c4")
+    st = SegmentedStep(tr)
+    for kw in precapture_plan(scfg, fixed):
+        st(b, **kw)
+    st(b, **fixed)
+    sync()
+    t1 = time.time()
+    for _ in range(steps):
+        st(b, **fixed)
+    sync()
+    ms = (time.time() - t1) / steps * 1e3
+    total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=True, res=scfg.resolution)
+    out = {"workload": "C4: SDXL generator 512x512 bs=1 (SD1.5 discriminator), N=50 denoise steps (K=5 sampled with grad), concept-"
+                       "matching + GAN + attribute concentration, clip+AdamW for G and D - scripts/sdxl.sh of the reference",
+           "ms_per_step": round(ms, 1), "images_per_sec": round(1e3 / ms, 3), "steps": steps, "build_s": round(t_build, 1),
+           "set_up_s": round(t1 - t0, 1), "launch_mode": f"no-grad UNet graphs + step segments ({st.stats()['segments']} segment graphs)",
+           "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS}
+    del st, tr, b
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def precapture_plan(scfg, fixed):
     """Keyword sets for a few REAL optimisation steps that make a SegmentedStep visit every (slot, variant) once before
     the timed region: with attribute concentration each trained-call slot has two variants (maps captured or not) and
@@ -533,6 +574,9 @@ def precapture_plan(scfg, fixed):
         plans.append([ts[4]])
     base = {k: v for k, v in fixed.items() if k != "training_steps"}
     return [dict(base, training_steps=list(ts), attrcon_steps=p) for p in plans]
+
+
+T_PROCESS = time.time()
 
 
 def main():
@@ -815,6 +859,14 @@ def main():
             secondary = {"c3": secondary_c3(trainer, batch, rank, sync)}
         except Exception as e:  # noqa: BLE001 - the headline number must not depend on the secondary one
             secondary = {"c3": {"error": f"{type(e).__name__}: {e}"}}
+        if os.environ.get("COMAT_SECONDARY_C4", "1") != "0":
+            if time.time() - T_PROCESS > 300:  # keep the default run within minutes whatever the box
+                secondary["c4"] = {"skipped": "the run had used more than 300 s before the SDXL measurement"}
+            else:
+                try:
+                    secondary["c4"] = secondary_c4(device, dtype, rank, sync)
+                except Exception as e:  # noqa: BLE001
+                    secondary["c4"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)

@@ -132,6 +132,7 @@ def load_library(path: str | None = None):
     lib = C.CDLL(p)
     lib.comat_abi_version.restype = C.c_int
     lib.comat_last_error.restype = C.c_char_p
+    lib.comat_build_id.restype = C.c_char_p
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -147,6 +148,12 @@ GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_k
                      4: "gemm2_tt_group_kernel (grouped k-major products)",
                      5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)",
                      6: "gemm2_chain_kernel (producer + consumer of a chained call in one launch)"}
+
+
+def build_id() -> str:
+    """hash of the sources the loaded library was built from (include/comat_hip.h: comat_build_id)"""
+    load_library()
+    return _lib.comat_build_id().decode()
 
 
 def last_gemm_kernel() -> int:

@@ -703,7 +703,7 @@ extern "C" int64_t comat_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, i
 
 extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p != nullptr, "comat_gemm: null params");
-    COMAT_REQUIRE(p->A && p->B && p->C, "comat_gemm: null operand");
+    COMAT_REQUIRE(p->A && p->B && (p->C || p->epi2 == 2), "comat_gemm: null operand");
     COMAT_REQUIRE(p->M > 0 && p->N > 0 && p->K > 0, "comat_gemm: bad shape M=%ld N=%ld K=%ld", (long)p->M,
                   (long)p->N, (long)p->K);
     COMAT_REQUIRE((dtype_ok(p->in_dtype) || p->in_dtype == COMAT_FP8_E4M3) && dtype_ok(p->out_dtype), "comat_gemm: bad dtype");

@@ -291,36 +291,23 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
                 mu[e] = st[0]; rs[e] = st[1];
             }
         }
-        // four rows per trip: their loads are issued before the first is consumed (a single 16-byte load per trip left the
-        // loop at one L2 round trip per row: round 4).  Rows are still accumulated in ascending order: same bits.
-        constexpr int UNR = 4;
-        for (int rb = r0 + rsub; rb < r1; rb += UNR * R) {
-            GV16 xv[UNR], gv[UNR];
+        for (int r = r0 + rsub; r < r1; r += R) {
+            GV16 xv, gv;
+            xv.u = *(const uint4*)(x + base + (int64_t)r * C + c0);
+            if (MODE == 1) gv.u = *(const uint4*)(dy + base + (int64_t)r * C + c0);
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = rb + u * R;
-                if (r < r1) {
-                    xv[u].u = *(const uint4*)(x + base + (int64_t)r * C + c0);
-                    if (MODE == 1) gv[u].u = *(const uint4*)(dy + base + (int64_t)r * C + c0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                if (rb + u * R >= r1) break;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    const float xe = gv_get<T>(xv[u], e);
-                    if (MODE == 0) {
-                        a1[e] += xe;
-                        a2[e] += xe * xe;
-                    } else {
-                        const float xh = (xe - mu[e]) * rs[e];
-                        float g = gv_get<T>(gv[u], e);
-                        if (silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
-                        g *= gm[e];
-                        a1[e] += g;
-                        a2[e] += g * xh;
-                    }
+            for (int e = 0; e < EPV; ++e) {
+                const float xe = gv_get<T>(xv, e);
+                if (MODE == 0) {
+                    a1[e] += xe;
+                    a2[e] += xe * xe;
+                } else {
+                    const float xh = (xe - mu[e]) * rs[e];
+                    float g = gv_get<T>(gv, e);
+                    if (silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
+                    g *= gm[e];
+                    a1[e] += g;
+                    a2[e] += g * xh;
                 }
             }
         }
@@ -331,43 +318,21 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    // the block's sums per group: 8 lanes per group take every 8th of the group's R x cpg partials (in index order) and meet
-    // in a fixed butterfly - the former single thread per group walked 60+ dependent LDS reads (round 4); a block with more
-    // than NT / 8 groups keeps that form
-    float f1 = 0.f, f2 = 0.f;
-    const bool par = G * 8 <= NT;
-    if (par) {
-        const int gq = threadIdx.x >> 3, sub = threadIdx.x & 7;
-        if (gq < G) {
-            const int n = R * cpg;
-            for (int i = sub; i < n; i += 8) {
-                const int rr = i / cpg, c = gq * cpg + (i - rr * cpg);
-                f1 += p_a[rr * C + c];
-                f2 += p_b[rr * C + c];
-            }
-        }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
-            f1 += __shfl_xor(f1, o, 64);
-            f2 += __shfl_xor(f2, o, 64);
-        }
-    } else if (threadIdx.x < G) {
+    if (threadIdx.x < G) {
+        float f1 = 0.f, f2 = 0.f;
         for (int rr = 0; rr < R; ++rr)
             for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
                 f1 += p_a[rr * C + c];
                 f2 += p_b[rr * C + c];
             }
-    }
-    const int gme = par ? (int)(threadIdx.x >> 3) : (int)threadIdx.x;  // the group this thread reports
-    if (gme < G && (!par || (threadIdx.x & 7) == 0)) {
         // per-block partial (no atomics): reduced in block order by gn_reduce_kernel -> bit-reproducible statistics
         double* part = ws + ((int64_t)(1 + blockIdx.x) * gridDim.y + b) * G * 2;
         if (tickets) {  // write-through (sc1) stores: another workgroup of THIS launch reads them (gemm_shared.h)
-            __hip_atomic_store(part + gme * 2 + 0, (double)f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part + gme * 2 + 1, (double)f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + threadIdx.x * 2 + 0, (double)f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + threadIdx.x * 2 + 1, (double)f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            part[gme * 2 + 0] = (double)f1;
-            part[gme * 2 + 1] = (double)f2;
+            part[threadIdx.x * 2 + 0] = (double)f1;
+            part[threadIdx.x * 2 + 1] = (double)f2;
         }
     }
     if (tickets == nullptr) return;  // three-launch form: gn_reduce(_finalize)_kernel combines the partials
@@ -529,45 +494,29 @@ __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x,
                 s2[e] = FIN ? sm_b[grp] : (float)ws[2 * sg + 1];
             }
         }
-        // rows in trips of UNR: every load of a trip is issued before the first row is processed (round 4: one row per trip
-        // was a load -> compute -> store chain per row)
-        constexpr int UNR = MODE == 0 ? 4 : 2;
-        for (int rb = r0 + rsub; rb < r1; rb += UNR * R) {
-            GV16 xv[UNR], gv[UNR], av[UNR];
+        for (int r = r0 + rsub; r < r1; r += R) {
+            const int64_t off = base + (int64_t)r * C + c0;
+            GV16 xv, gv, av, ov;
+            xv.u = *(const uint4*)(x + off);
+            if (MODE == 1) gv.u = *(const uint4*)(dy + off);
+            if (MODE == 1 && add) av.u = *(const uint4*)(add + off);
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = rb + u * R;
-                if (r < r1) {
-                    const int64_t off = base + (int64_t)r * C + c0;
-                    xv[u].u = *(const uint4*)(x + off);
-                    if (MODE == 1) gv[u].u = *(const uint4*)(dy + off);
-                    if (MODE == 1 && add) av[u].u = *(const uint4*)(add + off);
+            for (int e = 0; e < EPV; ++e) {
+                const float xh = (gv_get<T>(xv, e) - mu[e]) * rs[e];
+                if (MODE == 0) {
+                    float y = xh * gm[e] + bt[e];
+                    if (silu) y = silu_f(y);
+                    gv_set<T>(ov, e, y);
+                } else {
+                    float g = gv_get<T>(gv, e);
+                    if (silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
+                    g *= gm[e];
+                    float d = rs[e] * (g - (s1[e] + xh * s2[e]) * inv_n);
+                    if (add) d += gv_get<T>(av, e);
+                    gv_set<T>(ov, e, d);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int r = rb + u * R;
-                if (r >= r1) break;
-                const int64_t off = base + (int64_t)r * C + c0;
-                GV16 ov;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    const float xh = (gv_get<T>(xv[u], e) - mu[e]) * rs[e];
-                    if (MODE == 0) {
-                        float y = xh * gm[e] + bt[e];
-                        if (silu) y = silu_f(y);
-                        gv_set<T>(ov, e, y);
-                    } else {
-                        float g = gv_get<T>(gv[u], e);
-                        if (silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
-                        g *= gm[e];
-                        float d = rs[e] * (g - (s1[e] + xh * s2[e]) * inv_n);
-                        if (add) d += gv_get<T>(av[u], e);
-                        gv_set<T>(ov, e, d);
-                    }
-                }
-                *(uint4*)(out + off) = ov.u;
-            }
+            *(uint4*)(out + off) = ov.u;
         }
     }
 }

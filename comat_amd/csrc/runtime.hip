@@ -22,6 +22,10 @@ int comat_check_launch(const char* what) {
 }
 
 extern "C" int comat_abi_version(void) { return COMAT_ABI_VERSION; }
+#ifndef COMAT_SRC_HASH
+#define COMAT_SRC_HASH "unknown"
+#endif
+extern "C" const char* comat_build_id(void) { return COMAT_SRC_HASH; }
 extern "C" const char* comat_last_error(void) { return g_err; }
 
 static thread_local int g_last_gemm_kernel = -1;

@@ -32,6 +32,9 @@ enum { COMAT_ACT_NONE = 0, COMAT_ACT_SILU = 1, COMAT_ACT_GELU = 2 };
 
 int comat_abi_version(void);
 const char* comat_last_error(void);
+/* 16 hex digits: a hash of the sources (kernels, headers, plan table, build flags) this library was built from.  Profiles of
+ * the library (rocprofv3 counter passes under profiles/) record it; bench.py quotes them only for the library they describe. */
+const char* comat_build_id(void);
 /* Kernel-selection options for A/B runs, microbenchmarks and the parity tests of every kernel variant: "flash_trim",
  * "flash_tr", "flash_kt", "flash_merge", "gemm2", "gemm2_tt", "g2_cfg", "g2_splits", "force_splits", "norm_fused".  Each defaults to the environment variable
  * COMAT_<NAME> (read once) or its built-in default.  They select among kernels that compute the same function; results

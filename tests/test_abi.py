@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/comat_hip.h but not exported"
-    bound = set(_hip.SIGNATURES) | {"comat_abi_version", "comat_last_error"}
+    bound = set(_hip.SIGNATURES) | {"comat_abi_version", "comat_last_error", "comat_build_id"}
     assert bound == set(names), (bound ^ set(names))
     assert lib.comat_abi_version() == 5
 

@@ -99,7 +99,13 @@ def main():
                 write_cal = CAL_BYTES / (c["WRITE_SIZE"] * 1024)
     groups = sorted((g for g in ctr if "anonymous" in g[0]), key=lambda g: first[g])
     seen = defaultdict(int)
-    out = {"calibration": {"stream_bytes_each_way": CAL_BYTES, "true_over_FETCH_SIZE_KiB": fetch_cal,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from comat_amd import _hip
+    # the library these passes profiled: run this converter from the SAME tree, right after the passes (bench.py quotes the
+    # figures only for a library with this build id)
+    out = {"build_id": _hip.build_id(),
+           "calibration": {"stream_bytes_each_way": CAL_BYTES, "true_over_FETCH_SIZE_KiB": fetch_cal,
                            "true_over_WRITE_SIZE_KiB": write_cal,
                            "applied": "reads: FETCH_SIZE x 1024 x 2 (MI355X_MICROARCH.md, HBM); writes: WRITE_SIZE x 1024 x "
                                       "the measured write factor"}}
