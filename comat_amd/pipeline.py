@@ -201,7 +201,7 @@ class TrainableSDPipeline:
     def decode_tokens(self, lat, bs, h, w, return_latents=False):
         """`vae.decode(latents / scaling_factor)` (+ `/2 + 0.5`, TrainableSDPipeline.py:219-223) on channels-last latent
         tokens -> (image tokens [bs*H*W, 3], H, W)"""
-        z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), self.dtype)
+        z0 = ops.cast_grad(ops.affine(lat, 1.0 / self.vae.cfg.scaling_factor, 0.0), getattr(self.vae, "dtype", self.dtype))
         img, H, W = self.vae(z0, bs, h, w)
         if not (self.is_sdxl and return_latents):  # SDXL + return_latents returns the raw decode (:838-840)
             img = ops.affine(img, 0.5, 0.5)

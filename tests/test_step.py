@@ -22,10 +22,10 @@ from oracle import step as OS
 DTYPES = [torch.float32, torch.bfloat16]
 # bf16 storage against the fp32 oracle on the SAME (bf16-representable) weights: the gradient error is the rounding of
 # every stored activation (2^-9 relative each) carried through ~100 layers and three denoise steps of a random-weight
-# toy network.  Limits = 2 x the largest error measured on an MI355X (profiles/r02_g_bf16_errors.txt) or on the ABI
-# simulator: generator 8.8e-2 (SD1.5 layout) / 1.33e-1 (SDXL layout), discriminator 2.2e-2, discriminator head 6.0e-3.
-# At the REAL model size the same comparison gives 2.8e-2 (tests/test_zz_fullsize_c1.py).
-BF16_GRAD_LIMIT = 0.18
+# toy network.  Limits = 2 x the largest error measured on an MI355X (profiles/r03_z_bf16_errors.txt) or on the ABI
+# simulator: generator 8.4e-2 (SD1.5 layout) / 1.09e-1 (SDXL layout; 1.33e-1 on the simulator), discriminator 3.1e-2 (2.2e-2 at
+# rank 4), discriminator head 7.5e-3.  At the REAL model size the same comparison gives 1.7e-2 (tests/test_zz_fullsize_c1.py).
+BF16_GRAD_LIMIT = 0.17
 BF16_GRAD_LIMIT_SDXL = 0.27
 BF16_D_GRAD_LIMIT = 0.045
 BF16_HEAD_GRAD_LIMIT = 0.012

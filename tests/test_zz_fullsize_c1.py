@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 pytestmark = [pytest.mark.gpu]
-BF16_FULL_GRAD_LIMIT = 0.06  # 2 x the 2.8e-2 measured on an MI355X (profiles/r02_g_bf16_errors.txt)
+BF16_FULL_GRAD_LIMIT = 0.035  # 2 x the 1.7e-2 measured on an MI355X (profiles/r03_z_bf16_errors.txt, r04_*)
 
 
 def test_c1_full_size_bf16_error_is_bounded(hip):

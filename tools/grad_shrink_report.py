@@ -6,7 +6,12 @@ grouped by UNet level, attention kind, projection and factor.  For every group: 
 relative error, and the COSINE between the two gradients estimated from the projections - a ratio below one with cosine
 near one is a systematic attenuation, a ratio near sqrt(1 - err^2)-ish with lower cosine is noise.
 
-    python tools/grad_shrink_report.py > gpurun_out/grad_shrink.txt"""
+    python tools/grad_shrink_report.py > gpurun_out/grad_shrink.txt
+    python tools/grad_shrink_report.py --bisect >> gpurun_out/grad_shrink.txt
+
+--bisect (round 4): the same step with ONE component at a time in fp32 storage (exact-f32 MFMA) and the others in
+bf16 - UNet, VAE decoder, BLIP - and all three in fp32: which link of the chain loss -> BLIP -> resample -> VAE -> latents -> UNet
+carries the uniform attenuation of the bf16 gradient (|g_bf16| / |g_fp32| = 0.9958 in every group)."""
 import os
 import sys
 from collections import defaultdict
@@ -30,22 +35,46 @@ dev = torch.device("cuda:0")
 ops.set_kernel_backend(_hip.HipKernels())
 gold = np.load(os.path.join(ROOT, "tests", "golden", "c1_full.npz"))
 (ucfg, vcfg, bcfg), sd, batch, scfg, ts, crop = c1_inputs()
-dtype = torch.bfloat16
-bank = LoRABank(ucfg, sd["lora"], dtype, dev)
-pipe = TrainableSDPipeline(UNet(ucfg, sd["unet"], dtype, dev, bank), VAEDecoder(vcfg, sd["vae"], dtype, dev))
-trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], dtype, dev), None, scfg, seed=0)
-bank.set_requires_grad(True)
-bank.zero_grad()
-out = trainer.compute_losses(batch, training_steps=ts, crop=crop)
-out["loss"].backward()
-torch.cuda.synchronize()
 names = [str(n) for n in gold["names"]]
-rows = []
-for i, n in enumerate(names):
-    g = bank.params[n].grad.detach().double().cpu().reshape(-1)
-    p = (rademacher(n, g.numel()).double() @ g).numpy()          # 8 projections of the bf16 gradient
-    pr = gold["grad_proj"][i]                                     # ... of the fp32 oracle gradient
-    rows.append((n, float(g.norm()), float(gold["grad_norm"][i]), p, pr))
+DT = {"b": torch.bfloat16, "f": torch.float32}
+
+
+def run(mix):
+    """mix = storage dtype of (UNet, VAE decoder, BLIP), 'b' or 'f' each -> (rows, loss)"""
+    du, dv, db = (DT[c] for c in mix)
+    bank = LoRABank(ucfg, sd["lora"], du, dev)
+    pipe = TrainableSDPipeline(UNet(ucfg, sd["unet"], du, dev, bank), VAEDecoder(vcfg, sd["vae"], dv, dev))
+    trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], db, dev), None, scfg, seed=0)
+    bank.set_requires_grad(True)
+    bank.zero_grad()
+    out = trainer.compute_losses(batch, training_steps=ts, crop=crop)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    rows = []
+    for i, n in enumerate(names):
+        g = bank.params[n].grad.detach().double().cpu().reshape(-1)
+        p = (rademacher(n, g.numel()).double() @ g).numpy()          # 8 projections of this run's gradient
+        pr = gold["grad_proj"][i]                                     # ... of the fp32 oracle gradient
+        rows.append((n, float(g.norm()), float(gold["grad_norm"][i]), p, pr))
+    loss = float(out["loss"].detach())
+    del trainer, pipe, bank, out
+    torch.cuda.empty_cache()
+    return rows, loss
+
+
+if "--bisect" in sys.argv:
+    print("# storage dtype of (UNet, VAE decoder, BLIP): b = bf16, f = fp32 (exact-f32 MFMA); against the fp32 CPU oracle")
+    print("# mix   |g| / |g_fp32|   est. rel err   loss (fp32 oracle %.5f)" % float(gold["loss"]))
+    for mix in ("bbb", "fbb", "bfb", "bbf", "bff", "fff"):
+        rows, loss = run(mix)
+        nb = np.sqrt(sum(r[1] ** 2 for r in rows))
+        nr = np.sqrt(sum(r[2] ** 2 for r in rows))
+        err = np.sqrt(sum(float(np.mean((r[3] - r[4]) ** 2)) for r in rows))
+        print(f"  {mix}   {nb / nr:9.4f}   {err / nr:11.3e}   {loss:.5f}", flush=True)
+    sys.exit(0)
+
+rows, loss_b = run("bbb")
+out = {"loss": loss_b}
 
 
 def level(n):
