@@ -146,7 +146,8 @@ class Blip:
         y0, x0, ch, cw = crop
         if not (0 <= y0 and 0 <= x0 and ch > 0 and cw > 0 and y0 + ch <= H and x0 + cw <= W):
             raise ValueError(f"crop {crop} does not fit the {H}x{W} image (training_script.py:606-609 keeps it inside)")
-        return ops.resample(img_tokens, self.tables(H, W, crop), B, 3, scale=self.norm_scale, shift=self.norm_shift)
+        return ops.resample(img_tokens, self.tables(H, W, crop), B, 3, scale=self.norm_scale, shift=self.norm_shift,
+                            out_dtype=self.dtype)  # (the image may come from a VAE of another storage type)
 
     # ---- vision encoder ----------------------------------------------------------------------------------------
     def vision(self, pixel_tokens, B):

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 pytestmark = [pytest.mark.gpu]
-BF16_FULL_GRAD_LIMIT = 0.035  # 2 x the 1.7e-2 measured on an MI355X (profiles/r03_z_bf16_errors.txt, r04_*)
+BF16_FULL_GRAD_LIMIT = 0.042  # 2 x the 2.1e-2 measured on an MI355X (profiles/r04_z_bf16_errors.txt; 1.7e-2 in round 3: the figure moves with every change of a summation order)
 
 
 def test_c1_full_size_bf16_error_is_bounded(hip):
