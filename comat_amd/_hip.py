@@ -54,7 +54,6 @@ class ConvParams(C.Structure):
         ("act", C.c_int32), ("in_dtype", C.c_int32), ("out_dtype", C.c_int32), ("r_dtype", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
-        ("W_strip", C.c_void_p),
     ]
 
 
@@ -148,8 +147,7 @@ GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_k
                      2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)",
                      4: "gemm2_tt_group_kernel (grouped k-major products)",
                      5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)",
-                     6: "gemm2_chain_kernel (producer + consumer of a chained call in one launch)",
-                     7: "gemm2_strip_kernel (3x3 conv, input strip in LDS)"}
+                     6: "gemm2_chain_kernel (producer + consumer of a chained call in one launch)"}
 
 
 def build_id() -> str:
@@ -365,11 +363,9 @@ class HipKernels:
                "comat_transpose_cast_tiles")
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
-               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, W_strip=None):
-        """W_strip: the same weights in (channel chunk, tap) order (comat_conv_params::W_strip), or None"""
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
         p = ConvParams()
         p.X, p.W, p.Y = _ptr(X), _ptr(W), _ptr(Y)
-        p.W_strip = _ptr(W_strip)
         p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
         if bias is not None:
             assert bias.dtype == torch.float32

@@ -580,262 +580,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_chain_kernel(ChainArgs2 a) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 3x3 stride-1 same-size convs with the INPUT STRIP in LDS (round 4).
-// Counter passes over the step's 3x3 convs (profiles/r04_a_pmc_diag.txt) show the implicit-GEMM kernel above bound by the
-// per-CU L2 -> LDS fill: 42 % of the wave cycles wait for DMA / barriers, MFMA busy 17 %, 21 B/clk per CU through an L1 whose
-// miss queue is full a third of the time.  Half of those bytes are the im2col operand, and they are 9-fold redundant: the
-// k-loop walks (tap, channel chunk) and fetches every input pixel's chunk again for each of the nine taps.
-// Here the k-loop walks (channel chunk, tap): the input pixels a block tile can touch - its output rows plus a one-pixel
-// halo: (BM / W + 2) x (W + 2) pixels, or 3 x (BM + 2) when a row is longer than the tile - are DMA'd ONCE per 32-channel
-// chunk into a double-buffered LDS strip of 64-byte pixel rows, and the nine taps read their fragments from it at shifted
-// addresses (tap (ky, kx) of output pixel p = strip pixel p + ky * SW + kx).  Only the weights still stream per k-tile,
-// from a copy stored in the same (chunk, tap) order ([Cout][Cin / 32][3][3][32], comat_conv_params::W_strip).  L2 -> LDS
-// bytes per k-tile of a 128 x 128 block: 16 KB -> 8 KB + 1.9 KB.
-// Same ring protocol for the weights as gemm2_kernel (NST stages, one barrier per k-tile, counted vmcnt); the strip of
-// chunk c + 1 is issued at the first tap of chunk c (nine k-tiles ahead), into the buffer chunk c - 1 was read from; its
-// DMA instructions are the same number on every wave (pixels beyond the strip read the zero page), so the vmcnt arithmetic
-// stays exact: for the NST - 3 iterations after their issue they are younger than the weight tile being waited for and
-// are allowed to stay in flight.  Padding pixels read the zero page.  The summation order over k differs from the im2col
-// kernel's (chunk-major instead of tap-major): results agree to rounding, not to the bit; run to run they are identical.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wait_vm_rt(int n) {  // s_waitcnt vmcnt(n) for a wave-uniform run-time n (immediates only)
-    switch (n) {
-        case 0: wait_vmcnt<0>(); break;
-        case 1: wait_vmcnt<1>(); break;
-        case 2: wait_vmcnt<2>(); break;
-        case 3: wait_vmcnt<3>(); break;
-        case 4: wait_vmcnt<4>(); break;
-        case 5: wait_vmcnt<5>(); break;
-        case 6: wait_vmcnt<6>(); break;
-        case 7: wait_vmcnt<7>(); break;
-        case 8: wait_vmcnt<8>(); break;
-        case 9: wait_vmcnt<9>(); break;
-        case 10: wait_vmcnt<10>(); break;
-        case 11: wait_vmcnt<11>(); break;
-        case 12: wait_vmcnt<12>(); break;
-        case 13: wait_vmcnt<13>(); break;
-        case 14: wait_vmcnt<14>(); break;
-        case 15: wait_vmcnt<15>(); break;
-        case 16: wait_vmcnt<16>(); break;
-        case 17: wait_vmcnt<17>(); break;
-        case 18: wait_vmcnt<18>(); break;
-        case 19: wait_vmcnt<19>(); break;
-        case 20: wait_vmcnt<20>(); break;
-        case 21: wait_vmcnt<21>(); break;
-        case 22: wait_vmcnt<22>(); break;
-        case 23: wait_vmcnt<23>(); break;
-        case 24: wait_vmcnt<24>(); break;
-        default: wait_vmcnt<0>(); break;
-    }
-}
-
-template <int BM, int NW> struct StripGeo {
-    static constexpr int SPMAX = 3 * (BM + 2);                          // strip pixels at most (a tile inside one image row)
-    static constexpr int LS = (SPMAX + 16 * NW - 1) / (16 * NW);        // strip DMA instructions per wave (16 pixels each)
-    static constexpr int STRIP = LS * NW * 1024;                        // bytes per strip buffer
-};
-
-template <int BM, int BN, int WM, int WN, int NST>
-__global__ __launch_bounds__(WM* WN * 64) void gemm2_strip_kernel(Args2 g) {
-    constexpr int RBK = 64, NW = WM * WN, NTH = NW * 64;
-    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int IB = BN / (16 * NW);
-    static_assert(IB >= 1 && BN % (16 * NW) == 0 && TM >= 1 && TN >= 1, "tile too small for the block");
-    typedef StripGeo<BM, NW> SG;
-    constexpr int LS = SG::LS, STRIP = SG::STRIP, SB = BN * RBK;
-    static_assert(NST >= 4 && (NST - 3) * IB + LS <= 24, "ring depth / vmcnt range");
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STRIP + NST * SB];  // [strip 0 | strip 1 | NST weight stages]
-    char* const bring = smem + 2 * STRIP;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const int wr = wave / WN, wc = wave % WN;
-
-    unsigned lin = (unsigned)xcd_chunk_map(blockIdx.x, gridDim.x);
-    const int sp = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.splits));
-    lin /= (unsigned)g.splits;
-    int tm, tn;
-    if (g.order) {
-        tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
-        tn = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_m));
-    } else {
-        tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
-        tm = __builtin_amdgcn_readfirstlane((int)(lin / (unsigned)g.tiles_n));
-    }
-    const int64_t tile = (int64_t)tm * g.tiles_n + tn;
-    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int per = (g.nkt + g.splits - 1) / g.splits;
-    int kt0 = sp * per;
-    if (kt0 > g.nkt) kt0 = g.nkt;
-    const int kt1 = kt0 + per < g.nkt ? kt0 + per : g.nkt;
-    const int nt = __builtin_amdgcn_readfirstlane(kt1 - kt0);
-
-    // ---- geometry (host: H W % BM == 0, and BM % W == 0 or W % BM == 0: a tile is whole image rows, or a piece of one) ----
-    const int H = g.Hin, W = g.Win;
-    const int TW = W < BM ? W : BM;      // output pixels per tile row
-    const int SW = TW + 2;               // strip row length
-    const int SP = (BM / TW + 2) * SW;   // strip pixels
-    const int hw = H * W;
-    const int b0 = (int)(m0 / hw), rem0 = (int)(m0 - (int64_t)b0 * hw);
-    const int y0 = rem0 / W, x0 = rem0 - y0 * W;
-    // strip DMA: wave-instruction i covers strip pixels (i * NW + wave) * 16 .. + 16, lane -> (pixel, 16-byte slot);
-    // pixel q = image (y0 - 1 + q / SW, x0 - 1 + q % SW); the lane fetches chunk slot ^ swz(q) of the pixel's 64 bytes
-    int soff[LS];  // byte offset of the lane's 16 bytes for channel chunk 0, or -1: outside the image / beyond the strip
-#pragma unroll
-    for (int i = 0; i < LS; ++i) {
-        const int q = (i * NW + wave) * 16 + (lane >> 2);
-        const int sr = q / SW, sc = q - sr * SW;
-        const int y = y0 - 1 + sr, x = x0 - 1 + sc;
-        const bool ok = q < SP && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        soff[i] = ok ? ((b0 * H + y) * W + x) * g.Cin * 2 + (((lane & 3) ^ ((q >> 2) & 3)) << 4) : -1;
-    }
-    const char* zsrc = (const char*)g_zero_page + (lane & 15) * 16;
-    auto issue_strip = [&](int chunk, int par) {
-        char* dst = smem + par * STRIP + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < LS; ++i)
-            dma16(soff[i] >= 0 ? (const void*)(g.seg[0].A + soff[i] + chunk * 64) : (const void*)zsrc, dst + i * NW * 1024);
-    };
-    // weight DMA: as gemm2_kernel (rows of 64 bytes, source-side swizzle)
-    const int drow = lane >> 2;
-    const int csrc = (lane & 3) ^ ((drow >> 2) & 3);
-    const char* pb[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        int64_t gr = n0 + (i * NW + wave) * 16 + drow;
-        if (gr >= g.N) gr = g.N - 1;
-        pb[i] = g.seg[0].B + gr * g.seg[0].ldb + (int64_t)kt0 * RBK + csrc * 16;
-    }
-    auto issue_b = [&](int st) {
-        char* dst = bring + st * SB + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            dma16(pb[i], dst + i * NW * 1024);
-            pb[i] += RBK;
-        }
-    };
-
-    f32x16_t acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-
-    // fragment addressing.  A: output pixel m of the tile = strip pixel p0 = (m / TW) * SW + m % TW for tap (0, 0); tap
-    // (ky, kx) adds ky * SW + kx; k-step s of strip pixel q reads slot (2 s + h) ^ swz(q): k-step 1 = k-step 0 ^ 32 bytes.
-    int p0[TM];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int m = wr * WTM + a * 32 + r;
-        p0[a] = (m / TW) * SW + (m - (m / TW) * TW);
-    }
-    auto a_addr = [&](int a, int tap, int par) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int q = p0[a] + ky * SW + kx;
-        return par * STRIP + q * 64 + ((h ^ ((q >> 2) & 3)) << 4);
-    };
-    const int swb = (r >> 2) & 3;
-    const int fb0 = wc * WTN * RBK + r * RBK + ((h ^ swb) << 4);  // weight fragment, k-step 0 (k-step 1: ^ 32)
-
-    // read-side cursor: tile t of this block = k-tile kt0 + t = (chunk, tap); strips alternate between the two buffers
-    const int c_first = kt0 / 9;
-    int tap = kt0 - c_first * 9, chunk = c_first, par = 0;
-    const int c_last = kt1 > kt0 ? (kt1 - 1) / 9 : c_first;
-
-    // ---- prologue: the first two strips, then NST - 1 weight tiles ----
-    if (nt > 0) {
-        issue_strip(c_first, 0);
-        if (c_first < c_last) issue_strip(c_first + 1, 1);
-    }
-#pragma unroll
-    for (int u = 0; u < NST - 1; ++u)
-        if (u < nt) issue_b(u);
-    int ao[TM];        // A fragment offsets (k-step 0) of the tile whose k-step-0 fragments are in xf0
-    short8_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
-    if (nt > 0) {
-        wait_tiles<IB, NST - 2>(nt - 1);  // weight tile 0 landed; the strips are older: landed too
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            ao[a] = a_addr(a, tap, par);
-            xf0[a] = *(const short8_t*)(smem + ao[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wf0[b] = *(const short8_t*)(bring + fb0 + b * 32 * RBK);
-    }
-    int stage = 0;
-    int since_strip = NST;  // iterations since the last in-loop strip issue (>= NST - 2: nothing extra may stay in flight)
-    for (int t = 0; t + 1 < nt; ++t) {
-        const char* cur = bring + stage * SB;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) xf1[a] = *(const short8_t*)(smem + (ao[a] ^ 32));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wf1[b] = *(const short8_t*)(cur + (fb0 ^ 32) + b * 32 * RBK);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf0[b], xf0[a]);
-        const int nstage = stage + 1 == NST ? 0 : stage + 1;
-        {   // weight tile t + 1 must have landed: up to NST - 3 younger weight tiles (and a strip issued within the last
-            // NST - 3 iterations, which is younger than tile t + 1's DMA) may stay in flight
-            int keep = nt - 2 - t;
-            if (keep > NST - 3) keep = NST - 3;
-            wait_vm_rt(keep * IB + ((since_strip >= 1 && since_strip <= NST - 3) ? LS : 0));
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // first tile of a chunk (beyond the first, whose successor went out in the prologue): the strip of the NEXT chunk
-        // goes into the buffer the PREVIOUS chunk was read from (its last fragment reads were issued before the barrier of
-        // the previous iteration)
-        if (tap == 0 && chunk > c_first && chunk < c_last) {
-            issue_strip(chunk + 1, par ^ 1);
-            since_strip = 0;
-        }
-        if (t + NST - 1 < nt) issue_b(stage == 0 ? NST - 1 : stage - 1);
-        ++since_strip;
-        // the next tile
-        if (++tap == 9) {
-            tap = 0;
-            ++chunk;
-            par ^= 1;
-        }
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            ao[a] = a_addr(a, tap, par);
-            xf0[a] = *(const short8_t*)(smem + ao[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wf0[b] = *(const short8_t*)(bring + nstage * SB + fb0 + b * 32 * RBK);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf1[b], xf1[a]);
-        stage = nstage;
-    }
-    if (nt > 0) {  // last tile
-        const char* cur = bring + stage * SB;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) xf1[a] = *(const short8_t*)(smem + (ao[a] ^ 32));
-#pragma unroll
-        for (int b = 0; b < TN; ++b) wf1[b] = *(const short8_t*)(cur + (fb0 ^ 32) + b * 32 * RBK);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf0[b], xf0[a]);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf1[b], xf1[a]);
-    }
-    __syncthreads();  // the split-K ticket flag lives at the head of the (now idle) LDS image
-    g2_finish<TM, TN, WTM, WTN, NTH>(acc, g, sp, tile, 0, m0, n0, wr, wc, r, h, tid, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // k-major operands: C[M, N] (+)= A^T B with A stored [K, M] and B stored [K, N] (rows = k).  This is every LoRA weight
 // gradient of the step: dU = g^T h and dD = u^T x contract over the TOKEN axis of two row-major token matrices
 // (training_utils/pipeline.py:94-115 leaves them to autograd's addmm).  The general kernel gathers such fragments
@@ -1310,18 +1054,6 @@ static void launch_chain_cfg(int c, const ChainArgs2& a, unsigned blocks, hipStr
     }
 }
 
-// strip convs: block shapes with BM <= 128 (the strip of a 256-row tile does not fit next to the weight ring)
-static void launch_strip_cfg(int c, const Args2& a, unsigned blocks, hipStream_t st) {
-    switch (c) {
-        case CFG_128x64: hipLaunchKernelGGL((gemm2_strip_kernel<128, 64, 2, 2, 6>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_64x128: hipLaunchKernelGGL((gemm2_strip_kernel<64, 128, 2, 2, 6>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_strip_kernel<128, 128, 2, 2, 6>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_64x64: hipLaunchKernelGGL((gemm2_strip_kernel<64, 64, 2, 2, 8>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_W8: hipLaunchKernelGGL((gemm2_strip_kernel<128, 128, 2, 4, 4>), dim3(blocks), dim3(512), 0, st, a); break;
-        default: hipLaunchKernelGGL((gemm2_strip_kernel<128, 128, 2, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-    }
-}
-
 // options (runtime.hip): gemm2 = 0 routes everything to gemm.hip's general kernel; g2_cfg / g2_splits force the block
 // tile and the split count (tools/mb_gemm2.py sweeps them)
 static bool g2_enabled() { return comat_option(COMAT_OPT_GEMM2) != 0; }
@@ -1700,33 +1432,6 @@ int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {
     a.ep.ldc = p->Cout; a.ep.ldr = p->Cout; a.ep.rows_per_b2 = (int64_t)p->Hout * p->Wout;
     a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
-    // 3x3 / stride 1 / same size, bf16, the caller supplies the (chunk, tap)-ordered weight copy: the input strip in LDS
-    // (gemm2_strip_kernel) wherever a block tile is whole image rows or a piece of one (option g2_strip; 0 = im2col form)
-    if (!fp8 && !zins && p->W_strip && al16(p->W_strip) && comat_option(COMAT_OPT_G2_STRIP) != 0 && p->mode == 0 && p->stride == 1 &&
-        p->ups == 1 && p->KH == 3 && p->KW == 3 && p->pad == 1 && p->Hout == p->Hin && p->Wout == p->Win && p->Cin % 32 == 0) {
-        int c, s;
-        plan2(true, false, a.M, a.N, a.nkt, 1, p->ws ? p->ws_bytes : 0, &c, &s);
-        if (cfg_is_k4(c)) c = cfg_k2_twin(c);
-        if (c == CFG_256x128) c = CFG_128x128_W8;
-        const Cfg2 d = cfg_dims(c);
-        const int64_t hw = (int64_t)p->Hin * p->Win;
-        if (hw % d.bm == 0 && (d.bm % p->Win == 0 || p->Win % d.bm == 0)) {
-            a.seg[0].B = (const char*)p->W_strip;
-            a.tiles_m = (int)(a.M / d.bm);
-            a.tiles_n = (int)cdiv64(a.N, d.bn);
-            a.ntiles = (int64_t)a.tiles_m * a.tiles_n;
-            if (s > a.nkt) s = a.nkt;
-            a.splits = s < 1 ? 1 : s;
-            a.order = tile_order(a, true, false, d.bm, d.bn);
-            a.ws = (float*)p->ws;
-            const int64_t blocks = a.ntiles * a.splits;
-            if (blocks < (1ll << 31) && a.ntiles <= WS_COUNTERS) {
-                a.vec = epi_vec_ok(a.ep, a.N, a.sC, a.sR, a.sBias, a.M);
-                launch_strip_cfg(c, a, (unsigned)blocks, (hipStream_t)stream);
-                return 7;
-            }
-        }
-    }
     return finish_launch(a, true, fp8, 1, p->ws, p->ws_bytes, stream);
 }
 

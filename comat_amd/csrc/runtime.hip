@@ -87,8 +87,6 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // launches), 1 where the lean kernel's rule wants the consumer, 2 always
     {"gemm2_chain", "COMAT_GEMM2_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch of the pipelined kernel (producer
                                                           // tiles first, the consumer's last segment waits for its row block)
-    {"g2_strip", "COMAT_G2_STRIP", 0, 0, false},          // 3x3 stride-1 convs with the input strip in LDS (gemm2_strip_kernel)
-                                                          // where the caller supplies comat_conv_params::W_strip
 };
 }  // namespace
 

@@ -396,15 +396,6 @@ def frozen_linear_group(weights, biases, dtype, device):
     return out
 
 
-# COMAT_CONV_STRIP=0: never hand the (chunk, tap)-ordered weight copies to the library (3x3 convs stay on the im2col form)
-_conv_strip = os.environ.get("COMAT_CONV_STRIP", "1") != "0"
-
-
-def set_conv_strip(flag: bool):
-    global _conv_strip
-    _conv_strip = bool(flag)
-
-
 class FrozenConv:
     """A frozen conv2d.  `w` is [Cout, KH, KW, Cin]; `wd` is the tap-flipped, channel-transposed weight
     [Cin, KH, KW, Cout] that turns the data-gradient into the same implicit-GEMM gather."""
@@ -416,24 +407,6 @@ class FrozenConv:
         self.wd = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(dtype)
         self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
         self.stride, self.pad = stride, pad
-        self._strip = {}
-
-    def strip_weight(self, which):
-        """`w` ("w") or `wd` ("wd") in (channel chunk, tap) order [Cout', Cin' / 32, KH, KW, 32] (comat_conv_params::W_strip: 3x3
-        stride-1 convs keep their input strip in LDS), or None where that form does not apply.  Made at the first call (the
-        eager call that precedes any graph capture) and kept."""
-        if not _conv_strip or self.kh != 3 or self.kw != 3 or self.stride != 1 or self.pad != 1 or self.w.dtype != torch.bfloat16:
-            return None
-        t = self._strip.get(which)
-        if t is None:
-            w = self.w if which == "w" else self.wd
-            co, kh, kw, ci = w.shape
-            if ci % 32:
-                return None
-            if w.is_cuda and torch.cuda.is_current_stream_capturing():
-                return None  # never allocate a persistent buffer inside a capture
-            t = self._strip[which] = w.reshape(co, kh, kw, ci // 32, 32).permute(0, 3, 1, 2, 4).contiguous()
-        return t
 
 
 class LoRAGroup:
@@ -1158,7 +1131,7 @@ class _Conv(Function):
         else:
             kernels().conv2d(x, conv.w, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad,
                              mode=0, ups=ups, bias=conv.bias, bias2=bias2, R=residual,
-                             beta=1.0 if residual is not None else 0.0, W_strip=conv.strip_weight("w") if ups == 1 else None)
+                             beta=1.0 if residual is not None else 0.0)
         ctx.conv, ctx.geo = conv, (B, H, W, Ho, Wo, ups)
         ctx.has_res = residual is not None
         return y
@@ -1175,8 +1148,7 @@ class _Conv(Function):
             if conv.stride == 1:
                 Hs, Ws = H * ups, W * ups
                 du = g.new_empty((B * Hs * Ws, conv.cin))
-                k.conv2d(g, conv.wd, du, B, Ho, Wo, conv.cout, Hs, Ws, conv.cin, conv.kh, conv.kw, 1, padd, mode=0,
-                         W_strip=conv.strip_weight("wd") if (Hs == Ho and Ws == Wo) else None)
+                k.conv2d(g, conv.wd, du, B, Ho, Wo, conv.cout, Hs, Ws, conv.cin, conv.kh, conv.kw, 1, padd, mode=0)
                 if ups == 2:
                     dx = g.new_empty((B * H * W, conv.cin))
                     k.sumpool2x2(du, dx, B, H, W, conv.cin)

@@ -179,11 +179,6 @@ typedef struct {
     int64_t ws_bytes;
     const float* scale_a;  /* in_dtype == COMAT_FP8_E4M3 (mode 0, Cin % 64 == 0): per-tensor scales of X and W, as in */
     const float* scale_b;  /* comat_gemm_params */
-    /* ABI 5, optional: W in (channel chunk, tap) order - [Cout][Cin / 32][KH][KW][32], i.e. the same weights with the 32-channel
-     * chunk index moved in front of the taps.  With it a 3x3 / stride 1 / pad 1 / same-size bf16 conv (mode 0, ups 1, Cin % 32
-     * == 0) may run with its input strip held in LDS: every input pixel is fetched once per channel chunk instead of once per
-     * tap.  Results agree with the W form to rounding (the summation order over k differs).  NULL: always the W form. */
-    const void* W_strip;
 } comat_conv_params;
 int comat_conv2d(const comat_conv_params* p, void* stream);
 

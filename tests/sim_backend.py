@@ -122,12 +122,8 @@ class SimKernels:
             df[do:do + rows * cols].view(cols, rows)[c0:c1, r0:r1] = blk.t().to(dst.dtype)
 
     def conv2d(self, X, W, Y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=1, bias=None,
-               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, W_strip=None):
+               bias2=None, R=None, alpha=1.0, beta=0.0, act=ACT_NONE, scales=None):
         assert (scales is not None) == (X.dtype == torch.uint8)
-        if W_strip is not None:  # the (chunk, tap)-ordered copy must be the same weights
-            assert KH == 3 and KW == 3 and Cin % 32 == 0
-            assert torch.equal(_v(W_strip, (Cout, Cin // 32, KH, KW, 32), (KH * KW * Cin, KH * KW * 32, KW * 32, 32, 1)).permute(0, 2, 3, 1, 4)
-                               .reshape(Cout, KH, KW, Cin), _v(W, (Cout, KH, KW, Cin), (KH * KW * Cin, KW * Cin, Cin, 1)))
         if scales is not None:
             assert mode == 0 and Cin % 64 == 0
         sa, sb = scales if scales is not None else (None, None)

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     # 6 pointers + 18 int64 + 2 float + 6 int32 + pointer + int64 + 2 scale pointers (ABI 3)
     assert C.sizeof(_hip.GemmParams) == 6 * 8 + 18 * 8 + 2 * 4 + 6 * 4 + 8 + 8 + 2 * 8 + 8 + 8 + 8  # ABI 5: + C2, ldc2, epi2 (+ 4 bytes of padding)
     assert C.sizeof(_hip.TTProblem) == 3 * 8 + 6 * 8  # comat_tt_problem (ABI 4)
-    assert C.sizeof(_hip.ConvParams) == 6 * 8 + 13 * 4 + 2 * 4 + 4 * 4 + 4 + 8 + 8 + 2 * 8 + 8  # incl. 4 bytes of padding; ABI 5: + W_strip
+    assert C.sizeof(_hip.ConvParams) == 6 * 8 + 13 * 4 + 2 * 4 + 4 * 4 + 4 + 8 + 8 + 2 * 8  # incl. 4 bytes of padding
 
 
 def test_argument_validation_reports_errors_without_launching():

@@ -769,7 +769,7 @@ def test_adamw_with_clip(dev):
 
 
 # the library's defaults for the options whose default moved in round 4 (runtime.hip)
-DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0, g2_strip=0)
+DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0)
 
 
 def _set_opts(**kw):
@@ -784,7 +784,7 @@ def default_opts():
     yield
     _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=DEFAULT_OPTS['flash_xcd'],
               g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
-              gemm2_chain=DEFAULT_OPTS['gemm2_chain'], g2_strip=DEFAULT_OPTS['g2_strip'])
+              gemm2_chain=DEFAULT_OPTS['gemm2_chain'])
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1116,46 +1116,6 @@ def test_geglu_linear(dev, dtype, shape):
     finally:
         ops.set_geglu_fused(True)
     assert torch.equal(y3, y) and torch.equal(xs.grad, xd.grad), "fused and two-launch GEGLU differ"
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("g2cfg,splits", [(0, 0), (1, 0), (2, 3), (4, 0), (6, 2), (7, 0), (5, 0)])
-def test_conv_strip_matches_im2col(hip, g2cfg, splits, default_opts):
-    """gemm2_strip_kernel (option g2_strip = 1: 3x3 stride-1 convs with the input strip in LDS, weights in (chunk, tap) order)
-    against the im2col form of the same kernel family and against torch's conv2d: forward and data-gradient at the step's
-    shapes (tiles of several image rows, of one row, of a piece of a row; 4 output channels; batch 2), with bias, per-sample
-    bias and residual, every block shape and forced split counts.  The two forms differ in summation order only; the strip
-    form is reproducible run to run."""
-    from comat_amd import _hip
-    dtype = torch.bfloat16
-    for (B_, H, Cin, Cout) in ((2, 64, 320, 320), (2, 32, 640, 640), (2, 16, 1280, 640), (1, 128, 256, 128), (1, 256, 128, 128), (2, 64, 320, 4),
-                               (2, 32, 64, 96)):
-        w = rnd(Cout, Cin, 3, 3, dtype=dtype, seed=2, scale=1.0 / math.sqrt(Cin * 9))
-        bias, b2 = rnd(Cout, seed=5), rnd(B_, Cout, seed=6)
-        conv = ops.FrozenConv(w, bias, dtype, hip)
-        x = rnd(B_ * H * H, Cin, dtype=dtype, seed=3)
-        res = rnd(B_ * H * H, Cout, dtype=dtype, seed=7)
-        go = rnd(B_ * H * H, Cout, dtype=dtype, seed=4)
-        outs = {}
-        for strip in (0, 1, 1):
-            _set_opts(g2_strip=strip, g2_cfg=g2cfg, g2_splits=splits)
-            xd = dv(x, hip, dtype, grad=True)
-            y = ops.conv2d(xd, conv, B_, H, H, residual=dv(res, hip, dtype), bias2=dv(b2, hip, torch.float32))
-            kid = _hip.last_gemm_kernel()
-            y.backward(dv(go, hip, dtype))
-            torch.cuda.synchronize()
-            if strip:
-                assert kid == 7 and _hip.last_gemm_kernel() == 7, f"{H}x{H} {Cin}->{Cout}: the strip kernel did not take the conv"
-            if strip in outs:
-                assert torch.equal(outs[strip][0], y) and torch.equal(outs[strip][1], xd.grad), "strip conv is not reproducible"
-            outs[strip] = (y.detach(), xd.grad.detach())
-        xr = x.reshape(B_, H, H, Cin).permute(0, 3, 1, 2).clone().requires_grad_(True)
-        ref = F.conv2d(xr, w, bias, padding=1) + b2[:, :, None, None] + res.reshape(B_, H, H, Cout).permute(0, 3, 1, 2)
-        ref.backward(go.reshape(B_, H, H, Cout).permute(0, 3, 1, 2))
-        tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
-        check(outs[1][0], tok(ref), dtype, f"strip conv {H}x{H} {Cin}->{Cout}", factor=2)
-        check(outs[1][1], tok(xr.grad), dtype, f"strip conv dgrad {H}x{H} {Cin}->{Cout}", factor=2)
-        assert rel_l2(outs[1][0], outs[0][0]) < 6e-3 and rel_l2(outs[1][1], outs[0][1]) < 6e-3, "strip and im2col forms differ beyond rounding"
 
 
 G3_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9]
