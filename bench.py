@@ -556,7 +556,9 @@ def secondary_c4(device, dtype, rank, sync, steps=3):
                        "matching + GAN + attribute concentration, clip+AdamW for G and D - scripts/sdxl.sh of the reference",
            "ms_per_step": round(ms, 1), "images_per_sec": round(1e3 / ms, 3), "steps": steps, "build_s": round(t_build, 1),
            "set_up_s": round(t1 - t0, 1), "launch_mode": f"no-grad UNet graphs + step segments ({st.stats()['segments']} segment graphs)",
-           "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS}
+           "step_algorithmic_tflop": total, "step_frac": total / (ms * 1e-3) / PEAK_BF16_TFLOPS,
+           "note": "measured inside the process that also holds the C2 and C3 worlds and their graphs; `bench.py --config c4` on its own "
+                   "measured 938 ms where this line's predecessor measured ~1 090 - 1 160 (profiles/r04_h_c4_ab.txt)"}
     del st, tr, b
     gc.collect()
     torch.cuda.empty_cache()
