@@ -124,7 +124,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    p = path or _LIB_PATH
+    p = path or os.environ.get("COMAT_LIB_PATH") or _LIB_PATH  # COMAT_LIB_PATH: A/B runs of two builds on one box (tools/mb_flash_ab.py)
     if not os.path.exists(p):
         raise RuntimeError(
             f"libcomat_hip.so not found at {p}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

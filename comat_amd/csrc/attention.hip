@@ -24,6 +24,22 @@
 namespace {
 
 constexpr int NT = 256;
+// The bf16 kernels for head dims <= 64 hold 100 - 240 registers and the step's shapes give a CU at most two of their 4-wave
+// blocks: they never run more than two waves per SIMD.  Saying so (COMAT_FLASH_W2) lets the scheduler spend registers on
+// batching the LDS fragment reads ahead of the MFMAs instead of cycling two fragment registers to stay inside a
+// three-waves budget nobody uses.  Larger head dims and fp32 already sit at 256 registers: the same hint makes them spill.
+#ifndef COMAT_FLASH_W2
+#define COMAT_FLASH_W2 0
+#endif
+// COMAT_FLASH_EARLY_TR: the 2-tile kernels issue the transposed LDS reads of their second product (P V, dS K, P^T dO /
+// dS^T Q) ahead of the softmax arithmetic that produces the other operand, so the reads' latency hides under that VALU work
+// and the product's MFMAs run back to back (forward, dQ: all four k-steps, +32 registers; dK/dV: one k-step ahead, +16).
+#ifndef COMAT_FLASH_EARLY_TR
+#define COMAT_FLASH_EARLY_TR 0
+#endif
+constexpr bool flash_two_waves(int dmax, int elem_bytes) { return COMAT_FLASH_W2 && dmax <= 64 && elem_bytes == 2; }
+#define FLASH_OCC(DMAX, ESZ) \
+    __attribute__((amdgpu_waves_per_eu(flash_two_waves(DMAX, ESZ) ? 2 : 1, flash_two_waves(DMAX, ESZ) ? 2 : 8)))
 
 template <typename T> struct FragOf;
 template <> struct FragOf<bf16_t> { typedef short8_t type; };
@@ -98,6 +114,13 @@ template <typename T, int DMAX, bool TR> struct BwdLds {
     static constexpr int DQ2 = 8 * G::TILE_BYTES;            // two double-buffered [K | V] tile pairs
     static constexpr int DKDV2 = 8 * G::TILE_BYTES + 1024;   // two double-buffered [Q | dO | lse | D] tile pairs
 };
+
+// Every global load issued so far has landed.  Placed (unconditionally) at the end of a kernel's prologue: the prologue's
+// own waits sit inside divergent branches (threads that copy no tile chunk skip them), so without this the compiler must
+// assume the Q / K / V fragment loads may still be in flight at the loop head and puts an `s_waitcnt vmcnt(0)` in front
+// of the loop's first MFMA - behind the NEXT tile's loads, which the loop has just issued: every iteration then pays a
+// full global-load latency (round 4, tools/isa_loop.py --order).  A builtin, not inline asm: the waitcnt pass reads it.
+__device__ __forceinline__ void loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), nothing else
 
 // cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
 template <typename T, int DMAX> struct TileMover {
@@ -276,7 +299,7 @@ __device__ __forceinline__ void flash_block_xy(int xcd, int& bx, int& by) {
 }
 
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     // LDS: [K tile | V tile (TR: its transposed image)], TWICE when it fits (DB): the next tile is written into the other
@@ -315,6 +338,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
     km.store(Kt);
     if (SWT) vm.store_t(Vt);
     else vm.store(Vt);
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = 0; t < ntiles; ++t) {
@@ -411,7 +435,7 @@ __global__ __launch_bounds__(NT) void flash_fwd_kernel(FlashArgs a) {
 // results the softmax of the other can overlap.  Same arithmetic per score as flash_fwd_kernel; the running maximum moves
 // at 64-key granularity, so results agree with the 32-key kernel to rounding, not bit for bit.
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(FlashArgs a) {
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
@@ -454,6 +478,7 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
     };
     load_pair(0);
     store_pair(cur);
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int p = 0; p < npairs; ++p) {
@@ -466,6 +491,19 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
         for (int s = 0; s < NK; ++s) {
             mma(s0, frag_kc<T, DMAX>(cur, r, s, hh), qf[s]);
             mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
+        }
+        // the V fragments of the four P V k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise)
+        TrF vf[4][G::NT32];
+        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        auto issue_v = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            tr_issue_j<G::RS, (k & 1)>(k < 2 ? va0 : va1, vf[k], std::make_integer_sequence<int, G::NT32>{});
+        };
+        if (COMAT_FLASH_EARLY_TR) {
+            issue_v(std::integral_constant<int, 0>{});
+            issue_v(std::integral_constant<int, 1>{});
+            issue_v(std::integral_constant<int, 2>{});
+            issue_v(std::integral_constant<int, 3>{});
         }
         if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
 #pragma unroll
@@ -503,19 +541,17 @@ __global__ __launch_bounds__(NT) void flash_fwd2_kernel(FlashArgs a) {
         }
         l += ps;
         m = m_new;
-        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
-        auto step = [&](auto jc, unsigned va, const f32x16_t& st) {
-            constexpr int j = decltype(jc)::value;
-            TrF vf[G::NT32];
-            tr_issue_j<G::RS, j>(va, vf, std::make_integer_sequence<int, G::NT32>{});
-            const F pb = pack_acc<T>(st, j);
+        auto step = [&](auto kc, const f32x16_t& st) {
+            constexpr int k = decltype(kc)::value;
+            if (!COMAT_FLASH_EARLY_TR) issue_v(kc);
+            const F pb = pack_acc<T>(st, k & 1);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[t2]), pb);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[k][t2]), pb);
         };
-        step(std::integral_constant<int, 0>{}, va0, s0);
-        step(std::integral_constant<int, 1>{}, va0, s0);
-        step(std::integral_constant<int, 0>{}, va1, s1);
-        step(std::integral_constant<int, 1>{}, va1, s1);
+        step(std::integral_constant<int, 0>{}, s0);
+        step(std::integral_constant<int, 1>{}, s0);
+        step(std::integral_constant<int, 2>{}, s1);
+        step(std::integral_constant<int, 3>{}, s1);
         cur = smem + ((p + 1) & 1) * PAIR;  // last read in iteration p-1, which every wave left through the barrier below
         if (more) store_pair(cur);
         __syncthreads();
@@ -591,6 +627,7 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, in
     km.store(Kt);
     if (SWT) km.store_t(KtT);
     vm.store(Vt);
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = 0; t < ntiles; ++t) {
@@ -662,7 +699,7 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, in
     }
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) void flash_dq_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dq_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DQ];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -710,13 +747,14 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
     const int per = (ntq + a.qsplit - 1) / a.qsplit;
     const int tbeg = bz * per;
     const int ntiles = tbeg + per < ntq ? tbeg + per : ntq;
-    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31 (lse in log2 units)
+    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..31; lse goes to log2 units when it is STORED to LDS (a multiply
+                                   // here would wait for the load right behind its issue)
     const float c2 = a.scale * LOG2E;
     qm.load(Qb, a.ldq, tbeg * 32, a.Nq, a.d);
     gm.load(Gb, a.ldo, tbeg * 32, a.Nq, a.d);
     if (threadIdx.x < 32) {
         const int qi = tbeg * 32 + threadIdx.x;
-        lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
+        lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
         D_r = qi < a.Nq ? D_g[qi] : 0.f;
     }
     qm.store(Qt);
@@ -725,7 +763,8 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
         qm.store_t(QtT);
         gm.store_t(GtT);
     }
-    if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
+    if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r * LOG2E; D_s[threadIdx.x] = D_r; }
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = tbeg; t < ntiles; ++t) {
@@ -735,7 +774,7 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
             gm.load(Gb, a.ldo, (t + 1) * 32, a.Nq, a.d);
             if (threadIdx.x < 32) {
                 const int qi = (t + 1) * 32 + threadIdx.x;
-                lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
+                lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
                 D_r = qi < a.Nq ? D_g[qi] : 0.f;
             }
         }
@@ -805,7 +844,7 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
                 qm.store_t(QtT);
                 gm.store_t(GtT);
             }
-            if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r; D_s[threadIdx.x] = D_r; }
+            if (threadIdx.x < 32) { lse_s[threadIdx.x] = lse_r * LOG2E; D_s[threadIdx.x] = D_r; }
         }
         if (DB || more) __syncthreads();
     }
@@ -833,7 +872,7 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
     }
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) void flash_dkdv_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dkdv_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DKDV];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -904,6 +943,7 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
     };
     load_pair(0);
     store_pair(cur);
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int p = 0; p < npairs; ++p) {
@@ -918,6 +958,19 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
             mma(d0, frag_kc<T, DMAX>(cur + G::TILE_BYTES, r, s, hh), gf[s]);
             mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
             mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), gf[s]);
+        }
+        // the K fragments of the four dS K k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise)
+        TrF kfr[4][G::NT32];
+        const unsigned ka0 = lds_addr32(cur) + tr_off, ka1 = lds_addr32(cur + ONE) + tr_off;
+        auto issue_k = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            tr_issue_j<G::RS, (k & 1)>(k < 2 ? ka0 : ka1, kfr[k], std::make_integer_sequence<int, G::NT32>{});
+        };
+        if (COMAT_FLASH_EARLY_TR) {
+            issue_k(std::integral_constant<int, 0>{});
+            issue_k(std::integral_constant<int, 1>{});
+            issue_k(std::integral_constant<int, 2>{});
+            issue_k(std::integral_constant<int, 3>{});
         }
         {
             const f32x2_t c2v = splat2(c2), nl = splat2(-lse_q), nD = splat2(-D_q), scv = splat2(a.scale);
@@ -937,19 +990,17 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
                 if (p * 64 + 32 + crow(i, hh) >= a.Nk) s1[i] = 0.f;
             }
         }
-        const unsigned ka0 = lds_addr32(cur) + tr_off, ka1 = lds_addr32(cur + ONE) + tr_off;
-        auto step = [&](auto jc, unsigned ka, const f32x16_t& ds) {
-            constexpr int j = decltype(jc)::value;
-            TrF kfr[G::NT32];
-            tr_issue_j<G::RS, j>(ka, kfr, std::make_integer_sequence<int, G::NT32>{});
-            const F db = pack_acc<T>(ds, j);
+        auto step = [&](auto kc, const f32x16_t& ds) {
+            constexpr int k = decltype(kc)::value;
+            if (!COMAT_FLASH_EARLY_TR) issue_k(kc);
+            const F db = pack_acc<T>(ds, k & 1);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[t2]), db);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[k][t2]), db);
         };
-        step(std::integral_constant<int, 0>{}, ka0, s0);
-        step(std::integral_constant<int, 1>{}, ka0, s0);
-        step(std::integral_constant<int, 0>{}, ka1, s1);
-        step(std::integral_constant<int, 1>{}, ka1, s1);
+        step(std::integral_constant<int, 0>{}, s0);
+        step(std::integral_constant<int, 1>{}, s0);
+        step(std::integral_constant<int, 2>{}, s1);
+        step(std::integral_constant<int, 3>{}, s1);
         cur = smem + ((p + 1) & 1) * PAIR;
         if (more) store_pair(cur);
         __syncthreads();
@@ -965,7 +1016,7 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
     }
 }
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) void flash_dq2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_dq2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DQ2];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -1008,7 +1059,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
     const int tbeg = bz * per;
     const int tend = tbeg + per < ntq ? tbeg + per : ntq;
     const float c2 = a.scale * LOG2E;
-    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..63: queries of the pair (lse in log2 units)
+    float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..63: queries of the pair (lse -> log2 units at the LDS store)
     auto load_pair = [&](int t) {
         qm0.load(Qb, a.ldq, t * 32, a.Nq, a.d);
         gm0.load(Gb, a.ldo, t * 32, a.Nq, a.d);
@@ -1016,7 +1067,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
         gm1.load(Gb, a.ldo, t * 32 + 32, a.Nq, a.d);
         if (threadIdx.x < 64) {
             const int qi = t * 32 + threadIdx.x;
-            lse_r = qi < a.Nq ? lse_g[qi] * LOG2E : 0.f;
+            lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
             D_r = qi < a.Nq ? D_g[qi] : 0.f;
         }
     };
@@ -1027,7 +1078,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
         gm1.store(dst + ONE + G::TILE_BYTES);
         if (threadIdx.x < 64) {
             float* st = (float*)(dst + (threadIdx.x >> 5) * ONE + 2 * G::TILE_BYTES);
-            st[threadIdx.x & 31] = lse_r;
+            st[threadIdx.x & 31] = lse_r * LOG2E;
             st[32 + (threadIdx.x & 31)] = D_r;
         }
     };
@@ -1035,6 +1086,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
         load_pair(tbeg);
         store_pair(cur);
     }
+    loads_landed();
     __syncthreads();
     const unsigned tr_off = tr_lane_off<G::RS>(lane);
     for (int t = tbeg; t < tend; t += 2) {
@@ -1051,6 +1103,18 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
             mma(c1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), kf[s]);
             mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), vf[s]);
         }
+        const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
+        const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        // the dO / Q fragments of the four k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise); with COMAT_FLASH_EARLY_TR
+        // the reads of step k + 1 are in flight while step k multiplies (two register sets)
+        TrF gfr[COMAT_FLASH_EARLY_TR ? 2 : 1][G::NT32], qfr[COMAT_FLASH_EARLY_TR ? 2 : 1][G::NT32];
+        auto issue_gq = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int slot = COMAT_FLASH_EARLY_TR ? (k & 1) : 0;
+            tr_issue_j<G::RS, (k & 1)>(k < 2 ? ga0 : ga1, gfr[slot], std::make_integer_sequence<int, G::NT32>{});
+            tr_issue_j<G::RS, (k & 1)>(k < 2 ? qa0 : qa1, qfr[slot], std::make_integer_sequence<int, G::NT32>{});
+        };
+        if (COMAT_FLASH_EARLY_TR) issue_gq(std::integral_constant<int, 0>{});
         const float* st0 = (const float*)(cur + 2 * G::TILE_BYTES);
         const float* st1 = (const float*)(cur + ONE + 2 * G::TILE_BYTES);
         // rows beyond Nq / a missing second tile: last pair only; keys beyond Nk: last key block only - a BLOCK-uniform
@@ -1082,25 +1146,34 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
             d0[i] = e0.x; d0[i + 1] = e0.y;
             d1[i] = e1.x; d1[i + 1] = e1.y;
         }
-        const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
-        const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
-        auto step = [&](auto jc, unsigned qa, unsigned ga, const f32x16_t& pr, const f32x16_t& ds) {
-            constexpr int j = decltype(jc)::value;
-            TrF gfr[G::NT32], qfr[G::NT32];
-            tr_issue_j<G::RS, j>(ga, gfr, std::make_integer_sequence<int, G::NT32>{});
-            tr_issue_j<G::RS, j>(qa, qfr, std::make_integer_sequence<int, G::NT32>{});
-            const F pb = pack_acc<T>(pr, j);
-            const F db = pack_acc<T>(ds, j);
+        auto step = [&](auto kc, const f32x16_t& pr, const f32x16_t& ds) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int slot = COMAT_FLASH_EARLY_TR ? (k & 1) : 0;
+            if (!COMAT_FLASH_EARLY_TR) issue_gq(kc);
+            const F pb = pack_acc<T>(pr, k & 1);
+            const F db = pack_acc<T>(ds, k & 1);
+            if (COMAT_FLASH_EARLY_TR) {
+                short8_t gv[G::NT32], qv[G::NT32];
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) {
-                mma(dvT[t2], tr_take(gfr[t2]), pb);
-                mma(dkT[t2], tr_take(qfr[t2]), db);
+                for (int t2 = 0; t2 < G::NT32; ++t2) { gv[t2] = tr_take(gfr[slot][t2]); qv[t2] = tr_take(qfr[slot][t2]); }
+                if (k < 3) issue_gq(std::integral_constant<int, (k + 1) % 4>{});
+#pragma unroll
+                for (int t2 = 0; t2 < G::NT32; ++t2) {
+                    mma(dvT[t2], gv[t2], pb);
+                    mma(dkT[t2], qv[t2], db);
+                }
+            } else {
+#pragma unroll
+                for (int t2 = 0; t2 < G::NT32; ++t2) {
+                    mma(dvT[t2], tr_take(gfr[0][t2]), pb);
+                    mma(dkT[t2], tr_take(qfr[0][t2]), db);
+                }
             }
         };
-        step(std::integral_constant<int, 0>{}, qa0, ga0, c0, d0);
-        step(std::integral_constant<int, 1>{}, qa0, ga0, c0, d0);
-        step(std::integral_constant<int, 0>{}, qa1, ga1, c1, d1);
-        step(std::integral_constant<int, 1>{}, qa1, ga1, c1, d1);
+        step(std::integral_constant<int, 0>{}, c0, d0);
+        step(std::integral_constant<int, 1>{}, c0, d0);
+        step(std::integral_constant<int, 2>{}, c1, d1);
+        step(std::integral_constant<int, 3>{}, c1, d1);
         cur = smem + (((t - tbeg) / 2 + 1) & 1) * PAIR;
         if (more) store_pair(cur);
         __syncthreads();
@@ -1129,7 +1202,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
     }
 }
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) void flash_dkdv2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_dkdv2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DKDV2];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -1170,7 +1243,7 @@ __global__ __launch_bounds__(NT) void flash_delta_kernel(FlashArgs a) {
 // 32 x 32 level: 128 each), so run side by side they take max(dQ, dK/dV) instead of the sum.  Same bodies, same bits as the
 // separate kernels.  DQ2: the dQ role walks two key tiles per iteration (flash_dq2_body).
 template <typename T, int DMAX, int NK, bool TR, bool DQ2>
-__global__ __launch_bounds__(NT) void flash_bwd_kernel(FlashArgs a, int nqb, int nkb) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_bwd_kernel(FlashArgs a, int nqb, int nkb) {
     typedef BwdLds<T, DMAX, TR> L;
     constexpr int LDQ = DQ2 ? L::DQ2 : L::DQ;
     __shared__ __attribute__((aligned(16))) char smem[LDQ > L::DKDV ? LDQ : L::DKDV];
