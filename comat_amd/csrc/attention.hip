@@ -24,22 +24,31 @@
 namespace {
 
 constexpr int NT = 256;
-// The bf16 kernels for head dims <= 64 hold 100 - 240 registers and the step's shapes give a CU at most two of their 4-wave
-// blocks: they never run more than two waves per SIMD.  Saying so (COMAT_FLASH_W2) lets the scheduler spend registers on
-// batching the LDS fragment reads ahead of the MFMAs instead of cycling two fragment registers to stay inside a
-// three-waves budget nobody uses.  Larger head dims and fp32 already sit at 256 registers: the same hint makes them spill.
+// ---- build-time policy of the fused attention kernels (round 4, calls 12 - 15: same-box A/B of one build per setting,
+// profiles/r04_l_mb_flash_ab.txt, r04_n_mb_flash_diet.txt; every switch can be overridden with -D for such a run) ----------
+// COMAT_FLASH_W2: the bf16 backward kernels for head dims <= 64 hold 160 - 250 registers and the step's shapes give a CU at
+//   most two of their 4-wave blocks - they never run more than two waves per SIMD.  Saying so (amdgpu_waves_per_eu(2, 2)) lets
+//   the scheduler batch LDS fragment reads ahead of the MFMAs instead of cycling two fragment registers to stay inside a
+//   three-waves budget nobody uses: backward 2 x 8 x 4096^2 d=40 265.9 -> 259.1 us, 1 x 8: 173.2 -> 159.1.  Not the forward
+//   kernels (d = 64: 144 -> 163 us), not head dims > 64 or fp32 (already at 256 registers: the hint makes them spill).
 #ifndef COMAT_FLASH_W2
-#define COMAT_FLASH_W2 0
+#define COMAT_FLASH_W2 1
 #endif
-// COMAT_FLASH_EARLY_TR: the 2-tile kernels issue the transposed LDS reads of their second product (P V, dS K, P^T dO /
-// dS^T Q) ahead of the softmax arithmetic that produces the other operand, so the reads' latency hides under that VALU work
-// and the product's MFMAs run back to back (forward, dQ: all four k-steps, +32 registers; dK/dV: one k-step ahead, +16).
-#ifndef COMAT_FLASH_EARLY_TR
-#define COMAT_FLASH_EARLY_TR 0
+// COMAT_FLASH_FULL_TILES: tiles with every row inside the matrix come through buffer loads with scalar tile offsets
+//   (TileMover::load_full): forward 109.3 -> 101.4 us, backward 270.2 -> 262.8 at 2 x 8 x 4096^2 d=40, every 2-tile shape gains.
+#ifndef COMAT_FLASH_FULL_TILES
+#define COMAT_FLASH_FULL_TILES 1
 #endif
-constexpr bool flash_two_waves(int dmax, int elem_bytes) { return COMAT_FLASH_W2 && dmax <= 64 && elem_bytes == 2; }
-#define FLASH_OCC(DMAX, ESZ) \
-    __attribute__((amdgpu_waves_per_eu(flash_two_waves(DMAX, ESZ) ? 2 : 1, flash_two_waves(DMAX, ESZ) ? 2 : 8)))
+// COMAT_FLASH_SCALE_OUT: dS = P (dP - D) without the softmax scale; dQ and dK are multiplied by it once, when they are stored
+//   (one multiply per score less in every backward iteration; the products see dS before instead of after the scaling):
+//   backward d=40 262.8 -> 252.1 us, d=64 445 -> 433; the 96-wide kernels (d = 80) lose (83.3 -> 88.9) and keep the old form.
+#ifndef COMAT_FLASH_SCALE_OUT
+#define COMAT_FLASH_SCALE_OUT 1
+#endif
+constexpr bool flash_scale_out(int dmax) { return COMAT_FLASH_SCALE_OUT && dmax != 96; }
+constexpr bool flash_two_waves(int dmax, int elem_bytes, bool bwd) { return COMAT_FLASH_W2 && bwd && dmax <= 64 && elem_bytes == 2; }
+#define FLASH_OCC(DMAX, ESZ, BWD) \
+    __attribute__((amdgpu_waves_per_eu(flash_two_waves(DMAX, ESZ, BWD) ? 2 : 1, flash_two_waves(DMAX, ESZ, BWD) ? 2 : 8)))
 
 template <typename T> struct FragOf;
 template <> struct FragOf<bf16_t> { typedef short8_t type; };
@@ -122,6 +131,12 @@ template <typename T, int DMAX, bool TR> struct BwdLds {
 // full global-load latency (round 4, tools/isa_loop.py --order).  A builtin, not inline asm: the waitcnt pass reads it.
 __device__ __forceinline__ void loads_landed() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), nothing else
 
+// resource descriptor of one (batch, head) slab [rows x d] with row stride ld: raw (untyped) access, every byte up to the
+// end of the last row's head columns in range (the slab must stay below 2 GiB: comat_flash_attn_* check it)
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const T* base, int rows, int64_t ld, int d) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(rows - 1) * ld + d) * (int64_t)sizeof(T)), 0x00020000);
+}
+
 // cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
 template <typename T, int DMAX> struct TileMover {
     typedef Geo<T, DMAX> G;
@@ -136,6 +151,28 @@ template <typename T, int DMAX> struct TileMover {
                 if (row0 + rr < nrows && col < d) v = *(const uint4*)(base + (int64_t)(row0 + rr) * ld + col);
             }
             regs[i] = v;
+        }
+    }
+    // Full tiles (every row inside the matrix - all but the last tile of a loop) come through BUFFER loads: the operand's
+    // (batch, head) slab is one resource descriptor in SGPRs, the tile's byte offset a scalar, and a thread's chunk offset
+    // inside a tile never changes (prepare(), once per kernel and operand).  Lanes that hold no data - columns beyond d -
+    // carry an offset beyond the descriptor's size and read zeros from the range check.  Per tile and iteration: one load
+    // instruction, no 64-bit pointer arithmetic, no compare / select / re-zero, no divergent region (they were ~20 of the
+    // ~150 VALU instructions of a 64-key forward iteration, and four exec-mask branches).
+    unsigned voff[G::NCHK];
+    __device__ __forceinline__ void prepare(int64_t ld, int d) {
+#pragma unroll
+        for (int i = 0; i < G::NCHK; ++i) {
+            const int c = threadIdx.x + i * NT;
+            const int rr = c / G::CPRW, col = (c % G::CPRW) * G::KC;
+            voff[i] = (c < 32 * G::CPRW && col < d) ? (unsigned)((rr * ld + col) * (int64_t)sizeof(T)) : 0x80000000u;
+        }
+    }
+    __device__ __forceinline__ void load_full(__amdgpu_buffer_rsrc_t slab, unsigned tile_off) {
+#pragma unroll
+        for (int i = 0; i < G::NCHK; ++i) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(slab, voff[i], tile_off, 0);
+            __builtin_memcpy(&regs[i], &v, 16);
         }
     }
     __device__ __forceinline__ void store(char* lds) const {
@@ -299,7 +336,7 @@ __device__ __forceinline__ void flash_block_xy(int xcd, int& bx, int& by) {
 }
 
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_fwd_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T), false) void flash_fwd_kernel(FlashArgs a) {
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     // LDS: [K tile | V tile (TR: its transposed image)], TWICE when it fits (DB): the next tile is written into the other
@@ -435,7 +472,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_fwd_kerne
 // results the softmax of the other can overlap.  Same arithmetic per score as flash_fwd_kernel; the running maximum moves
 // at 64-key granularity, so results agree with the 32-key kernel to rounding, not bit for bit.
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2, false) void flash_fwd2_kernel(FlashArgs a) {
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
@@ -464,7 +501,21 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(Flash
     const float c2 = a.scale * LOG2E;
     TileMover<T, DMAX> km0, vm0, km1, vm1;
     const int npairs = (a.Nk + 63) / 64;
-    auto load_pair = [&](int p) {  // rows beyond Nk come back as zeros (TileMover), their scores are masked below
+    const __amdgpu_buffer_rsrc_t k_slab = slab_rsrc(Kb, a.Nk, a.ldk, a.d), v_slab = slab_rsrc(Vb, a.Nk, a.ldv, a.d);
+    km0.prepare(a.ldk, a.d);
+    vm0.prepare(a.ldv, a.d);
+    km1.prepare(a.ldk, a.d);
+    vm1.prepare(a.ldv, a.d);
+    auto load_pair = [&](int p) {
+        if (COMAT_FLASH_FULL_TILES && (p + 1) * 64 <= a.Nk) {
+            const unsigned ko = (unsigned)(p * 64 * a.ldk * (int64_t)sizeof(T)), vo = (unsigned)(p * 64 * a.ldv * (int64_t)sizeof(T));
+            km0.load_full(k_slab, ko);
+            vm0.load_full(v_slab, vo);
+            km1.load_full(k_slab, ko + (unsigned)(32 * a.ldk * (int64_t)sizeof(T)));
+            vm1.load_full(v_slab, vo + (unsigned)(32 * a.ldv * (int64_t)sizeof(T)));
+            return;
+        }
+        // rows beyond Nk come back as zeros (TileMover), their scores are masked below
         km0.load(Kb, a.ldk, p * 64, a.Nk, a.d);
         vm0.load(Vb, a.ldv, p * 64, a.Nk, a.d);
         km1.load(Kb, a.ldk, p * 64 + 32, a.Nk, a.d);
@@ -491,19 +542,6 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(Flash
         for (int s = 0; s < NK; ++s) {
             mma(s0, frag_kc<T, DMAX>(cur, r, s, hh), qf[s]);
             mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
-        }
-        // the V fragments of the four P V k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise)
-        TrF vf[4][G::NT32];
-        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
-        auto issue_v = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            tr_issue_j<G::RS, (k & 1)>(k < 2 ? va0 : va1, vf[k], std::make_integer_sequence<int, G::NT32>{});
-        };
-        if (COMAT_FLASH_EARLY_TR) {
-            issue_v(std::integral_constant<int, 0>{});
-            issue_v(std::integral_constant<int, 1>{});
-            issue_v(std::integral_constant<int, 2>{});
-            issue_v(std::integral_constant<int, 3>{});
         }
         if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
 #pragma unroll
@@ -541,17 +579,19 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(Flash
         }
         l += ps;
         m = m_new;
-        auto step = [&](auto kc, const f32x16_t& st) {
-            constexpr int k = decltype(kc)::value;
-            if (!COMAT_FLASH_EARLY_TR) issue_v(kc);
-            const F pb = pack_acc<T>(st, k & 1);
+        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        auto step = [&](auto jc, unsigned va, const f32x16_t& st) {
+            constexpr int j = decltype(jc)::value;
+            TrF vf[G::NT32];
+            tr_issue_j<G::RS, j>(va, vf, std::make_integer_sequence<int, G::NT32>{});
+            const F pb = pack_acc<T>(st, j);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[k][t2]), pb);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[t2]), pb);
         };
-        step(std::integral_constant<int, 0>{}, s0);
-        step(std::integral_constant<int, 1>{}, s0);
-        step(std::integral_constant<int, 2>{}, s1);
-        step(std::integral_constant<int, 3>{}, s1);
+        step(std::integral_constant<int, 0>{}, va0, s0);
+        step(std::integral_constant<int, 1>{}, va0, s0);
+        step(std::integral_constant<int, 0>{}, va1, s1);
+        step(std::integral_constant<int, 1>{}, va1, s1);
         cur = smem + ((p + 1) & 1) * PAIR;  // last read in iteration p-1, which every wave left through the barrier below
         if (more) store_pair(cur);
         __syncthreads();
@@ -572,6 +612,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_fwd2_kernel(Flash
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false, bool WRITE_D = true>
 __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, int bx, int by) {
+    constexpr bool SCALE_OUT = flash_scale_out(DMAX);
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain K tile
@@ -647,7 +688,7 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, in
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float p = exp2_fast(__builtin_fmaf(st[i], c2, -lse_q));
-            st[i] = p * a.scale * (dp[i] - D_q);
+            st[i] = SCALE_OUT ? p * (dp[i] - D_q) : p * a.scale * (dp[i] - D_q);
         }
         if ((t + 1) * 32 > a.Nk) {  // keys beyond Nk exist only in the last tile
 #pragma unroll
@@ -694,12 +735,12 @@ __device__ __forceinline__ void flash_dq_body(const FlashArgs& a, char* smem, in
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = t2 * 32 + crow(i, hh);
-                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, dqT[t2][i]);
+                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, SCALE_OUT ? dqT[t2][i] * a.scale : dqT[t2][i]);
             }
     }
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dq_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T), true) void flash_dq_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DQ];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -709,6 +750,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dq_kernel
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, int bx, int by, int bz) {
+    constexpr bool SCALE_OUT = flash_scale_out(DMAX);
     typedef Geo<T, DMAX> G;
     typedef typename FragOf<T>::type F;
     constexpr bool HW = TR && sizeof(T) == 2;  // bf16: hardware transpose reads from the plain Q / dO tiles
@@ -797,7 +839,8 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
                 if (!((t * 32 + crow(i, hh) < a.Nq) && (key < a.Nk))) sc[i] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dp[i] = sc[i] * a.scale * (dp[i] - D_s[crow(i, hh)]);
+        for (int i = 0; i < 16; ++i)
+            dp[i] = SCALE_OUT ? sc[i] * (dp[i] - D_s[crow(i, hh)]) : sc[i] * a.scale * (dp[i] - D_s[crow(i, hh)]);
         if constexpr (HW) {
             const unsigned qa = lds_addr32(Qt) + tr_off, ga = lds_addr32(Gt) + tr_off;
             auto step = [&](auto jc) {
@@ -860,11 +903,12 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
             for (int i = 0; i < 16; ++i) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) {
+                    const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
                     if (a.qsplit > 1) {
-                        pk[n] = dkT[t2][i];
+                        pk[n] = dk;
                         pv[n] = dvT[t2][i];
                     } else {
-                        stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
+                        stf<T>(dKb + (int64_t)key * a.ldk + n, dk);
                         stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
                     }
                 }
@@ -872,7 +916,7 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
     }
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dkdv_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T), true) void flash_dkdv_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<T, DMAX, TR>::DKDV];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -885,6 +929,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_dkdv_kern
 // come from the forward), so dQ / dK / dV differ from theirs only in the order the two tiles' MFMA products are added.
 template <int DMAX, int NK, bool WRITE_D = true>
 __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, int bx, int by) {
+    constexpr bool SCALE_OUT = flash_scale_out(DMAX);
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
@@ -929,7 +974,20 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
         for (int i = 0; i < 16; ++i) dqT[t][i] = 0.f;
     TileMover<T, DMAX> km0, vm0, km1, vm1;
     const int npairs = (a.Nk + 63) / 64;
+    const __amdgpu_buffer_rsrc_t k_slab = slab_rsrc(Kb, a.Nk, a.ldk, a.d), v_slab = slab_rsrc(Vb, a.Nk, a.ldv, a.d);
+    km0.prepare(a.ldk, a.d);
+    vm0.prepare(a.ldv, a.d);
+    km1.prepare(a.ldk, a.d);
+    vm1.prepare(a.ldv, a.d);
     auto load_pair = [&](int p) {
+        if (COMAT_FLASH_FULL_TILES && (p + 1) * 64 <= a.Nk) {
+            const unsigned ko = (unsigned)(p * 64 * a.ldk * (int64_t)sizeof(T)), vo = (unsigned)(p * 64 * a.ldv * (int64_t)sizeof(T));
+            km0.load_full(k_slab, ko);
+            vm0.load_full(v_slab, vo);
+            km1.load_full(k_slab, ko + (unsigned)(32 * a.ldk * (int64_t)sizeof(T)));
+            vm1.load_full(v_slab, vo + (unsigned)(32 * a.ldv * (int64_t)sizeof(T)));
+            return;
+        }
         km0.load(Kb, a.ldk, p * 64, a.Nk, a.d);
         vm0.load(Vb, a.ldv, p * 64, a.Nk, a.d);
         km1.load(Kb, a.ldk, p * 64 + 32, a.Nk, a.d);
@@ -959,26 +1017,14 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
             mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
             mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), gf[s]);
         }
-        // the K fragments of the four dS K k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise)
-        TrF kfr[4][G::NT32];
-        const unsigned ka0 = lds_addr32(cur) + tr_off, ka1 = lds_addr32(cur + ONE) + tr_off;
-        auto issue_k = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            tr_issue_j<G::RS, (k & 1)>(k < 2 ? ka0 : ka1, kfr[k], std::make_integer_sequence<int, G::NT32>{});
-        };
-        if (COMAT_FLASH_EARLY_TR) {
-            issue_k(std::integral_constant<int, 0>{});
-            issue_k(std::integral_constant<int, 1>{});
-            issue_k(std::integral_constant<int, 2>{});
-            issue_k(std::integral_constant<int, 3>{});
-        }
         {
             const f32x2_t c2v = splat2(c2), nl = splat2(-lse_q), nD = splat2(-D_q), scv = splat2(a.scale);
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 const f32x2_t p0 = exp2_fast2(__builtin_elementwise_fma(pair_of(s0, i), c2v, nl));
                 const f32x2_t p1 = exp2_fast2(__builtin_elementwise_fma(pair_of(s1, i), c2v, nl));
-                const f32x2_t e0 = (p0 * scv) * (pair_of(d0, i) + nD), e1 = (p1 * scv) * (pair_of(d1, i) + nD);
+                const f32x2_t e0 = (SCALE_OUT ? p0 : p0 * scv) * (pair_of(d0, i) + nD);
+                const f32x2_t e1 = (SCALE_OUT ? p1 : p1 * scv) * (pair_of(d1, i) + nD);
                 s0[i] = e0.x; s0[i + 1] = e0.y;
                 s1[i] = e1.x; s1[i + 1] = e1.y;
             }
@@ -990,17 +1036,19 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
                 if (p * 64 + 32 + crow(i, hh) >= a.Nk) s1[i] = 0.f;
             }
         }
-        auto step = [&](auto kc, const f32x16_t& ds) {
-            constexpr int k = decltype(kc)::value;
-            if (!COMAT_FLASH_EARLY_TR) issue_k(kc);
-            const F db = pack_acc<T>(ds, k & 1);
+        const unsigned ka0 = lds_addr32(cur) + tr_off, ka1 = lds_addr32(cur + ONE) + tr_off;
+        auto step = [&](auto jc, unsigned ka, const f32x16_t& ds) {
+            constexpr int j = decltype(jc)::value;
+            TrF kfr[G::NT32];
+            tr_issue_j<G::RS, j>(ka, kfr, std::make_integer_sequence<int, G::NT32>{});
+            const F db = pack_acc<T>(ds, j);
 #pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[k][t2]), db);
+            for (int t2 = 0; t2 < G::NT32; ++t2) mma(dqT[t2], tr_take(kfr[t2]), db);
         };
-        step(std::integral_constant<int, 0>{}, s0);
-        step(std::integral_constant<int, 1>{}, s0);
-        step(std::integral_constant<int, 2>{}, s1);
-        step(std::integral_constant<int, 3>{}, s1);
+        step(std::integral_constant<int, 0>{}, ka0, s0);
+        step(std::integral_constant<int, 1>{}, ka0, s0);
+        step(std::integral_constant<int, 0>{}, ka1, s1);
+        step(std::integral_constant<int, 1>{}, ka1, s1);
         cur = smem + ((p + 1) & 1) * PAIR;
         if (more) store_pair(cur);
         __syncthreads();
@@ -1011,12 +1059,12 @@ __device__ __forceinline__ void flash_dq2_body(const FlashArgs& a, char* smem, i
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int n = t2 * 32 + crow(i, hh);
-                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, dqT[t2][i]);
+                if (n < a.d) stf<T>(dQb + (int64_t)q * a.ldq + n, SCALE_OUT ? dqT[t2][i] * a.scale : dqT[t2][i]);
             }
     }
 }
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_dq2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2, true) void flash_dq2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DQ2];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -1025,6 +1073,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_dq2_kernel(FlashA
 
 template <int DMAX, int NK>
 __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem, int bx, int by, int bz) {
+    constexpr bool SCALE_OUT = flash_scale_out(DMAX);
     typedef bf16_t T;
     typedef Geo<T, DMAX> G;
     typedef short8_t F;
@@ -1060,11 +1109,24 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
     const int tend = tbeg + per < ntq ? tbeg + per : ntq;
     const float c2 = a.scale * LOG2E;
     float lse_r = 0.f, D_r = 0.f;  // staged by threads 0..63: queries of the pair (lse -> log2 units at the LDS store)
+    const __amdgpu_buffer_rsrc_t q_slab = slab_rsrc(Qb, a.Nq, a.ldq, a.d), g_slab = slab_rsrc(Gb, a.Nq, a.ldo, a.d);
+    qm0.prepare(a.ldq, a.d);
+    gm0.prepare(a.ldo, a.d);
+    qm1.prepare(a.ldq, a.d);
+    gm1.prepare(a.ldo, a.d);
     auto load_pair = [&](int t) {
-        qm0.load(Qb, a.ldq, t * 32, a.Nq, a.d);
-        gm0.load(Gb, a.ldo, t * 32, a.Nq, a.d);
-        qm1.load(Qb, a.ldq, t * 32 + 32, a.Nq, a.d);
-        gm1.load(Gb, a.ldo, t * 32 + 32, a.Nq, a.d);
+        if (COMAT_FLASH_FULL_TILES && (t + 2) * 32 <= a.Nq) {
+            const unsigned qo = (unsigned)(t * 32 * a.ldq * (int64_t)sizeof(T)), go = (unsigned)(t * 32 * a.ldo * (int64_t)sizeof(T));
+            qm0.load_full(q_slab, qo);
+            gm0.load_full(g_slab, go);
+            qm1.load_full(q_slab, qo + (unsigned)(32 * a.ldq * (int64_t)sizeof(T)));
+            gm1.load_full(g_slab, go + (unsigned)(32 * a.ldo * (int64_t)sizeof(T)));
+        } else {
+            qm0.load(Qb, a.ldq, t * 32, a.Nq, a.d);
+            gm0.load(Gb, a.ldo, t * 32, a.Nq, a.d);
+            qm1.load(Qb, a.ldq, t * 32 + 32, a.Nq, a.d);
+            gm1.load(Gb, a.ldo, t * 32 + 32, a.Nq, a.d);
+        }
         if (threadIdx.x < 64) {
             const int qi = t * 32 + threadIdx.x;
             lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
@@ -1103,18 +1165,6 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
             mma(c1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), kf[s]);
             mma(d1, frag_kc<T, DMAX>(cur + ONE + G::TILE_BYTES, r, s, hh), vf[s]);
         }
-        const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
-        const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
-        // the dO / Q fragments of the four k-steps (tile 0: rows 0-15, 16-31; tile 1 likewise); with COMAT_FLASH_EARLY_TR
-        // the reads of step k + 1 are in flight while step k multiplies (two register sets)
-        TrF gfr[COMAT_FLASH_EARLY_TR ? 2 : 1][G::NT32], qfr[COMAT_FLASH_EARLY_TR ? 2 : 1][G::NT32];
-        auto issue_gq = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int slot = COMAT_FLASH_EARLY_TR ? (k & 1) : 0;
-            tr_issue_j<G::RS, (k & 1)>(k < 2 ? ga0 : ga1, gfr[slot], std::make_integer_sequence<int, G::NT32>{});
-            tr_issue_j<G::RS, (k & 1)>(k < 2 ? qa0 : qa1, qfr[slot], std::make_integer_sequence<int, G::NT32>{});
-        };
-        if (COMAT_FLASH_EARLY_TR) issue_gq(std::integral_constant<int, 0>{});
         const float* st0 = (const float*)(cur + 2 * G::TILE_BYTES);
         const float* st1 = (const float*)(cur + ONE + 2 * G::TILE_BYTES);
         // rows beyond Nq / a missing second tile: last pair only; keys beyond Nk: last key block only - a BLOCK-uniform
@@ -1142,38 +1192,30 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
         for (int i = 0; i < 16; i += 2) {
             const int qr = crow(i, hh);
             const f32x2_t D0 = *(const f32x2_t*)(st0 + 32 + qr), D1 = *(const f32x2_t*)(st1 + 32 + qr);
-            const f32x2_t e0 = (pair_of(c0, i) * scv) * (pair_of(d0, i) - D0), e1 = (pair_of(c1, i) * scv) * (pair_of(d1, i) - D1);
+            const f32x2_t e0 = (SCALE_OUT ? pair_of(c0, i) : pair_of(c0, i) * scv) * (pair_of(d0, i) - D0);
+            const f32x2_t e1 = (SCALE_OUT ? pair_of(c1, i) : pair_of(c1, i) * scv) * (pair_of(d1, i) - D1);
             d0[i] = e0.x; d0[i + 1] = e0.y;
             d1[i] = e1.x; d1[i + 1] = e1.y;
         }
-        auto step = [&](auto kc, const f32x16_t& pr, const f32x16_t& ds) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int slot = COMAT_FLASH_EARLY_TR ? (k & 1) : 0;
-            if (!COMAT_FLASH_EARLY_TR) issue_gq(kc);
-            const F pb = pack_acc<T>(pr, k & 1);
-            const F db = pack_acc<T>(ds, k & 1);
-            if (COMAT_FLASH_EARLY_TR) {
-                short8_t gv[G::NT32], qv[G::NT32];
+        const unsigned qa0 = lds_addr32(cur) + tr_off, ga0 = lds_addr32(cur + G::TILE_BYTES) + tr_off;
+        const unsigned qa1 = lds_addr32(cur + ONE) + tr_off, ga1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
+        auto step = [&](auto jc, unsigned qa, unsigned ga, const f32x16_t& pr, const f32x16_t& ds) {
+            constexpr int j = decltype(jc)::value;
+            TrF gfr[G::NT32], qfr[G::NT32];
+            tr_issue_j<G::RS, j>(ga, gfr, std::make_integer_sequence<int, G::NT32>{});
+            tr_issue_j<G::RS, j>(qa, qfr, std::make_integer_sequence<int, G::NT32>{});
+            const F pb = pack_acc<T>(pr, j);
+            const F db = pack_acc<T>(ds, j);
 #pragma unroll
-                for (int t2 = 0; t2 < G::NT32; ++t2) { gv[t2] = tr_take(gfr[slot][t2]); qv[t2] = tr_take(qfr[slot][t2]); }
-                if (k < 3) issue_gq(std::integral_constant<int, (k + 1) % 4>{});
-#pragma unroll
-                for (int t2 = 0; t2 < G::NT32; ++t2) {
-                    mma(dvT[t2], gv[t2], pb);
-                    mma(dkT[t2], qv[t2], db);
-                }
-            } else {
-#pragma unroll
-                for (int t2 = 0; t2 < G::NT32; ++t2) {
-                    mma(dvT[t2], tr_take(gfr[0][t2]), pb);
-                    mma(dkT[t2], tr_take(qfr[0][t2]), db);
-                }
+            for (int t2 = 0; t2 < G::NT32; ++t2) {
+                mma(dvT[t2], tr_take(gfr[t2]), pb);
+                mma(dkT[t2], tr_take(qfr[t2]), db);
             }
         };
-        step(std::integral_constant<int, 0>{}, c0, d0);
-        step(std::integral_constant<int, 1>{}, c0, d0);
-        step(std::integral_constant<int, 2>{}, c1, d1);
-        step(std::integral_constant<int, 3>{}, c1, d1);
+        step(std::integral_constant<int, 0>{}, qa0, ga0, c0, d0);
+        step(std::integral_constant<int, 1>{}, qa0, ga0, c0, d0);
+        step(std::integral_constant<int, 0>{}, qa1, ga1, c1, d1);
+        step(std::integral_constant<int, 1>{}, qa1, ga1, c1, d1);
         cur = smem + (((t - tbeg) / 2 + 1) & 1) * PAIR;
         if (more) store_pair(cur);
         __syncthreads();
@@ -1190,11 +1232,12 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
             for (int i = 0; i < 16; ++i) {
                 const int n = t2 * 32 + crow(i, hh);
                 if (n < a.d) {
+                    const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
                     if (a.qsplit > 1) {
-                        pk[n] = dkT[t2][i];
+                        pk[n] = dk;
                         pv[n] = dvT[t2][i];
                     } else {
-                        stf<T>(dKb + (int64_t)key * a.ldk + n, dkT[t2][i]);
+                        stf<T>(dKb + (int64_t)key * a.ldk + n, dk);
                         stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
                     }
                 }
@@ -1202,7 +1245,7 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
     }
 }
 template <int DMAX, int NK>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2) void flash_dkdv2_kernel(FlashArgs a) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2, true) void flash_dkdv2_kernel(FlashArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[BwdLds<bf16_t, DMAX, true>::DKDV2];
     int bx, by;
     flash_block_xy(a.xcd, bx, by);
@@ -1243,7 +1286,7 @@ __global__ __launch_bounds__(NT) void flash_delta_kernel(FlashArgs a) {
 // 32 x 32 level: 128 each), so run side by side they take max(dQ, dK/dV) instead of the sum.  Same bodies, same bits as the
 // separate kernels.  DQ2: the dQ role walks two key tiles per iteration (flash_dq2_body).
 template <typename T, int DMAX, int NK, bool TR, bool DQ2>
-__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T)) void flash_bwd_kernel(FlashArgs a, int nqb, int nkb) {
+__global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T), true) void flash_bwd_kernel(FlashArgs a, int nqb, int nkb) {
     typedef BwdLds<T, DMAX, TR> L;
     constexpr int LDQ = DQ2 ? L::DQ2 : L::DQ;
     __shared__ __attribute__((aligned(16))) char smem[LDQ > L::DKDV ? LDQ : L::DKDV];
@@ -1377,6 +1420,10 @@ int check_args(const char* what, const void* Q, const void* K, const void* V, in
     COMAT_REQUIRE(d <= 160 && d % kc == 0, "%s: head dim %d unsupported (<=160, multiple of %d)", what, d, kc);
     COMAT_REQUIRE(ldq % kc == 0 && ldk % kc == 0 && ldv % kc == 0 && ldo % kc == 0, "%s: leading dims must be 16-byte multiples", what);
     COMAT_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0, "%s: operands must be 16-byte aligned", what);
+    // one (batch, head) slab is addressed through a buffer descriptor with 32-bit offsets (TileMover::load_full)
+    const int64_t esz = dtype == COMAT_BF16 ? 2 : 4, lim = (int64_t)1 << 31;
+    COMAT_REQUIRE(Nq * ldq * esz < lim && Nk * ldk * esz < lim && Nk * ldv * esz < lim && Nq * ldo * esz < lim,
+                  "%s: a batch entry of an operand must stay below 2 GiB", what);
     return 0;
 }
 
