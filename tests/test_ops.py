@@ -1505,6 +1505,24 @@ def test_flash_backward_partials_do_not_touch_the_gemm_tickets(hip, default_opts
 
 
 @pytest.mark.gpu
+def test_flash_refuses_a_batch_entry_beyond_the_descriptor_range(hip, default_opts):
+    """Round 4: full attention tiles come through buffer loads whose offsets inside one (batch, head) slab are 32 bits wide
+    (TileMover::load_full).  A batch entry of 2 GiB or more must be refused by the entry point, not wrapped around; the
+    same shapes with an ordinary leading dimension go through, mixing full tiles (fast path) and a ragged last tile."""
+    k = ops.kernels()
+    dtype = torch.bfloat16
+    N, H, d = 200, 1, 64  # 3 full 64-key pairs + a ragged one
+    q = dv(rnd(N, H * d, dtype=dtype, seed=1), hip, dtype)
+    o, lse = torch.empty_like(q), torch.empty(1, H, N, device=hip)
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        k.flash_attn_fwd(q, q, q, o, lse, 1, H, N, N, d, 1 << 24, H * d, H * d, H * d, d ** -0.5)  # 200 rows x 2^24 x 2 B
+    k.flash_attn_fwd(q, q, q, o, lse, 1, H, N, N, d, H * d, H * d, H * d, H * d, d ** -0.5)
+    qf = q.float()
+    ref = torch.softmax(qf @ qf.t() * d ** -0.5, dim=-1) @ qf
+    check(o, ref, dtype, "flash forward, 200 keys (full pairs + ragged tail)")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("splits", [0, 1, 5])
 def test_gemm2_k_major_operands(hip, splits, default_opts):
     """C (+)= A^T B with both operands stored k-major (the LoRA weight gradients dU = g^T h, dD = u^T x: contraction over
