@@ -6,11 +6,3 @@ import os as _os
 # each dispatch otherwise fetches its argument block across PCIe (measured on MI355X: 322 -> 303 ms/step on the same
 # box).  Read by the HIP runtime when it initialises, so it must be set before the first GPU call of the process.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
-
-try:  # the generator-side discriminator loss and the D step run on their own streams by design (step.CoMatTrainer): the
-    # discriminator head's AccumulateGrad nodes then see gradients from more than one stream, which torch reports once per
-    # process as a warning about an unintended mismatch
-    import torch.autograd.graph as _ag
-    _ag.set_warn_on_accumulate_grad_stream_mismatch(False)
-except Exception:  # noqa: BLE001 - older torch: nothing to switch off
-    pass

@@ -12,6 +12,7 @@ gradient buffers, so clip + AdamW is one HBM pass per buffer.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import random
 import sys
@@ -120,6 +121,25 @@ def sample_crop(resolution, rng: random.Random):
     ox, oy = rng.randint(0, offset_range), rng.randint(0, offset_range)
     size = resolution - offset_range
     return (ox, oy, size, size)  # the reference slices dim 2 with x and dim 3 with y: (row0, col0, h, w)
+
+
+@contextlib.contextmanager
+def _own_streams_by_design():
+    """The generator-side discriminator loss and the D step run on their own streams by design, so the discriminator head's
+    AccumulateGrad nodes see gradients from more than one stream - which torch reports as a (once per process) warning about
+    an unintended mismatch.  Switched off for the duration of THIS package's forward + backward only, and put back: user code
+    around the step keeps torch's check (round-3 advice: it used to be switched off process-wide at import)."""
+    get = getattr(torch._C, "_warn_on_accumulate_grad_stream_mismatch", None)
+    put = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if get is None or put is None:  # older torch: no such check
+        yield
+        return
+    before = get()
+    put(False)
+    try:
+        yield
+    finally:
+        put(before)
 
 
 class CoMatTrainer:
@@ -263,6 +283,10 @@ class CoMatTrainer:
         return D_loss.detach()
 
     def _forward_backward(self, batch, fixed):
+        with _own_streams_by_design():
+            return self._forward_backward_impl(batch, fixed)
+
+    def _forward_backward_impl(self, batch, fixed):
         """G forward + backward and the D forward + backward (everything of the step that precedes the exchange and
         the optimizer updates).  Returns a dict of device scalars (no host sync).
 
