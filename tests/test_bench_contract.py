@@ -26,6 +26,14 @@ def _check(d, n, steps, warmup):
     assert "SELFTEST" in d["data"]  # a self-test line can never be mistaken for a measurement
 
 
+def _free_port():
+    """a port nobody listens on right now (a fixed number can be busy on a shared host, and torchrun then waits for minutes)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_single_process_selftest():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest", "--steps", "2", "--warmup", "1"],
@@ -37,7 +45,7 @@ def test_single_process_selftest():
 def test_two_rank_launch_like_the_driver():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--selftest"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
@@ -47,15 +55,15 @@ def test_two_rank_launch_like_the_driver():
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("fail, port", [("1:segments:1", 29733), ("0:segments:1", 29741), ("1:segments:0", 29743)])
-def test_a_capture_failure_on_one_rank_sends_every_rank_to_eager_launches(fail, port):
+@pytest.mark.parametrize("fail", ["1:segments:1", "0:segments:1", "1:segments:0"])
+def test_a_capture_failure_on_one_rank_sends_every_rank_to_eager_launches(fail):
     """fault injection (rank : stepper : call index; call 0 = building the stepper): rank 1's first capturing step raises.  The failing rank re-runs that step eagerly (the other rank
     is waiting in the step's two all-reduces), the outcome is agreed afterwards, and BOTH ranks time eager launches - no
     deadlock, no unmatched collective, one JSON line that says what happened."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     env["COMAT_SELFTEST_FAIL"] = fail
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--selftest"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
