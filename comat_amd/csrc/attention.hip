@@ -1115,6 +1115,14 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
     qm1.prepare(a.ldq, a.d);
     gm1.prepare(a.ldo, a.d);
     auto load_pair = [&](int t) {
+        // lse / D first: the compiler guards their registers with vmcnt waits (the previous pair's loads were consumed inside a
+        // divergent region it cannot see through) - behind the tile loads those waits would cover the tiles as well, and the
+        // block's barrier would hand wave 0's stall to everybody
+        if (threadIdx.x < 64) {
+            const int qi = t * 32 + threadIdx.x;
+            lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
+            D_r = qi < a.Nq ? D_g[qi] : 0.f;
+        }
         if (COMAT_FLASH_FULL_TILES && (t + 2) * 32 <= a.Nq) {
             const unsigned qo = (unsigned)(t * 32 * a.ldq * (int64_t)sizeof(T)), go = (unsigned)(t * 32 * a.ldo * (int64_t)sizeof(T));
             qm0.load_full(q_slab, qo);
@@ -1126,11 +1134,6 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
             gm0.load(Gb, a.ldo, t * 32, a.Nq, a.d);
             qm1.load(Qb, a.ldq, t * 32 + 32, a.Nq, a.d);
             gm1.load(Gb, a.ldo, t * 32 + 32, a.Nq, a.d);
-        }
-        if (threadIdx.x < 64) {
-            const int qi = t * 32 + threadIdx.x;
-            lse_r = qi < a.Nq ? lse_g[qi] : 0.f;
-            D_r = qi < a.Nq ? D_g[qi] : 0.f;
         }
     };
     auto store_pair = [&](char* dst) {
