@@ -87,6 +87,12 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // launches), 1 where the lean kernel's rule wants the consumer, 2 always
     {"gemm2_chain", "COMAT_GEMM2_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch of the pipelined kernel (producer
                                                           // tiles first, the consumer's last segment waits for its row block)
+    {"flash_ks", "COMAT_FLASH_KS", 0, 0, false},          // 2-tile forward attention with an in-block key split (8 waves: two groups
+                                                          // of 4 own the same 128 queries and half of the keys each, merged in fixed
+                                                          // order through LDS): 0 never, 1 where the grid leaves a CU fewer than four
+                                                          // 4-wave blocks (<= 768 blocks, >= 256 keys, head dim <= 64), 2 wherever
+                                                          // the kernel exists.  Written in round 4 from the occupancy table
+                                                          // (profiles/r04_q_flash_occupancy.txt), NOT yet measured: off
 };
 }  // namespace
 
