@@ -92,6 +92,7 @@ SIGNATURES = {
     "comat_sumpool2x2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_permute_nchw_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_transpose_cast_tiles": [_vp, _vp, _vp, _i64, _i32, _vp],
+    "comat_lora_merge": [_vp, _vp, _i64, _f, _vp],
     "comat_cfg_ddpm_fwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i32, _vp],
     "comat_cfg_ddpm_bwd": [_vp, _vp, _vp, _i64, _f, _f, _f, _i32, _vp],
     "comat_resample2d": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32,
@@ -114,6 +115,7 @@ SIGNATURES = {
     "comat_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
+ABI_VERSION = 6
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
 
 _lib = None
@@ -131,14 +133,15 @@ def load_library(path: str | None = None):
             "(comat_amd has no CPU fallback)")
     lib = C.CDLL(p)
     lib.comat_abi_version.restype = C.c_int
+    if lib.comat_abi_version() != ABI_VERSION:  # checked before anything newer than ABI 1 is bound: a stale build says so
+        raise RuntimeError(f"libcomat_hip.so ABI version mismatch: the library at {p} is ABI {lib.comat_abi_version()}, "
+                           f"this package binds ABI {ABI_VERSION} - rebuild it (__graft_entry__.build())")
     lib.comat_last_error.restype = C.c_char_p
     lib.comat_build_id.restype = C.c_char_p
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, C.c_int)
-    if lib.comat_abi_version() != 5:
-        raise RuntimeError("libcomat_hip.so ABI version mismatch")
     _lib = lib
     return lib
 
@@ -356,6 +359,19 @@ class HipKernels:
             e.A, e.B, e.C, e.M, e.N, e.K, e.lda, e.ldb, e.ldc = _ptr(A), _ptr(B), _ptr(Cacc), M, N, K, lda, ldb, ldc
         ws = self._workspace(problems[0][0].device)
         _check(_lib.comat_gemm_tt_grouped(arr, n, BF16, ws.data_ptr(), self.WS_BYTES, _stream()), "comat_gemm_tt_grouped")
+
+    @staticmethod
+    def lora_merge_ok(W, U, Dt, r, ldu, lddt):
+        """what comat_lora_merge takes (include/comat_hip.h); anything else is merged by one comat_gemm per group"""
+        N, K = W.shape
+        return (W.dtype == torch.bfloat16 and U.dtype == torch.bfloat16 and Dt.dtype == torch.bfloat16 and W.is_contiguous()
+                and N % 8 == 0 and K % 8 == 0 and r % 16 == 0 and ldu % 8 == 0 and lddt % 8 == 0
+                and all(t.data_ptr() % 16 == 0 for t in (W, U, Dt)))
+
+    def lora_merge(self, problems, tiles, scale):
+        """problems: device int64 [n, 10], tiles: device int32 [n_tiles, 3] (include/comat_hip.h: comat_lora_merge)"""
+        assert problems.dtype == torch.int64 and problems.shape[1] == 10 and tiles.dtype == torch.int32 and tiles.shape[1] == 3
+        _check(_lib.comat_lora_merge(_ptr(problems), _ptr(tiles), tiles.shape[0], float(scale), _stream()), "comat_lora_merge")
 
     def transpose_cast_tiles(self, src, dst, tiles):
         assert src.dtype == torch.float32 and tiles.dtype == torch.int64 and tiles.shape[1] == 6

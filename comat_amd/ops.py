@@ -230,9 +230,9 @@ def set_tt_grouping(flag: bool):
 class _TTQueue:
     def __init__(self, dev, issuing, side):
         self.dev, self.issuing, self.side = dev, issuing, side
-        self.items, self.outs, self.keep = [], set(), []
+        self.items, self.outs, self.keep, self.pre = [], set(), [], []
 
-    def add(self, prob, keep):
+    def add(self, prob, keep, pre=None):
         # the byte range the problem accumulates into: [C, C + ((M - 1) ldc + N) * 4).  A problem whose output OVERLAPS one
         # the group already holds (the same factor at another denoise step, or any partially overlapping view) must not
         # share its launch: the two read-modify-write passes would race
@@ -243,18 +243,24 @@ class _TTQueue:
         self.items.append(prob)
         self.outs.add((lo, hi))
         self.keep.append(keep)
+        if pre is not None:
+            self.pre.append(pre)
 
     def flush(self):
         if not self.items:
             return
-        items, keep = self.items, self.keep
-        self.items, self.outs, self.keep = [], set(), []
+        items, keep, pre = self.items, self.keep, self.pre
+        self.items, self.outs, self.keep, self.pre = [], set(), [], []
         if self.side is None:
             with torch.cuda.stream(self.issuing):
+                for fn in pre:
+                    fn()
                 kernels().gemm_tt_grouped(items)
         else:
             self.side.wait_stream(self.issuing)  # every operand queued so far has been produced on the issuing stream
             with torch.cuda.stream(self.side):
+                for fn in pre:  # operands the problems read that nothing on the issuing stream needs (merged LoRA: h, u)
+                    fn()
                 kernels().gemm_tt_grouped(items)
             if not any(st is self.side for _, st in _side_dirty):
                 _side_dirty.append((self.dev, self.side))
@@ -266,14 +272,17 @@ class _HostQueue(_TTQueue):
 
     def flush(self):
         if self.items:
-            items = self.items
-            self.items, self.outs, self.keep = [], set(), []
+            items, pre = self.items, self.pre
+            self.items, self.outs, self.keep, self.pre = [], set(), [], []
+            for fn in pre:
+                fn()
             kernels().gemm_tt_grouped(items)
 
 
-def _tt_enqueue(dev, problems, keep):
+def _tt_enqueue(dev, problems, keep, pre=None):
     """queue weight-gradient problems [(A, B, C, M, N, K, lda, ldb, ldc)] of the backward pass running on the current
-    stream; `keep` = tensors that own the operands"""
+    stream; `keep` = tensors that own the operands; `pre` = a callable that produces operands only these problems read
+    (launched right in front of their group, on the stream the group runs on)"""
     if dev.type != "cuda":
         q = _ttq.get((dev, 0))
         if q is None:
@@ -286,8 +295,8 @@ def _tt_enqueue(dev, problems, keep):
             q = _ttq[key] = _TTQueue(dev, cur, None)
         if not q.items:
             q.side = _side_stream(dev)  # decided per group: side streams may be suspended for a forked D step
-    for pr in problems:
-        q.add(pr, keep)
+    for j, pr in enumerate(problems):
+        q.add(pr, keep, pre if j == 0 else None)
     _queue_join()
 
 
@@ -506,49 +515,124 @@ class LoRAStore:
             k.transpose_cast_tiles(self.flat, self.flat_t, self._tiles)
             self._fresh = True
             self.epoch = getattr(self, "epoch", 0) + 1  # consumers that cache products of the copies compare this
-            for ent in self._merged.values():  # merged inference weights that exist follow the parameters
-                self._merge_into(ent)
+            if self._merged:  # merged weights that exist follow the parameters
+                self._merge_entries()
 
     def mark_updated(self):
         """call after an in-place update of `flat` (optimizer kernel): the derived copies are refreshed lazily."""
         self._fresh = False
 
-    # ---- merged weights for no-grad calls (opt-in, see lora_group_linear) ------------------------------------------
+    # ---- merged weights W + s U D (see lora_group_linear / _LoRAMergedLinear) ---------------------------------------
     def merged_weights(self, grp, lins):
-        """[W_i + s * U_i D_i] in the compute dtype for the projections `lins` of group `grp`: persistent buffers (one
-        [G, N, K] allocation when the frozen weights are co-allocated), created at the first no-grad use and refreshed
-        in place whenever the compute copies are (i.e. once per optimizer step), so captured graphs can read them."""
+        """([W_i + s U_i D_i], [their transposes]) in the compute dtype for the projections `lins` of group `grp`: persistent
+        buffers (one [G, N, K] + one [G, K, N] allocation when the frozen weights are co-allocated), created at the first
+        use and refreshed in place whenever the compute copies are (once per optimizer step), so captured graphs can read
+        them.  Memory: a second and third copy of every LoRA'd attention weight (SD1.5: 2 x 186 MB per UNet)."""
         self.ensure_compute_copy()
         key = (grp.index, tuple(id(l) for l in lins))
         ent = self._merged.get(key)
         if ent is None:
+            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("merged LoRA weights must exist before a capture begins (run the call eagerly once)")
             G = len(lins)
             shp = tuple(lins[0].w.shape)
             if G > 1 and all(tuple(l.w.shape) == shp for l in lins):
-                buf = lins[0].w.new_empty((G,) + shp)
-                wm = list(buf.unbind(0))
+                wm = list(lins[0].w.new_empty((G,) + shp).unbind(0))
+                wmt = list(lins[0].w.new_empty((G, shp[1], shp[0])).unbind(0))
             else:
                 wm = [torch.empty_like(l.w) for l in lins]
-            ent = self._merged[key] = dict(grp=grp, lins=tuple(lins), wm=wm)
-            self._merge_into(ent)
-        return ent["wm"]
+                wmt = [torch.empty_like(l.wt) for l in lins]
+            ent = self._merged[key] = dict(grp=grp, lins=tuple(lins), wm=wm, wmt=wmt)
+            self._build_merge_table()
+            self._merge_entries([ent])
+        return ent["wm"], ent["wmt"]
+
+    def _entry_problems(self, ent):
+        """rows of comat_lora_merge's problem table for one entry, or None when the grouped kernel cannot take it"""
+        grp, lins = ent["grp"], ent["lins"]
+        _, ucs, dct, _ = self.group_views[grp.index]
+        r, Gr = grp.rank, grp.size * grp.rank
+        k = kernels()
+        if not hasattr(k, "lora_merge"):
+            return None
+        rows = []
+        for i, lin in enumerate(lins):
+            dt_i = dct[:, i * r:(i + 1) * r]
+            if not k.lora_merge_ok(lin.w, ucs[i], dt_i, r, r, Gr):
+                return None
+            N, Kd = lin.w.shape
+            rows.append((lin.w.data_ptr(), ucs[i].data_ptr(), dt_i.data_ptr(), ent["wm"][i].data_ptr(), ent["wmt"][i].data_ptr(),
+                         N, Kd, r, r, Gr))
+        return rows
+
+    def _build_merge_table(self):
+        """device tables of ONE comat_lora_merge launch over every merged entry the grouped kernel takes (rebuilt whenever
+        an entry is added - eagerly: the refresh inside a captured step only reads them)"""
+        import numpy as np
+        probs, tiles, rest = [], [], []
+        for ent in self._merged.values():
+            rows = self._entry_problems(ent)
+            if rows is None:
+                rest.append(ent)
+                continue
+            for row in rows:
+                pi, N, Kd = len(probs), row[5], row[6]
+                probs.append(row)
+                n0, k0 = np.meshgrid(np.arange(0, N, 64), np.arange(0, Kd, 64), indexing="ij")
+                tiles.append(np.stack([np.full(n0.size, pi), n0.reshape(-1), k0.reshape(-1)], 1))
+        self._merge_rest = rest
+        if probs:
+            self._merge_table = (torch.tensor(probs, dtype=torch.int64).to(self.device),
+                                 torch.from_numpy(np.concatenate(tiles).astype(np.int32)).to(self.device))
+        else:
+            self._merge_table = None
+
+    def _merge_entries(self, ents=None):
+        """refresh the merged weights: every entry (ents None: one grouped launch + the entries it cannot take) or just
+        `ents` (a new entry)"""
+        k = kernels()
+        if ents is None:
+            if getattr(self, "_merge_table", None) is not None:
+                k.lora_merge(self._merge_table[0], self._merge_table[1], self.groups[0].scale)
+            for ent in getattr(self, "_merge_rest", ()):
+                self._merge_into(ent)
+            return
+        for ent in ents:
+            rows = self._entry_problems(ent)
+            if rows is None or any(g.scale != self.groups[0].scale for g in (ent["grp"],)):
+                self._merge_into(ent)
+                continue
+            import numpy as np
+            tiles = []
+            for pi, row in enumerate(rows):
+                n0, k0 = np.meshgrid(np.arange(0, row[5], 64), np.arange(0, row[6], 64), indexing="ij")
+                tiles.append(np.stack([np.full(n0.size, pi), n0.reshape(-1), k0.reshape(-1)], 1))
+            k.lora_merge(torch.tensor(rows, dtype=torch.int64).to(self.device),
+                         torch.from_numpy(np.concatenate(tiles).astype(np.int32)).to(self.device), ent["grp"].scale)
 
     def _merge_into(self, ent):
-        grp, lins, wm = ent["grp"], ent["lins"], ent["wm"]
+        """one entry through comat_gemm (fp32 parity mode, shapes the grouped kernel does not take): Wm_i = W_i + s U_i D_i
+        and WmT_i = W_i^T + s D_i^T U_i^T, a batched launch each for a co-allocated group"""
+        grp, lins, wm, wmt = ent["grp"], ent["lins"], ent["wm"], ent["wmt"]
         _, ucs, dct, _ = self.group_views[grp.index]
         G, r = grp.size, grp.rank
         Gr = G * r
         k = kernels()
         N, Kd = lins[0].w.shape
         sw, su, sm = _uniform_stride([l.w for l in lins]), _uniform_stride(ucs), _uniform_stride(wm)
-        if G > 1 and sw is not None and su is not None and sm is not None:
+        swt, smt = _uniform_stride([l.wt for l in lins]), _uniform_stride(wmt)
+        if G > 1 and None not in (sw, su, sm, swt, smt):
             # Wm_i[N, K] = W_i + s * U_i[N, r] (D^T[K, G*r] columns i*r..)^T  for all i in one batched launch
             k.gemm(ucs[0], dct, wm[0], N, Kd, r, r, Gr, Kd, batch=(G, 1), sA=(su, 0), sB=(r, 0), sC=(sm, 0),
                    R=lins[0].w, ldr=Kd, sR=(sw, 0), alpha=grp.scale, beta=1.0)
+            k.gemm(dct, ucs[0], wmt[0], Kd, N, r, Gr, r, N, batch=(G, 1), sA=(r, 0), sB=(su, 0), sC=(smt, 0),
+                   R=lins[0].wt, ldr=N, sR=(swt, 0), alpha=grp.scale, beta=1.0)
         else:
             for i, lin in enumerate(lins):
                 N, Kd = lin.w.shape
                 k.gemm(ucs[i], dct[:, i * r:(i + 1) * r], wm[i], N, Kd, r, r, Gr, Kd, R=lin.w, ldr=Kd, alpha=grp.scale,
+                       beta=1.0)
+                k.gemm(dct[:, i * r:(i + 1) * r], ucs[i], wmt[i], Kd, N, r, Gr, r, N, R=lin.wt, ldr=N, alpha=grp.scale,
                        beta=1.0)
 
     def zero_grad(self):
@@ -1063,12 +1147,12 @@ class _LoRAGroupLinear(Function):
         return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
 
 
-def _merged_nograd_forward(x, lins, grp, residual):
-    """no-grad call with merged weights: y_i = x (W_i + s U_i D_i)^T + b_i (+ residual), one plain GEMM per projection
-    or one batched GEMM for a co-allocated group; no low-rank activations, no segments."""
+def _merged_forward(x, lins, grp, residual):
+    """y_i = x (W_i + s U_i D_i)^T + b_i (+ residual): one plain GEMM per projection or one batched GEMM for a co-allocated
+    group; no low-rank activations, no segments."""
     x = _c(x)
     M, Kd = x.shape
-    wm = grp.store.merged_weights(grp, lins)
+    wm, _ = grp.store.merged_weights(grp, lins)
     k = kernels()
     G = len(lins)
     sm = _uniform_stride(wm)
@@ -1088,10 +1172,111 @@ def _merged_nograd_forward(x, lins, grp, residual):
     return tuple(ys)
 
 
+# COMAT_TRAIN_MERGED (default 1, round 5): the TRAINED calls use the merged weights too.  0 = the low-rank form of rounds 1-4
+# (_LoRAGroupLinear: h = s x D^T on the dependent chain, then a K-segmented product).
+_train_merged = os.environ.get("COMAT_TRAIN_MERGED", "1") != "0"
+
+
+def set_train_merged(flag: bool):
+    global _train_merged
+    _train_merged = bool(flag)
+
+
+class _LoRAMergedLinear(Function):
+    """(y_1 .. y_G) with y_i = x W_eff,i^T + b_i (+ residual),  W_eff,i = W_i + s U_i D_i  (LoRAStore.merged_weights: both
+    orientations refreshed once per optimizer step) - the same function as _LoRAGroupLinear
+    (training_utils/pipeline.py:94-115), arranged so that nothing of the low-rank branch sits on the dependent chain:
+      forward   ONE plain (batched) GEMM;
+      backward  dx = sum_i g_i W_eff,i on the issuing stream (one K-segmented GEMM over the g_i, no u segment);
+                the factor gradients dU_i += g_i^T (s x D_i^T), d[D_1; ..] += (s g_i U_i)^T x need the two M x G r products
+                h and u - nobody else reads them, so they are launched with their weight-gradient group on the side stream."""
+
+    @staticmethod
+    def forward(ctx, x, residual, grp, lins, down_cat, *ups):
+        x = _c(x)
+        ys = _merged_forward(x, lins, grp, residual)
+        ctx.save_for_backward(x)
+        ctx.grp, ctx.lins = grp, lins
+        ctx.has_res = residual is not None
+        assert down_cat.grad is not None and all(u.grad is not None for u in ups), \
+            "LoRA factors need preallocated .grad views"
+        return ys
+
+    @staticmethod
+    def backward(ctx, *gs):
+        (x,) = ctx.saved_tensors
+        grp, lins = ctx.grp, ctx.lins
+        M, Kd = x.shape
+        G, r = grp.size, grp.rank
+        Gr = G * r
+        k = kernels()
+        gs = [_c(g) if g is not None else x.new_zeros((M, lin.out_features)) for g, lin in zip(gs, lins)]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, wmt = grp.store.merged_weights(grp, lins)
+            dx = x.new_empty((M, Kd))
+            if G == 1:
+                N = lins[0].out_features
+                k.gemm(gs[0], wmt[0], dx, M, Kd, N, N, N, Kd)
+            else:
+                k.gemm_segments([(gs[i], wmt[i], lin.out_features, lin.out_features, lin.out_features)
+                                 for i, lin in enumerate(lins)], dx, M, Kd, Kd)
+        want_down, want_ups = ctx.needs_input_grad[4], ctx.needs_input_grad[5:]
+        if want_down or any(want_ups):
+            dc, _, _, uts = grp.compute_copies()
+            h = x.new_empty((M, Gr)) if any(want_ups) else None
+            u = x.new_empty((M, Gr)) if want_down else None
+            N0 = lins[0].out_features
+            sg, su = _uniform_stride(gs), _uniform_stride(uts)
+
+            def low_rank():  # h = s x [D_1; ..]^T,  u_i = s g_i U_i (through U_i^T [r, N]: both operands k-contiguous)
+                if h is not None:
+                    k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
+                if u is None:
+                    return
+                if G > 1 and sg is not None and su is not None:
+                    k.gemm(gs[0], uts[0], u, M, r, N0, N0, N0, Gr, alpha=grp.scale, batch=(G, 1), sA=(sg, 0), sB=(su, 0),
+                           sC=(r, 0))
+                else:
+                    for i, lin in enumerate(lins):
+                        N = lin.out_features
+                        k.gemm(gs[i], uts[i], u[:, i * r:(i + 1) * r], M, r, N, N, N, Gr, alpha=grp.scale)
+
+            probs = []
+            for i, lin in enumerate(lins):
+                if want_ups[i]:
+                    probs.append((gs[i], h[:, i * r:(i + 1) * r], grp.ups[i].grad, lin.out_features, r, M,
+                                  lin.out_features, Gr, r))
+            if want_down:
+                probs.append((u, x, grp.down_cat.grad, Gr, Kd, M, Gr, Kd, Kd))
+            if _tt_grouping and all(k.tt_group_ok(*pr) for pr in probs):
+                _tt_enqueue(x.device, probs, (gs, h, u, x), pre=low_rank)
+            else:  # fp32 parity mode, odd shapes: one launch per gradient, still off the issuing stream
+
+                def weight_grads():
+                    low_rank()
+                    for A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc in probs:
+                        k.gemm(A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc, transA=True, transB=True, R=Cacc, ldr=ldc, beta=1.0)
+
+                side = _side_stream(x.device)
+                if side is None:
+                    weight_grads()
+                else:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        weight_grads()
+                    if not any(st is side for _, st in _side_dirty):
+                        _side_dirty.append((x.device, side))
+                    _side_keep.append((gs, h, u, x))  # keep the operands alive until join_side_streams()
+                    _queue_join()
+        return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
+
+
 def lora_group_linear(x, lins, grp: LoRAGroup | None, residual=None):
     """(x W_i^T + b_i + lora_i(x)) for the projections `lins` that share the input x; a tuple of len(lins).
-    COMAT_NOGRAD_MERGED (default 1 since round 4; 0 = the low-rank products as in the trained calls): calls under torch.no_grad()
-    — the untrained denoise steps — use merged weights W + s U D, refreshed once per optimizer step."""
+    Merged weights W + s U D (refreshed once per optimizer step) serve the no-grad calls (COMAT_NOGRAD_MERGED, default 1 since
+    round 4) and the trained calls (COMAT_TRAIN_MERGED, default 1 since round 5: _LoRAMergedLinear); 0 selects the low-rank
+    products of rounds 1-3 (_LoRAGroupLinear)."""
     if grp is None:
         assert residual is None or len(lins) == 1
         return tuple(linear(x, lin, residual) for lin in lins)
@@ -1101,8 +1286,13 @@ def lora_group_linear(x, lins, grp: LoRAGroup | None, residual=None):
     # and a no-grad UNet forward takes 6.74 instead of 7.32 ms.
     # (not under fp8_forward: there the frozen part runs on e4m3 weights quantised once - a merged weight would have to be
     # re-quantised after every optimizer step)
-    if not torch.is_grad_enabled() and not _fp8_on and os.environ.get("COMAT_NOGRAD_MERGED", "1") != "0":
-        return _merged_nograd_forward(x, tuple(lins), grp, residual)
+    if _fp8_on:
+        return _LoRAGroupLinear.apply(x, residual, grp, tuple(lins), grp.down_cat, *grp.ups)
+    if not torch.is_grad_enabled():
+        if os.environ.get("COMAT_NOGRAD_MERGED", "1") != "0":
+            return _merged_forward(x, tuple(lins), grp, residual)
+    elif _train_merged:
+        return _LoRAMergedLinear.apply(x, residual, grp, tuple(lins), grp.down_cat, *grp.ups)
     return _LoRAGroupLinear.apply(x, residual, grp, tuple(lins), grp.down_cat, *grp.ups)
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 5
+#define COMAT_ABI_VERSION 6
 
 enum { COMAT_F32 = 0, COMAT_BF16 = 1,
        COMAT_FP8_E4M3 = 2 /* OCP e4m3fn bytes; operand dtype of comat_gemm / comat_conv2d only (comat_fp8_quantize) */ };
@@ -272,6 +272,17 @@ int comat_sumpool2x2(const void* x, void* y, int32_t B, int32_t H, int32_t W, in
  * dst[dst_off + c*rows + r] = cast(src[src_off + r*cols + c]). */
 int comat_transpose_cast_tiles(const float* src, void* dst, const int64_t* tiles, int64_t n_tiles, int32_t out_dtype,
                                void* stream);
+/* Merged LoRA weights of MANY projections in ONE launch (ABI 6; once per optimizer step):
+ *     Wm_p[N, K] = bf16(W_p + scale * U_p[N, r] D_p[r, K]),     WmT_p[K, N] = Wm_p^T
+ * i.e. the weight of the function the reference's LoRA-wrapped Linear computes, y = W x + s * up(down(x))
+ * (training_utils/pipeline.py:94-115).  The trained and the no-grad calls of a step then run ONE plain GEMM per projection
+ * (forward on Wm, data-gradient on WmT) instead of a rank-r product in front of a K-segmented one.
+ *   problems: device int64 [n_problems, 10] = (W, U, Dt, Wm, WmT: device addresses; WmT may be 0), N, K, r, ldu, lddt:
+ *             W, Wm bf16 [N, K] contiguous; WmT bf16 [K, N] contiguous; U bf16 [N, r] with leading dimension ldu;
+ *             Dt = D^T bf16 [K, r] with leading dimension lddt.  N % 8 == K % 8 == 0, r % 16 == 0, ldu % 8 == lddt % 8 == 0,
+ *             every address 16-byte aligned.
+ *   tiles:    device int32 [n_tiles, 3] = (problem, n0, k0), one 64 x 64 output tile each (a launch may cover any subset). */
+int comat_lora_merge(const int64_t* problems, const int32_t* tiles, int64_t n_tiles, float scale, void* stream);
 /* NCHW <-> NHWC permutation of small boundary tensors (latents, images). to_nhwc != 0: [B,C,H,W] -> [B,H,W,C]. */
 int comat_permute_nchw_nhwc(const void* x, void* y, int32_t B, int32_t C, int32_t H, int32_t W, int32_t to_nhwc,
                             int32_t x_dtype, int32_t y_dtype, void* stream);

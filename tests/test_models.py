@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from comat_amd import config
+from comat_amd import config, ops
 from comat_amd.pipeline import DDPMScheduler, TrainableSDPipeline
 from comat_amd.unet import LoRABank, UNet, VAEDecoder, regroup_maps
 from helpers import check, oracle_cfgs, rel_l2, tiny_weights, tok, untok
@@ -45,7 +45,9 @@ def test_unet_forward_backward(dev, dtype):
     for k in mo:
         assert len(md[k]) == len(mo[k])
         for a, b in zip(md[k], mo[k]):
-            check(a, b, dtype, f"map {k}")
+            # bf16, worst single probability of the 8-token maps: 3.9e-2 with merged weights (round 5), 3.0e-2 in the low-rank
+            # form (eps: 1.7e-2 vs 1.9e-2) - rounding noise of one kind or the other, bounded at 1.5 x the 3e-2 of helpers.tol
+            check(a, b, dtype, f"map {k}", factor=1.0 if dtype == torch.float32 else 1.5)
     bank.zero_grad()
     ((e.float() * tok(g).to(dev)).sum() + (md["up_4"][1].float() * gmap.to(dev)).sum()).backward()
     check(e, tok(eo), dtype, "eps")
@@ -202,8 +204,9 @@ def test_gt_latent_producer(dev, dtype, tmp_path):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_nograd_merged_lora_weights_in_the_sampler(sim, dtype, monkeypatch):
-    """COMAT_NOGRAD_MERGED=1 changes only HOW the untrained denoise steps evaluate their LoRA projections (merged
-    weights): final latents, image and the LoRA gradients of the trained steps stay within rounding of the default."""
+    """COMAT_NOGRAD_MERGED / COMAT_TRAIN_MERGED change only HOW the untrained / the trained denoise steps evaluate their LoRA
+    projections (merged weights W + s U D instead of the low-rank products): final latents, image and the LoRA gradients of
+    the trained steps stay within rounding of the low-rank form."""
     usd, vsd, lsd = tiny_weights(dtype)
     bs, h, w, L = 1, 8, 8, 7
     cd = config.TINY_UNET.cross_attention_dim
@@ -212,21 +215,26 @@ def test_nograd_merged_lora_weights_in_the_sampler(sim, dtype, monkeypatch):
     noises = [rnd(bs, 4, h, w, seed=20 + i) for i in range(4)]
     gi = rnd(bs, 3, 8 * h, 8 * w, seed=30)
     res = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("COMAT_NOGRAD_MERGED", flag)
-        bank = LoRABank(config.TINY_UNET, lsd, dtype, sim)
-        pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, sim, bank),
-                                   VAEDecoder(config.TINY_VAE, vsd, dtype, sim))
-        img, latf = pipe.forward(cc, cu, height=8 * h, width=8 * w, training_timesteps=[2, 3], num_inference_steps=4,
-                                 guidance_scale=7.5, latents=lat, noises=noises, return_latents=True)
-        bank.zero_grad()
-        (img.float() * gi).sum().backward()
-        res.append((img.detach().float(), latf.detach().float(), bank.flat_grad.clone()))
-        assert bool(bank._merged) == (flag == "1")
+    try:
+        for flag, train in (("0", False), ("1", False), ("1", True)):
+            monkeypatch.setenv("COMAT_NOGRAD_MERGED", flag)
+            ops.set_train_merged(train)
+            bank = LoRABank(config.TINY_UNET, lsd, dtype, sim)
+            pipe = TrainableSDPipeline(UNet(config.TINY_UNET, usd, dtype, sim, bank),
+                                       VAEDecoder(config.TINY_VAE, vsd, dtype, sim))
+            img, latf = pipe.forward(cc, cu, height=8 * h, width=8 * w, training_timesteps=[2, 3], num_inference_steps=4,
+                                     guidance_scale=7.5, latents=lat, noises=noises, return_latents=True)
+            bank.zero_grad()
+            (img.float() * gi).sum().backward()
+            res.append((img.detach().float(), latf.detach().float(), bank.flat_grad.clone()))
+            assert bool(bank._merged) == (flag == "1")
+    finally:
+        ops.set_train_merged(os.environ.get("COMAT_TRAIN_MERGED", "1") != "0")
     f = 1.0 if dtype == torch.float32 else 4.0
-    check(res[1][0], res[0][0], dtype, "image", factor=f)
-    check(res[1][1], res[0][1], dtype, "latents", factor=f)
-    assert rel_l2(res[1][2], res[0][2]) < (1e-4 if dtype == torch.float32 else 0.15)
+    for other in res[1:]:
+        check(other[0], res[0][0], dtype, "image", factor=f)
+        check(other[1], res[0][1], dtype, "latents", factor=f)
+        assert rel_l2(other[2], res[0][2]) < (1e-4 if dtype == torch.float32 else 0.15)
 
 
 def test_vae_decoder_against_third_party_ldm_decoder(dev):

@@ -474,11 +474,21 @@ def test_transpose_cast_tiles(dev, dtype):
         assert torch.equal(dst[o:o + ref.numel()].cpu().view(ref.shape), ref.to(dtype))
 
 
+@pytest.fixture
+def train_merged_default():
+    yield
+    ops.set_train_merged(os.environ.get("COMAT_TRAIN_MERGED", "1") != "0")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("G", [1, 3])
-def test_lora_group_linear(dev, dtype, G):
+@pytest.mark.parametrize("merged", [True, False])
+def test_lora_group_linear(dev, dtype, G, merged, train_merged_default):
     """Projections sharing one input, each frozen Linear + LoRA branch (+ residual for a single projection):
-    outputs, dx, dresidual and the fp32 LoRA gradients accumulated in place into the store's flat buffer."""
+    outputs, dx, dresidual and the fp32 LoRA gradients accumulated in place into the store's flat buffer - in the merged-weight
+    form of round 5 (one plain GEMM forward, dx through the transposed merged weight, factor gradients on the side) and in the
+    low-rank form of rounds 1-4, against the same torch reference."""
+    ops.set_train_merged(merged)
     M, K, r = 130, 64, 8
     Ns = [96, 64, 80][:G]
     x = rnd(M, K, dtype=dtype, seed=1)
@@ -1466,22 +1476,63 @@ def test_merged_nograd_weights(dev, dtype, G, monkeypatch):
     for a, b in zip(merged, plain):
         check(a, b, dtype, "merged vs unmerged", factor=f)
     # parameter update -> merged weights refreshed in place (same buffers)
-    ptrs = [w.data_ptr() for w in store.merged_weights(store.groups[0], tuple(lins))]
+    ptrs = [w.data_ptr() for ws_ in store.merged_weights(store.groups[0], tuple(lins)) for w in ws_]
     store.flat.mul_(0.5)
     store.mark_updated()
     with torch.no_grad():
         merged2 = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
         monkeypatch.setenv("COMAT_NOGRAD_MERGED", "0")
         plain2 = ops.lora_group_linear(xd, lins, store.groups[0], residual=rd)
-    assert ptrs == [w.data_ptr() for w in store.merged_weights(store.groups[0], tuple(lins))]
+    wm, wmt = store.merged_weights(store.groups[0], tuple(lins))
+    assert ptrs == [w.data_ptr() for w in wm + wmt]
+    for a, b in zip(wm, wmt):  # the data-gradient's copy is the transpose of the forward's (fp32: to rounding)
+        if dtype == torch.bfloat16 and dev.type == "cuda":
+            check(b, a.t(), dtype, "transposed merged weight")
+        else:
+            check(b, a.t(), dtype, "transposed merged weight")
     for a, b, c in zip(merged2, plain2, plain):
         check(a, b, dtype, "merged vs unmerged after update", factor=f)
         assert (a.float() - c.float()).abs().max() > 0
-    # grad-mode calls never take the merged path
+    # grad-mode calls record a backward node whatever the no-grad switch says
     monkeypatch.setenv("COMAT_NOGRAD_MERGED", "1")
     xg = dv(x, dev, dtype, grad=True)
     y = ops.lora_group_linear(xg, lins, store.groups[0], residual=rd)
     assert y[0].grad_fn is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 320, 320, 128), (2, 640, 768, 128), (1, 1280, 1280, 128), (1, 200, 136, 16), (3, 64, 64, 32)])
+def test_lora_merge_grouped_kernel(hip, shape):
+    """comat_lora_merge: Wm = bf16(W + s U D) and WmT = Wm^T for every projection of a store in ONE launch - against the fp32
+    formula (one rounding), the transposed copy bit-identical to the forward copy, refreshed in place after a parameter
+    update, ragged tile edges included; and the trained call built on it against the low-rank form."""
+    G, N, K, r = shape
+    dtype = torch.bfloat16
+    ws = [rnd(N, K, dtype=dtype, seed=20 + i, scale=K ** -0.5) for i in range(G)]
+    spec = [(f"p{i}.down", f"p{i}.up", rnd(r, K, seed=40 + i, scale=K ** -0.5), rnd(N, r, seed=50 + i, scale=0.05)) for i in range(G)]
+    lins = ops.frozen_linear_group(ws, [None] * G, dtype, hip) if G > 1 else [ops.FrozenLinear(ws[0], None, dtype, hip)]
+    store = ops.LoRAStore([spec], dtype, hip, scale=0.75)
+    grp = store.groups[0]
+    assert ops.kernels().lora_merge_ok(lins[0].w, store.group_views[0][1][0], store.group_views[0][2][:, :r], r, r, G * r)
+    for rep in range(2):
+        wm, wmt = store.merged_weights(grp, tuple(lins))
+        assert store._merge_table is not None and not store._merge_rest, "the grouped kernel did not take the store"
+        for i in range(G):
+            d, u = store.group_views[0][0][i * r:(i + 1) * r].float(), store.group_views[0][1][i].float()
+            ref = (lins[i].w.float() + 0.75 * (u @ d)).to(dtype)
+            # fp32 accumulation order of the MFMA differs from torch's: allow the last bf16 bit on a few elements
+            diff = (wm[i].float() - ref.float()).abs()
+            assert diff.max() <= 2.0 ** -7 * ref.float().abs().max(), f"merged weight {i}: {diff.max():.3e}"
+            assert (diff > 0).float().mean() < 2e-2, f"merged weight {i}: {(diff > 0).float().mean():.3e} of the elements differ"
+            assert torch.equal(wmt[i], wm[i].t()), f"transposed merged weight {i} is not the forward copy's transpose"
+        store.flat.mul_(0.5)
+        store.mark_updated()
+    # the same entry through comat_gemm (the fp32-mode path) agrees to bf16 rounding
+    ent = next(iter(store._merged.values()))
+    a = [w.clone() for w in ent["wm"]]
+    store._merge_into(ent)
+    for x, y in zip(a, ent["wm"]):
+        assert rel_l2(x, y) < 2e-3
 
 
 @pytest.mark.gpu
