@@ -724,10 +724,35 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     }
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
-    COMAT_REQUIRE(p->epi2 == 0 || rc2 > 0,
-                  "comat_gemm: the GEGLU epilogue needs a problem the pipelined kernel takes (bf16 / fp8 k-contiguous operands, M >= 16, "
-                  "bf16 output, N %% 32 == 0, 16-byte aligned rows, no residual / bias2 / activation / batch)");
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
+    if (p->epi2 != 0) {
+        // The pipelined kernel declined (option gemm2 = 0, or a shape it does not take): the GEGLU epilogue is a fast path, not
+        // a different function - compute the same thing as two launches: the plain product into C (epi2 == 2: into
+        // the tail of the caller's workspace, unsplit), then the interleaved-layout GEGLU kernel into C2.
+        COMAT_REQUIRE(p->in_dtype == COMAT_BF16 && p->out_dtype == COMAT_BF16 && p->N % 32 == 0 && p->batch1 * p->batch2 == 1 &&
+                          !p->R && !p->bias2 && p->act == COMAT_ACT_NONE && p->ldc2 == p->N / 2,
+                      "comat_gemm: the GEGLU epilogue needs bf16 operands and output, N %% 32 == 0, ldc2 == N / 2, no residual / bias2 / "
+                      "activation / batch");
+        comat_gemm_params q = *p;
+        q.epi2 = 0;
+        q.C2 = nullptr;
+        if (p->epi2 == 2 || p->ldc != p->N) {
+            const int64_t need = p->M * p->N * 2;
+            COMAT_REQUIRE(p->ws && p->ws_bytes >= COMAT_WS_COUNTER_BYTES + need,
+                          "comat_gemm: the two-launch form of the GEGLU epilogue needs M * N * 2 bytes of workspace behind the counters");
+            q.C = (char*)p->ws + COMAT_WS_COUNTER_BYTES;
+            q.ldc = p->N;
+            q.ws = nullptr;  // the scratch lives where split-K slabs would: run unsplit
+            q.ws_bytes = 0;
+        }
+        const int rc = comat_gemm(&q, stream);
+        if (rc) return rc;
+        if (p->epi2 == 1 && q.C != p->C) {  // (pre-activations wanted in a strided C: not a shape the step has)
+            comat_set_error("comat_gemm: epi2 == 1 needs ldc == N outside the pipelined kernel");
+            return COMAT_EUNSUPPORTED;
+        }
+        return comat_geglu_il_fwd(q.C, p->C2, p->M, (int32_t)(p->N / 2), COMAT_BF16, stream);
+    }
     COMAT_REQUIRE(p->in_dtype != COMAT_FP8_E4M3,
                   "comat_gemm: fp8 operands need transA = transB = 0, K %% 64 == 0, 16-byte aligned rows, batch2 == 1");
     GemmArgs g;

@@ -52,10 +52,13 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
-    {"norm_fused", "COMAT_NORM_FUSED", 3, 0, false},      // GroupNorm: 3 = ONE launch wherever a (sample, group) fits a
-                                                          // workgroup's registers (every UNet level), 0 = always the
-                                                          // three-launch form, 1 / 2 = two launches (statistics finalised
-                                                          // by the last-arriving block / by the apply kernel's prologue)
+    {"norm_fused", "COMAT_NORM_FUSED", 4, 0, false},      // GroupNorm: 4 (default, round 5) = ONE launch everywhere it can be:
+                                                          // a workgroup per (sample, group) where that fits its registers
+                                                          // (HW <= 256), else the cooperative form (<= #CU resident blocks keep
+                                                          // their rows in registers and meet at a grid barrier: norm.hip);
+                                                          // 3 = the round-3 policy (one launch for HW <= 256, else three),
+                                                          // 0 = always the three-launch form, 1 / 2 = two launches (statistics
+                                                          // finalised by the last-arriving block / by the apply kernel)
     {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
                                                           // kernel with hardware transpose reads
     {"flash_kt", "COMAT_FLASH_KT", 4, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,

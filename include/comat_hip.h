@@ -80,7 +80,8 @@ typedef struct {
      * need transA == transB == 0, K % 64 == 0, lda/ldb % 16 == 0; anything else is COMAT_EINVAL (no silent fallback). */
     const float* scale_a;
     const float* scale_b;
-    /* Second epilogue (ABI 5; comat_gemm only, problems the pipelined kernel takes - else COMAT_EINVAL):
+    /* Second epilogue (ABI 5; comat_gemm only; ONE launch for the problems the pipelined kernel takes, else the plain product
+     * followed by comat_geglu_il_fwd - epi2 = 2 then needs M * N * 2 bytes of `ws` behind the counters - the same function):
      *   epi2 = 1 / 2: GEGLU.  The N = 2 D output columns hold value and gate channels INTERLEAVED in sixteens (columns
      *   32 t .. 32 t + 15 = value channels 16 t .., columns 32 t + 16 .. 32 t + 31 = their gate channels: the caller permutes
      *   the rows of B and the bias once); C2 [M, D] (leading dimension ldc2) receives value * gelu(gate), both rounded to bf16

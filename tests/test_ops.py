@@ -190,7 +190,10 @@ def test_groupnorm(dev, dtype, silu, shape):
                                    (2, 1024, 640, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), (2, 256, 2560, 32),
                                    (3, 77, 24, 8)])
 def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
-    """option norm_fused: 3 (default) = ONE launch, a workgroup per (sample, group) holding the group in registers (the
+    """option norm_fused: 4 (default since round 5) = 3 + the cooperative one-launch form (<= #CU resident blocks, rows in
+    registers, a grid barrier between the statistics and the normalisation) for what does not fit a workgroup - the 64^2 / 32^2
+    levels here, both register variants, ragged row blocks (HW = 130);
+    3 = ONE launch, a workgroup per (sample, group) holding the group in registers (the
     shapes cover its three register variants, forward and backward capacity limits - beyond them the call takes the
     three-launch form - and a group with an odd channel count); 1 = the last-arriving statistics block finalises, 2 = the
     prologue of the apply kernel does.  Same statistics up to the summation order of the partial sums: outputs and
@@ -206,8 +209,8 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
     xr.grad += gy2.reshape(B_, HW, C)
     res = []
     vec_ok = C % (4 if dtype == torch.float32 else 8) == 0  # what the multi-launch forms need (else: one launch or an error)
-    for mode in (0, 1, 2, 3, 3):
-        if mode != 3 and not vec_ok:
+    for mode in (0, 1, 2, 3, 3, 4, 4):
+        if mode not in (3, 4) and not vec_ok:
             res.append(None)
             continue
         _set_opts(norm_fused=mode)
@@ -218,12 +221,13 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
         check(y, yr, dtype, f"gn fwd (norm_fused={mode})")
         check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, f"gn bwd (norm_fused={mode})", factor=2)
     lim = 2e-6 if dtype == torch.float32 else 1e-2  # bf16: an output may flip by one ulp
-    for mode in (1, 2, 3):
+    for mode, idx in ((1, 1), (2, 2), (3, 3), (4, 5)):
         if res[0] is None:
             continue
-        for a, b_, name in zip(res[0], res[mode], ("y", "dx")):
+        for a, b_, name in zip(res[0], res[idx], ("y", "dx")):
             assert rel_l2(b_, a) < lim, f"norm_fused={mode}: {name} differs from the three-launch form by {rel_l2(b_, a):.2e}"
     assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])  # run-to-run bit-identical
+    assert torch.equal(res[5][0], res[6][0]) and torch.equal(res[5][1], res[6][1])  # the cooperative form too
 
 
 @pytest.mark.gpu
@@ -793,7 +797,7 @@ def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
     _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=DEFAULT_OPTS['flash_xcd'],
-              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
+              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=4, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
               gemm2_chain=DEFAULT_OPTS['gemm2_chain'], flash_ks=DEFAULT_OPTS['flash_ks'])
 
 
@@ -1126,6 +1130,32 @@ def test_geglu_linear(dev, dtype, shape):
     finally:
         ops.set_geglu_fused(True)
     assert torch.equal(y3, y) and torch.equal(xs.grad, xd.grad), "fused and two-launch GEGLU differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(300, 320, 1280), (2048, 640, 2560)])
+def test_geglu_linear_without_the_pipelined_kernel(hip, shape, default_opts):
+    """with option gemm2 = 0 (every contraction on the general kernel) the GEGLU epilogue of comat_gemm is not
+    available - the library then runs the product and the interleaved-layout GEGLU kernel as two launches (the no-grad form,
+    which has no buffer for the pre-activations, through its workspace) instead of refusing: same bits as the fused call."""
+    dtype = torch.bfloat16
+    M, K, D = shape
+    w, b = rnd(2 * D, K, dtype=dtype, seed=1, scale=K ** -0.5), rnd(2 * D, seed=2)
+    lin = ops.FrozenGegluLinear(w, b, dtype, hip)
+    x, go = rnd(M, K, dtype=dtype, seed=3), rnd(M, D, dtype=dtype, seed=4)
+    res = []
+    for g2 in (1, 0):
+        _set_opts(gemm2=g2, gemm3=0)
+        xd = dv(x, hip, dtype, grad=True)
+        y = ops.geglu_linear(xd, lin)
+        y.backward(dv(go, hip, dtype))
+        with torch.no_grad():
+            y2 = ops.geglu_linear(dv(x, hip, dtype), lin)
+        res.append((y.detach(), xd.grad, y2))
+    # the general kernel accumulates in another order: equal up to bf16 rounding of the pre-activations
+    for a, b_, name in zip(res[0], res[1], ("output", "input gradient", "no-grad output")):
+        assert rel_l2(b_, a) < 1e-2, f"{name}: {rel_l2(b_, a):.2e}"
+    assert torch.equal(res[1][0], res[1][2]), "gemm2 = 0: no-grad call differs from the grad-mode call"
 
 
 G3_CFGS = [1, 2, 3, 4, 5, 6, 7, 8, 9]
