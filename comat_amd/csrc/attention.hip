@@ -138,15 +138,13 @@ template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsr
 }
 
 // cooperative [32 rows x d] tile copy global -> registers -> LDS (zero padded to DMAX columns / missing rows)
-// GROUPED: the NT threads that move a tile are one of several groups of a larger block (split-key forward): `tid` is the
-// thread's index inside its group; otherwise it is threadIdx.x and the member is never touched
-template <typename T, int DMAX, bool GROUPED = false> struct TileMover {
+template <typename T, int DMAX> struct TileMover {
     typedef Geo<T, DMAX> G;
     uint4 regs[G::NCHK];
     __device__ __forceinline__ void load(const T* base, int64_t ld, int row0, int nrows, int d) {
 #pragma unroll
         for (int i = 0; i < G::NCHK; ++i) {
-            const int c = me() + i * NT;
+            const int c = threadIdx.x + i * NT;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (c < 32 * G::CPRW) {
                 const int rr = c / G::CPRW, col = (c % G::CPRW) * G::KC;
@@ -162,15 +160,10 @@ template <typename T, int DMAX, bool GROUPED = false> struct TileMover {
     // instruction, no 64-bit pointer arithmetic, no compare / select / re-zero, no divergent region (they were ~20 of the
     // ~150 VALU instructions of a 64-key forward iteration, and four exec-mask branches).
     unsigned voff[G::NCHK];
-    unsigned tid;
-    __device__ __forceinline__ unsigned me() const {
-        if constexpr (GROUPED) return tid;
-        else return threadIdx.x;
-    }
     __device__ __forceinline__ void prepare(int64_t ld, int d) {
 #pragma unroll
         for (int i = 0; i < G::NCHK; ++i) {
-            const int c = me() + i * NT;
+            const int c = threadIdx.x + i * NT;
             const int rr = c / G::CPRW, col = (c % G::CPRW) * G::KC;
             voff[i] = (c < 32 * G::CPRW && col < d) ? (unsigned)((rr * ld + col) * (int64_t)sizeof(T)) : 0x80000000u;
         }
@@ -185,7 +178,7 @@ template <typename T, int DMAX, bool GROUPED = false> struct TileMover {
     __device__ __forceinline__ void store(char* lds) const {
 #pragma unroll
         for (int i = 0; i < G::NCHK; ++i) {
-            const int c = me() + i * NT;
+            const int c = threadIdx.x + i * NT;
             if (c < 32 * G::CPRW) *(uint4*)(lds + (c / G::CPRW) * G::RS + (c % G::CPRW) * 16) = regs[i];
         }
     }
@@ -193,7 +186,7 @@ template <typename T, int DMAX, bool GROUPED = false> struct TileMover {
     __device__ __forceinline__ void store_t(char* ldsT) const {
 #pragma unroll
         for (int i = 0; i < G::NCHK; ++i) {
-            const int c = me() + i * NT;
+            const int c = threadIdx.x + i * NT;
             if (c < 32 * G::CPRW) {
                 const int rr = c / G::CPRW, col0 = (c % G::CPRW) * G::KC;
                 V16 v;
@@ -614,197 +607,6 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2, false) void flash_fwd2_kerne
             }
         if (hh == 0) a.lse[((int64_t)by) * a.Nq + q] = m * a.scale + __logf(l);
     }
-}
-
-// The 2-tile forward with an IN-BLOCK KEY SPLIT (option flash_ks; a copy of flash_fwd2_kernel's loop - kept apart so that
-// the kernel the step runs today stays byte-identical while this one is being measured).  The block has 2 x 4 waves; both
-// groups own the same 128 queries, group g walks key pairs [g * ceil(npairs / 2), ...) through its own double-buffered LDS
-// ring, and the two partial results (running maximum, denominator, accumulator) are merged through LDS in fixed order
-// (group 0 <- group 1).  What it buys is waves: the
-// step's 2 x 8 x 4096^2 forward is 512 blocks, two per CU, two waves per SIMD - a latency chain covered by a third
-// (profiles/r04_q_flash_occupancy.txt: 50.9 us per batch entry at two waves per SIMD, 41.7 at four).  The kernel holds <= 128
-// registers for head dims <= 64, so two 8-wave blocks fit a CU (LDS 2 x 74 KB).
-template <int DMAX, int NK>
-__device__ __forceinline__ void flash_fwd2s_body(const FlashArgs& a, char* smem_all) {
-    typedef bf16_t T;
-    typedef Geo<T, DMAX> G;
-    typedef short8_t F;
-    constexpr int KS = 2;  // key groups
-    constexpr int ONE = 2 * G::TILE_BYTES;  // [K tile | V tile] of one 32-key tile
-    constexpr int PAIR = 2 * ONE;
-    const int grp = (int)(threadIdx.x / NT), tid = (int)(threadIdx.x % NT);
-    char* smem = smem_all + grp * 2 * PAIR;
-    int bx, by;
-    flash_block_xy(a.xcd, bx, by);
-    char* cur = smem;
-    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int b = by / a.H, h = by % a.H;
-    const T* Qb = (const T*)a.Q + (int64_t)b * a.Nq * a.ldq + h * a.d;
-    const T* Kb = (const T*)a.K + (int64_t)b * a.Nk * a.ldk + h * a.d;
-    const T* Vb = (const T*)a.V + (int64_t)b * a.Nk * a.ldv + h * a.d;
-    T* Ob = (T*)a.Out + (int64_t)b * a.Nq * a.ldo + h * a.d;
-    const int q = bx * 128 + wave * 32 + r;
-    F qf[NK];
-    load_col_frags<T, DMAX, NK>(qf, Qb, a.ldq, q, a.Nq, a.d, hh);
-    f32x16_t oT[G::NT32];
-#pragma unroll
-    for (int t = 0; t < G::NT32; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oT[t][i] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const float c2 = a.scale * LOG2E;
-    TileMover<T, DMAX, true> km0, vm0, km1, vm1;
-    km0.tid = vm0.tid = km1.tid = vm1.tid = tid;
-    const int npairs_all = (a.Nk + 63) / 64;
-    // this group's pairs [p0, p0 + npairs); every group runs `nloop` iterations (the block barrier is shared)
-    const int nloop = (npairs_all + KS - 1) / KS, p0 = grp * nloop;
-    const int npairs = npairs_all - p0 < nloop ? (npairs_all - p0 > 0 ? npairs_all - p0 : 0) : nloop;
-    const __amdgpu_buffer_rsrc_t k_slab = slab_rsrc(Kb, a.Nk, a.ldk, a.d), v_slab = slab_rsrc(Vb, a.Nk, a.ldv, a.d);
-    km0.prepare(a.ldk, a.d);
-    vm0.prepare(a.ldv, a.d);
-    km1.prepare(a.ldk, a.d);
-    vm1.prepare(a.ldv, a.d);
-    auto load_pair = [&](int pl) {
-        const int p = p0 + pl;
-        if (COMAT_FLASH_FULL_TILES && (p + 1) * 64 <= a.Nk) {
-            const unsigned ko = (unsigned)(p * 64 * a.ldk * (int64_t)sizeof(T)), vo = (unsigned)(p * 64 * a.ldv * (int64_t)sizeof(T));
-            km0.load_full(k_slab, ko);
-            vm0.load_full(v_slab, vo);
-            km1.load_full(k_slab, ko + (unsigned)(32 * a.ldk * (int64_t)sizeof(T)));
-            vm1.load_full(v_slab, vo + (unsigned)(32 * a.ldv * (int64_t)sizeof(T)));
-            return;
-        }
-        // rows beyond Nk come back as zeros (TileMover), their scores are masked below
-        km0.load(Kb, a.ldk, p * 64, a.Nk, a.d);
-        vm0.load(Vb, a.ldv, p * 64, a.Nk, a.d);
-        km1.load(Kb, a.ldk, p * 64 + 32, a.Nk, a.d);
-        vm1.load(Vb, a.ldv, p * 64 + 32, a.Nk, a.d);
-    };
-    auto store_pair = [&](char* dst) {
-        km0.store(dst);
-        vm0.store(dst + G::TILE_BYTES);
-        km1.store(dst + ONE);
-        vm1.store(dst + ONE + G::TILE_BYTES);
-    };
-    if (npairs > 0) {
-        load_pair(0);
-        store_pair(cur);
-    }
-    loads_landed();
-    __syncthreads();
-    const unsigned tr_off = tr_lane_off<G::RS>(lane);
-    for (int it = 0; it < nloop; ++it) {
-        if (it >= npairs) {  // this group has run out of pairs (odd pair count): the other one still needs the barrier
-            __syncthreads();
-            continue;
-        }
-        const int p = p0 + it;  // the pair's index among all keys (masks below); `it`: its index in this group's ring
-        const bool more = it + 1 < npairs;
-        if (more) load_pair(it + 1);
-        f32x16_t s0, s1;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < NK; ++s) {
-            mma(s0, frag_kc<T, DMAX>(cur, r, s, hh), qf[s]);
-            mma(s1, frag_kc<T, DMAX>(cur + ONE, r, s, hh), qf[s]);
-        }
-        if ((p + 1) * 64 > a.Nk) {  // keys beyond Nk exist only in the last pair
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (p * 64 + crow(i, hh) >= a.Nk) s0[i] = -INFINITY;
-                if (p * 64 + 32 + crow(i, hh) >= a.Nk) s1[i] = -INFINITY;
-            }
-        }
-        float mt = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int i = 1; i < 16; ++i) mt = fmaxf(fmaxf(mt, s0[i]), s1[i]);  // one v_max3_f32 each (max is exact: any order)
-        mt = half_max(mt);
-        const float m_new = fmaxf(m, mt);
-        const float neg = -m_new * c2;
-        const f32x2_t c2v = splat2(c2), negv = splat2(neg);
-        float ps = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const f32x2_t p0 = exp2_fast2(__builtin_elementwise_fma(pair_of(s0, i), c2v, negv));
-            const f32x2_t p1 = exp2_fast2(__builtin_elementwise_fma(pair_of(s1, i), c2v, negv));
-            s0[i] = p0.x; s0[i + 1] = p0.y;
-            s1[i] = p1.x; s1[i + 1] = p1.y;
-            const f32x2_t t = p0 + p1;  // the pair sums of rows i, i + 1; added to the running sum in row order, as before
-            ps += t.x;
-            ps += t.y;
-        }
-        ps = half_sum(ps);
-        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {
-            const float alpha = exp2_fast((m - m_new) * c2);
-            l *= alpha;
-#pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oT[t2][i] *= alpha;
-        }
-        l += ps;
-        m = m_new;
-        const unsigned va0 = lds_addr32(cur + G::TILE_BYTES) + tr_off, va1 = lds_addr32(cur + ONE + G::TILE_BYTES) + tr_off;
-        auto step = [&](auto jc, unsigned va, const f32x16_t& st) {
-            constexpr int j = decltype(jc)::value;
-            TrF vf[G::NT32];
-            tr_issue_j<G::RS, j>(va, vf, std::make_integer_sequence<int, G::NT32>{});
-            const F pb = pack_acc<T>(st, j);
-#pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2) mma(oT[t2], tr_take(vf[t2]), pb);
-        };
-        step(std::integral_constant<int, 0>{}, va0, s0);
-        step(std::integral_constant<int, 1>{}, va0, s0);
-        step(std::integral_constant<int, 0>{}, va1, s1);
-        step(std::integral_constant<int, 1>{}, va1, s1);
-        cur = smem + ((it + 1) & 1) * PAIR;  // last read in iteration it-1, which every wave left through the barrier below
-        if (more) store_pair(cur);
-        __syncthreads();
-    }
-    {
-        // merge group 1 into group 0, in that fixed order, through LDS (every tile read is behind the loop's last barrier):
-        // [2 + 16 NT32][NT] floats, one column per thread - thread `tid` of both groups owns the same query column
-        float* xch = (float*)smem_all;
-        if (grp == 1) {
-            xch[tid] = m;
-            xch[NT + tid] = l;
-#pragma unroll
-            for (int t2 = 0; t2 < G::NT32; ++t2)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) xch[(2 + t2 * 16 + i) * NT + tid] = oT[t2][i];
-        }
-        __syncthreads();
-        if (grp == 1) return;
-        const float m1 = xch[tid], l1 = xch[NT + tid];
-        const float m_all = fmaxf(m, m1);  // group 0 always holds a valid key: finite
-        const float a0 = exp2_fast((m - m_all) * c2), a1 = exp2_fast((m1 - m_all) * c2);  // a1 = 0 for an empty group 1
-        l = l * a0 + l1 * a1;
-#pragma unroll
-        for (int t2 = 0; t2 < G::NT32; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oT[t2][i] = oT[t2][i] * a0 + xch[(2 + t2 * 16 + i) * NT + tid] * a1;
-        m = m_all;
-    }
-    if (q < a.Nq) {
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int t2 = 0; t2 < G::NT32; ++t2)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = t2 * 32 + crow(i, hh);
-                if (n < a.d) stf<T>(Ob + (int64_t)q * a.ldo + n, oT[t2][i] * inv);
-            }
-        if (hh == 0) a.lse[((int64_t)by) * a.Nq + q] = m * a.scale + __logf(l);
-    }
-}
-
-// two key groups of four waves each; 4 x PAIR of LDS (dynamic: beyond the static limit), <= 128 registers so that two such
-// blocks share a CU (four waves per SIMD)
-template <int DMAX, int NK>
-__global__ __launch_bounds__(2 * NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void flash_fwd2s_kernel(FlashArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-    flash_fwd2s_body<DMAX, NK>(a, smem_dyn);
 }
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
@@ -1524,23 +1326,7 @@ template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
 void launch_fwd(const FlashArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) == 2 && TR && 8 * Geo<T, DMAX>::TILE_BYTES <= 65536) {
         if (comat_option(COMAT_OPT_FLASH_KT) >= 2 && a.Nk > 64) {  // two key tiles per iteration
-            const dim3 grid((a.Nq + 127) / 128, a.B * a.H);
-            if constexpr (DMAX <= 64) {  // in-block key split (option flash_ks): twice the waves where the grid is small
-                const int ks = comat_option(COMAT_OPT_FLASH_KS);
-                const int64_t blocks = (int64_t)grid.x * grid.y;
-                if (ks >= 2 || (ks == 1 && blocks <= 768 && a.Nk >= 256)) {
-                    constexpr int lds = 16 * Geo<T, DMAX>::TILE_BYTES;  // two groups x two buffers x [K | V] x two tiles
-                    static int sized = 0;  // 0 not tried, 1 granted, -1 refused (a benign race: every caller writes the same value)
-                    if (sized == 0)
-                        sized = hipFuncSetAttribute((const void*)flash_fwd2s_kernel<DMAX, NK>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess ? 1 : -1;
-                    if (sized > 0) {
-                        hipLaunchKernelGGL((flash_fwd2s_kernel<DMAX, NK>), grid, dim3(2 * NT), lds, st, a);
-                        return;
-                    }
-                }
-            }
-            hipLaunchKernelGGL((flash_fwd2_kernel<DMAX, NK>), grid, dim3(NT), 0, st, a);
+            hipLaunchKernelGGL((flash_fwd2_kernel<DMAX, NK>), dim3((a.Nq + 127) / 128, a.B * a.H), dim3(NT), 0, st, a);
             return;
         }
     }

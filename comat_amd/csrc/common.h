@@ -78,7 +78,7 @@ int comat_check_launch(const char* what);
 enum { COMAT_OPT_FLASH_TRIM = 0, COMAT_OPT_FLASH_TR, COMAT_OPT_GEMM2, COMAT_OPT_G2_CFG, COMAT_OPT_G2_SPLITS,
        COMAT_OPT_FORCE_SPLITS, COMAT_OPT_NORM_FUSED, COMAT_OPT_GEMM2_TT, COMAT_OPT_FLASH_KT, COMAT_OPT_FLASH_MERGE,
        COMAT_OPT_G2_ORDER, COMAT_OPT_FLASH_XCD, COMAT_OPT_GEMM3, COMAT_OPT_G3_CFG, COMAT_OPT_GEMM3_CHAIN, COMAT_OPT_GEMM2_CHAIN,
-       COMAT_OPT_FLASH_KS, COMAT_N_OPTIONS };
+       COMAT_N_OPTIONS };
 int comat_option(int id);
 // which kernel family served the calling thread's last comat_gemm / comat_gemm_segments / comat_conv2d call
 // (comat_last_gemm_kernel() in the ABI): 0 general 64x64, 1 pipelined, 2 pipelined k-major, 3 pipelined fp8, 4 grouped k-major,

@@ -227,7 +227,7 @@ static bool gn_try_one(const void* x, const void* dy, const float* gamma, const 
     // The backward form holds two tensors per thread and gains less: 16x16 x 1 280 channels 13.8 -> 16.6 us (a loss), x 2 560
     // 21.4 -> 14.4 us, 8x8 13.5 -> 7.4 us - it serves HW <= 64, and HW <= 256 from 1 920 channels on.
     const bool pays = MODE == 0 ? HW <= 256 : (HW <= 64 || (HW <= 256 && C >= 1920));
-    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) < 3 || !pays)) return false;
+    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) != 3 || !pays)) return false;
     const int cpg = C / G;
     if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
     if (dtype == COMAT_F32) {
@@ -543,7 +543,7 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
 
 // workspace: [GN_TICKETS uint32 ticket counters (zeroed once by the caller, re-armed by the kernels) | doubles]
 constexpr int GN_TICKETS = 1024;
-static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) == 1 && B <= GN_TICKETS - 2; }  // (the last two words: gn_grid_barrier)
+static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) == 1 && B <= GN_TICKETS; }
 // norm_fused = 2: the apply kernel finalises (gn_vapply2_kernel<.., FIN>); needs whole waves of 8-lane groups
 static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_FUSED) == 2 && G % 8 == 0 && G <= 32; }
 
@@ -608,291 +608,6 @@ static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int
     const int R = vpr >= NT ? 1 : NT / (vpr > 0 ? vpr : 1);
     return (C % epv) == 0 && vpr <= NT * VSLOTS && (int64_t)R * C <= 4096 && ((uintptr_t)a % 16) == 0 &&
            ((uintptr_t)b % 16) == 0 && HW < (1ll << 31);
-}
-
-// ---- cooperative one-launch GroupNorm (round 5) -----------------------------------------------------------------------
-// The three-launch form reads x twice and pays three dependent launches (profiles/r04_y_kernel_trace_eager.txt: 2 052 GroupNorm
-// launches, 15.8 ms per C2 step; 14.2 us back to back for 2 x 64^2 x 320 where the data moves in ~3 us).  Here ONE launch of
-// <= #CU workgroups - all resident at once - does the whole norm: every block loads its rows ONCE and keeps them in registers,
-// writes its per-group partial sums (write-through), meets the others at a grid barrier, combines the partials of its
-// sample's groups in a fixed order (lane l takes blocks l, l + 64, ..; fixed butterfly: bit-reproducible, no float atomics),
-// and normalises its rows from the registers.  One read of x (and dy), one write, one launch.
-// Thread map as in gn_vstats / gn_vapply2: a thread owns one 16-byte channel vector and walks rows, R = 256 / (vectors per row)
-// rows in parallel; <= MAXV rows per thread.  bf16 only (the fp32 parity mode keeps the three-launch form).
-// The barrier: arrive = agent-scope ticket on `bar[0]`; the last arriver re-arms it and bumps the generation word `bar[1]`, the
-// others poll the generation (sc1 loads, s_sleep between polls).  Progress needs every block of the launch resident at the
-// same time.  Kernels of other streams never wait on this one, so the only hazard is ANOTHER cooperative launch (the step runs
-// GroupNorms on up to three streams at once: generator, discriminator step, generator-side discriminator loss): the blocks of
-// all of them must fit the device together, whatever the dispatch order.  The host therefore launches at most
-// #CU x (blocks of that variant a CU holds) / GN_COOP_STREAMS blocks (gn_try_coop).  A poll that outlasts ~2 s traps: a hang would
-// take the whole device with it, a trap is an error the caller sees.
-struct GnCoopArgs {
-    const bf16_t* x;
-    const bf16_t* dy;
-    const float* gamma;
-    const float* beta;
-    float* stats;      // MODE 0: written by block 0 of each sample; MODE 1: read
-    double* part;      // [B * G][nblk_s] pairs (s1, s2)
-    unsigned* bar;     // [2]: arrival counter, generation
-    bf16_t* out;
-    const bf16_t* add;
-    int HW, C, G, silu, rpb, nblk_s;
-    float eps;
-};
-
-__device__ __forceinline__ void gn_grid_barrier(unsigned* bar, unsigned nblk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned g0 = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the generation is read BEFORE this block arrives
-        const unsigned old = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == nblk - 1) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm, then release the others
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            unsigned spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) __builtin_trap();
-            }
-        }
-    }
-    __syncthreads();
-}
-
-template <int MODE, int MAXV>
-__global__ __launch_bounds__(NT, (MODE == 1 && MAXV == 16) ? 1 : 3) void gn_coop_kernel(GnCoopArgs a) {
-    constexpr int EPV = 8;
-    __shared__ float p_a[4096], p_b[4096];
-    __shared__ float sm_a[MAX_G], sm_b[MAX_G];
-    const int C = a.C, G = a.G, HW = a.HW;
-    const int VPR = C / EPV, R = NT / VPR, cpg = C / G;
-    const int b = blockIdx.x / a.nblk_s, kblk = blockIdx.x % a.nblk_s;
-    const int v = threadIdx.x % VPR, rsub = threadIdx.x / VPR;
-    const bool active = rsub < R;
-    const int c0 = v * EPV;
-    const int r0 = kblk * a.rpb, r1 = min(r0 + a.rpb, HW);
-    const int64_t base = (int64_t)b * HW * C + c0;
-    float gm[EPV], bt[EPV], mu[EPV], rs[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-        gm[e] = a.gamma[c0 + e];
-        bt[e] = a.beta[c0 + e];
-        if (MODE == 1) {
-            const float* st = a.stats + ((int64_t)b * G + (c0 + e) / cpg) * 2;
-            mu[e] = st[0];
-            rs[e] = st[1];
-        }
-    }
-    constexpr int NG = MODE == 1 ? MAXV : 1;
-    GV16 xv[MAXV], gv[NG];
-    if (active) {
-        // every load of the block's rows is issued before the first use (no branch around a load: a row beyond the block's
-        // range re-reads the last valid row and is zeroed below - a zero x / dy adds nothing to either sum)
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int r = min(r0 + rsub + i * R, HW - 1);
-            xv[i].u = *(const uint4*)(a.x + base + (int64_t)r * C);
-            if (MODE == 1) gv[i % NG].u = *(const uint4*)(a.dy + base + (int64_t)r * C);
-        }
-        float a1[EPV], a2[EPV];
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) a1[e] = a2[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const bool valid = r0 + rsub + i * R < r1;
-            GV16& z = MODE == 1 ? gv[i % NG] : xv[i];
-            z.u.x = valid ? z.u.x : 0u;
-            z.u.y = valid ? z.u.y : 0u;
-            z.u.z = valid ? z.u.z : 0u;
-            z.u.w = valid ? z.u.w : 0u;
-            __builtin_amdgcn_sched_barrier(0);  // one row's temporaries at a time: the scheduler would otherwise run every row's
-                                                // independent arithmetic ahead of the accumulation chain (2 x 64 pending values)
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float xe = bf16_to_f32(xv[i].h[e]);
-                if (MODE == 0) {
-                    a1[e] += xe;
-                    a2[e] += xe * xe;
-                } else {
-                    const float xh = (xe - mu[e]) * rs[e];
-                    float g = bf16_to_f32(gv[i % NG].h[e]);
-                    if (a.silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
-                    g *= gm[e];
-                    a1[e] += g;
-                    a2[e] += g * xh;
-                }
-                asm volatile("" : "+v"(a1[e]), "+v"(a2[e]));  // accumulate NOW (the compiler would sink all 2 x 64 products)
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            p_a[rsub * C + c0 + e] = a1[e];
-            p_b[rsub * C + c0 + e] = a2[e];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        float f1 = 0.f, f2 = 0.f;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = threadIdx.x * cpg; c < (threadIdx.x + 1) * cpg; ++c) {
-                f1 += p_a[rr * C + c];
-                f2 += p_b[rr * C + c];
-            }
-        double* part = a.part + (((int64_t)b * G + threadIdx.x) * a.nblk_s + kblk) * 2;
-        __hip_atomic_store(part, (double)f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(part + 1, (double)f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    gn_grid_barrier(a.bar, gridDim.x);
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const double count = (double)HW * cpg;
-        for (int g2 = wave; g2 < G; g2 += NT / 64) {
-            const double* part = a.part + ((int64_t)b * G + g2) * a.nblk_s * 2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = lane; k < a.nblk_s; k += 64) {
-                s1 += __hip_atomic_load(part + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s2 += __hip_atomic_load(part + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s1 = wave_sum_f64(s1);
-            s2 = wave_sum_f64(s2);
-            if (lane == 0) {
-                if (MODE == 0) {
-                    const double mean = s1 / count;
-                    double var = s2 / count - mean * mean;
-                    if (var < 0) var = 0;
-                    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)a.eps));
-                    sm_a[g2] = m;
-                    sm_b[g2] = r;
-                    if (kblk == 0) {
-                        a.stats[2 * ((int64_t)b * G + g2)] = m;
-                        a.stats[2 * ((int64_t)b * G + g2) + 1] = r;
-                    }
-                } else {
-                    sm_a[g2] = (float)s1;
-                    sm_b[g2] = (float)s2;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (!active) return;
-    // the rows are re-read from their PACKED registers: without this the compiler keeps every fp32 value of the statistics
-    // pass (x-hat, the SiLU-gated gradient) alive across the barrier instead - 128 more registers per thread in the backward
-    // form, and the number of blocks a CU holds bounds how many may be launched (gn_try_coop)
-    if (MODE == 1) {
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            asm volatile("" : "+v"(xv[i].u.x), "+v"(xv[i].u.y), "+v"(xv[i].u.z), "+v"(xv[i].u.w));
-            GV16& q = gv[i % NG];
-            asm volatile("" : "+v"(q.u.x), "+v"(q.u.y), "+v"(q.u.z), "+v"(q.u.w));
-        }
-    }
-    float s1[EPV], s2[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-        const int grp = (c0 + e) / cpg;
-        if (MODE == 0) {
-            mu[e] = sm_a[grp];
-            rs[e] = sm_b[grp];
-        } else {
-            s1[e] = sm_a[grp];
-            s2[e] = sm_b[grp];
-        }
-    }
-    const float inv_n = 1.0f / ((float)HW * (float)cpg);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int r = r0 + rsub + i * R;
-        __builtin_amdgcn_sched_barrier(0);
-        if (r < r1) {
-            GV16 ov, av;
-            if (MODE == 1 && a.add) av.u = *(const uint4*)(a.add + base + (int64_t)r * C);
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float xh = (bf16_to_f32(xv[i].h[e]) - mu[e]) * rs[e];
-                if (MODE == 0) {
-                    float y = xh * gm[e] + bt[e];
-                    if (a.silu) y = silu_f(y);
-                    ov.h[e] = f32_to_bf16(y);
-                } else {
-                    float g = bf16_to_f32(gv[i % NG].h[e]);
-                    if (a.silu) g *= silu_grad_f(xh * gm[e] + bt[e]);
-                    g *= gm[e];
-                    float d = rs[e] * (g - (s1[e] + xh * s2[e]) * inv_n);
-                    if (a.add) d += bf16_to_f32(av.h[e]);
-                    ov.h[e] = f32_to_bf16(d);
-                }
-            }
-            *(uint4*)(a.out + base + (int64_t)r * C) = ov.u;
-        }
-    }
-}
-
-constexpr int GN_COOP_STREAMS = 3;  // cooperative launches that may be in flight at once (see above)
-
-// (#CUs, resident blocks per CU of each variant) of the current device, asked once
-struct GnCoopDev {
-    int ncu;
-    int per_cu[2][2];  // [MODE][MAXV == 16]
-};
-static const GnCoopDev& gn_coop_dev() {
-    static GnCoopDev d = {0, {{0, 0}, {0, 0}}};
-    if (d.ncu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            v = 0;
-        d.ncu = v > 0 ? v : -1;
-        auto occ = [](const void* f) {
-            int n = 0;
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, NT, 0) == hipSuccess ? n : 0;
-        };
-        d.per_cu[0][0] = occ((const void*)gn_coop_kernel<0, 8>);
-        d.per_cu[0][1] = occ((const void*)gn_coop_kernel<0, 16>);
-        d.per_cu[1][0] = occ((const void*)gn_coop_kernel<1, 8>);
-        d.per_cu[1][1] = occ((const void*)gn_coop_kernel<1, 16>);
-        (void)hipGetLastError();
-    }
-    return d;
-}
-
-// option norm_fused = 4 (default since round 5): the cooperative form wherever it applies.  -> true when it took the call
-template <int MODE>
-static bool gn_try_coop(const void* x, const void* dy, const float* gamma, const float* beta, float* stats, void* out,
-                        double* ws_all, int B, int64_t HW, int C, int G, float eps, int silu, const void* add, int dtype,
-                        hipStream_t st) {
-    if (comat_option(COMAT_OPT_NORM_FUSED) != 4 || dtype != COMAT_BF16) return false;
-    if (C % 8 != 0 || G > MAX_G) return false;
-    const int VPR = C / 8;
-    if (VPR > NT || HW >= (1ll << 31)) return false;
-    const int R = NT / VPR;
-    if ((int64_t)R * C > 4096) return false;
-    if ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)dy | (uintptr_t)add) & 15) != 0) return false;
-    const GnCoopDev& d = gn_coop_dev();
-    for (int big = 0; big < 2; ++big) {  // the 8-row variant first: fewer registers, more blocks may be in flight
-        int64_t cap = (int64_t)d.ncu * d.per_cu[MODE][big] / GN_COOP_STREAMS;
-        if (cap > d.ncu) cap = d.ncu;
-        if (cap < B) continue;
-        int64_t nblk_s = cdiv64(HW, (int64_t)R * 4);  // ~4 rows per thread: enough loads in flight, few partials to combine
-        if (nblk_s > cap / B) nblk_s = cap / B;
-        if (nblk_s > 1024) nblk_s = 1024;  // the workspace the ABI asks for holds 1 025 slabs of B x G pairs
-        const int64_t rpb = cdiv64(HW, nblk_s);
-        nblk_s = cdiv64(HW, rpb);
-        if (cdiv64(rpb, R) > (big ? 16 : 8)) continue;  // the rows of a block live in registers
-        GnCoopArgs a;
-        a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.gamma = gamma; a.beta = beta; a.stats = stats;
-        a.part = ws_all + GN_TICKETS / 2;
-        a.bar = (unsigned*)ws_all + (GN_TICKETS - 2);
-        a.out = (bf16_t*)out; a.add = (const bf16_t*)add;
-        a.HW = (int)HW; a.C = C; a.G = G; a.silu = silu; a.rpb = (int)rpb; a.nblk_s = (int)nblk_s; a.eps = eps;
-        const dim3 grid((unsigned)(B * nblk_s));
-        if (!big) hipLaunchKernelGGL((gn_coop_kernel<MODE, 8>), grid, dim3(NT), 0, st, a);
-        else hipLaunchKernelGGL((gn_coop_kernel<MODE, 16>), grid, dim3(NT), 0, st, a);
-        return true;
-    }
-    return false;
 }
 
 // ---- LayerNorm: one wave per row ----------------------------------------------------------------------------------
@@ -1089,8 +804,6 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
     // for the large tensors of the VAE; nothing else: a shape neither takes is an error, not a slower kernel
     if (gn_try_one<0>(x, nullptr, gamma, beta, stats, y, B, HW, C, G, eps, silu, nullptr, dtype, !vec, st))
         return comat_check_launch("comat_groupnorm_fwd");
-    if (gn_try_coop<0>(x, nullptr, gamma, beta, stats, y, ws, B, HW, C, G, eps, silu, nullptr, dtype, st))
-        return comat_check_launch("comat_groupnorm_fwd");
     if (!vec) {
         comat_set_error("comat_groupnorm_fwd: unsupported shape (C = %d, G = %d, HW = %lld): groups of more than 65 536 "
                         "register units need C %% %d == 0 and 16-byte aligned tensors", C, G, (long long)HW,
@@ -1112,8 +825,6 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
     hipStream_t st = (hipStream_t)stream;
     const bool vec = gn_vec_ok(x, dx, C, dtype, HW) && ((uintptr_t)dy % 16) == 0 && (!add || ((uintptr_t)add % 16) == 0);
     if (gn_try_one<1>(x, dy, gamma, beta, (float*)stats, dx, B, HW, C, G, 0.f, silu, add, dtype, !vec, st))
-        return comat_check_launch("comat_groupnorm_bwd");
-    if (gn_try_coop<1>(x, dy, gamma, beta, (float*)stats, dx, ws, B, HW, C, G, 0.f, silu, add, dtype, st))
         return comat_check_launch("comat_groupnorm_bwd");
     if (!vec) {
         comat_set_error("comat_groupnorm_bwd: unsupported shape (C = %d, G = %d, HW = %lld): groups of more than 40 960 "

@@ -52,13 +52,13 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
-    {"norm_fused", "COMAT_NORM_FUSED", 4, 0, false},      // GroupNorm: 4 (default, round 5) = ONE launch everywhere it can be:
-                                                          // a workgroup per (sample, group) where that fits its registers
-                                                          // (HW <= 256), else the cooperative form (<= #CU resident blocks keep
-                                                          // their rows in registers and meet at a grid barrier: norm.hip);
-                                                          // 3 = the round-3 policy (one launch for HW <= 256, else three),
-                                                          // 0 = always the three-launch form, 1 / 2 = two launches (statistics
-                                                          // finalised by the last-arriving block / by the apply kernel)
+    {"norm_fused", "COMAT_NORM_FUSED", 3, 0, false},      // GroupNorm: 3 = ONE launch wherever a (sample, group) fits a
+                                                          // workgroup's registers (every UNet level), 0 = always the
+                                                          // three-launch form, 1 / 2 = two launches (statistics finalised
+                                                          // by the last-arriving block / by the apply kernel's prologue).
+                                                          // (Round 5 measured a cooperative one-launch form - resident blocks,
+                                                          // rows in registers, a grid barrier - at 29 vs 14 us for 2 x 64^2 x 320:
+                                                          // profiles/r05_a_mb_gn_coop.txt; branch exp/r5-coop-gn-keysplit)
     {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
                                                           // kernel with hardware transpose reads
     {"flash_kt", "COMAT_FLASH_KT", 4, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,
@@ -90,12 +90,6 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // launches), 1 where the lean kernel's rule wants the consumer, 2 always
     {"gemm2_chain", "COMAT_GEMM2_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch of the pipelined kernel (producer
                                                           // tiles first, the consumer's last segment waits for its row block)
-    {"flash_ks", "COMAT_FLASH_KS", 0, 0, false},          // 2-tile forward attention with an in-block key split (8 waves: two groups
-                                                          // of 4 own the same 128 queries and half of the keys each, merged in fixed
-                                                          // order through LDS): 0 never, 1 where the grid leaves a CU fewer than four
-                                                          // 4-wave blocks (<= 768 blocks, >= 256 keys, head dim <= 64), 2 wherever
-                                                          // the kernel exists.  Written in round 4 from the occupancy table
-                                                          // (profiles/r04_q_flash_occupancy.txt), NOT yet measured: off
 };
 }  // namespace
 

@@ -190,10 +190,7 @@ def test_groupnorm(dev, dtype, silu, shape):
                                    (2, 1024, 640, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), (2, 256, 2560, 32),
                                    (3, 77, 24, 8)])
 def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
-    """option norm_fused: 4 (default since round 5) = 3 + the cooperative one-launch form (<= #CU resident blocks, rows in
-    registers, a grid barrier between the statistics and the normalisation) for what does not fit a workgroup - the 64^2 / 32^2
-    levels here, both register variants, ragged row blocks (HW = 130);
-    3 = ONE launch, a workgroup per (sample, group) holding the group in registers (the
+    """option norm_fused: 3 (default) = ONE launch, a workgroup per (sample, group) holding the group in registers (the
     shapes cover its three register variants, forward and backward capacity limits - beyond them the call takes the
     three-launch form - and a group with an odd channel count); 1 = the last-arriving statistics block finalises, 2 = the
     prologue of the apply kernel does.  Same statistics up to the summation order of the partial sums: outputs and
@@ -209,8 +206,8 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
     xr.grad += gy2.reshape(B_, HW, C)
     res = []
     vec_ok = C % (4 if dtype == torch.float32 else 8) == 0  # what the multi-launch forms need (else: one launch or an error)
-    for mode in (0, 1, 2, 3, 3, 4, 4):
-        if mode not in (3, 4) and not vec_ok:
+    for mode in (0, 1, 2, 3, 3):
+        if mode != 3 and not vec_ok:
             res.append(None)
             continue
         _set_opts(norm_fused=mode)
@@ -221,13 +218,12 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
         check(y, yr, dtype, f"gn fwd (norm_fused={mode})")
         check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, f"gn bwd (norm_fused={mode})", factor=2)
     lim = 2e-6 if dtype == torch.float32 else 1e-2  # bf16: an output may flip by one ulp
-    for mode, idx in ((1, 1), (2, 2), (3, 3), (4, 5)):
+    for mode in (1, 2, 3):
         if res[0] is None:
             continue
-        for a, b_, name in zip(res[0], res[idx], ("y", "dx")):
+        for a, b_, name in zip(res[0], res[mode], ("y", "dx")):
             assert rel_l2(b_, a) < lim, f"norm_fused={mode}: {name} differs from the three-launch form by {rel_l2(b_, a):.2e}"
     assert torch.equal(res[3][0], res[4][0]) and torch.equal(res[3][1], res[4][1])  # run-to-run bit-identical
-    assert torch.equal(res[5][0], res[6][0]) and torch.equal(res[5][1], res[6][1])  # the cooperative form too
 
 
 @pytest.mark.gpu
@@ -783,7 +779,7 @@ def test_adamw_with_clip(dev):
 
 
 # the library's defaults for the options whose default moved in round 4 (runtime.hip)
-DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0, flash_ks=0)
+DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0)
 
 
 def _set_opts(**kw):
@@ -797,8 +793,8 @@ def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
     _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=DEFAULT_OPTS['flash_xcd'],
-              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=4, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
-              gemm2_chain=DEFAULT_OPTS['gemm2_chain'], flash_ks=DEFAULT_OPTS['flash_ks'])
+              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
+              gemm2_chain=DEFAULT_OPTS['gemm2_chain'])
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1583,38 +1579,6 @@ def test_flash_backward_partials_do_not_touch_the_gemm_tickets(hip, default_opts
         out = torch.full((512, 256), float("nan"), dtype=torch.float32, device=hip)
         k.gemm(dv(A, hip, dtype), dv(Bm, hip, dtype), out, 512, 256, 4096, 4096, 4096, 256)
         check(out, A @ Bm.t(), dtype, f"split-K GEMM after a split flash backward (gemm2={g2})")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(2, 256, 256, 8, 40), (1, 200, 320, 2, 64), (1, 130, 577, 3, 64), (2, 128, 4096, 2, 40),
-                                 (1, 64, 100, 2, 32), (1, 96, 192, 1, 48)])
-def test_flash_forward_with_an_in_block_key_split(hip, cfg, default_opts):
-    """option flash_ks = 2: the 2-tile forward with two key groups per block (8 waves), merged in fixed order through LDS,
-    against the unsplit kernel (same arithmetic per score; the running maxima of the two halves meet only at the end:
-    equal to bf16 rounding, log-sum-exp to fp32 rounding) and against a materialised fp32 reference.  Even and odd pair
-    counts (4, 5, 10, 64 pairs; 2 and 3: one group ends early), ragged last pairs, ragged query blocks; launched twice
-    (the result must not depend on what the exchange area held)."""
-    dtype = torch.bfloat16
-    B, Nq, Nk, H, d = cfg
-    q, k_, v = (rnd(B * n, H * d, dtype=dtype, seed=i) for i, n in ((1, Nq), (2, Nk), (3, Nk)))
-    K = ops.kernels()
-    HD = H * d
-    outs = []
-    for ks in (0, 2, 2):
-        _set_opts(flash_ks=ks)
-        qd, kd, vd = (dv(t, hip, dtype) for t in (q, k_, v))
-        o = torch.full_like(qd, float("nan"))
-        lse = torch.full((B, H, Nq), float("nan"), device=hip)
-        K.flash_attn_fwd(qd, kd, vd, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
-        outs.append((o.float(), lse.clone()))
-    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1]), "the split kernel is not reproducible"
-    assert rel_l2(outs[1][0], outs[0][0]) < 6e-3, f"O: split differs from unsplit by {rel_l2(outs[1][0], outs[0][0]):.2e}"
-    assert (outs[1][1] - outs[0][1]).abs().max() < 1e-4 * (1 + outs[0][1].abs().max())
-    qr, kr, vr = (t.float().reshape(B, n, H, d).permute(0, 2, 1, 3) for t, n in ((q, Nq), (k_, Nk), (v, Nk)))
-    sc = qr @ kr.transpose(-1, -2) * d ** -0.5
-    ref = (torch.softmax(sc, -1) @ vr).permute(0, 2, 1, 3).reshape(B * Nq, HD)
-    check(outs[1][0], ref, dtype, "flash forward with an in-block key split")
-    assert (outs[1][1].cpu() - torch.logsumexp(sc, -1)).abs().max() < 2e-2
 
 
 @pytest.mark.gpu
