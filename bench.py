@@ -45,7 +45,7 @@ F_UNET, F_VAE, F_BLIP = 0.839, 2.515, 0.408
 F_UNET_SDXL = 1.678  # SDXL UNet @64x64 latent incl. LoRA r=128, per sample forward
 
 
-def step_tflop(total_step, K, gan, sdxl=False, res=512):
+def step_tflop(total_step, K, gan, sdxl=False, res=512, bs=1):
     """Algorithmic TFLOP of one step (SURVEY.md 8d counting convention).  The discriminator is the SD1.5 UNet in every
     configuration (scripts of the reference).  The per-call figures are quoted at 512^2 (64^2 latents); at 1024^2 the
     UNets and the VAE see 4x the positions (self-attention grows 16x: undercounted here), BLIP still sees 384^2."""
@@ -56,7 +56,7 @@ def step_tflop(total_step, K, gan, sdxl=False, res=512):
     f = nograd + train + F_VAE * px * 2 + F_BLIP * 2
     if gan:
         f += F_UNET * px * 2 + 2 * F_UNET * px * 2
-    return f
+    return f * bs  # every term is per prompt
 
 
 MFMA_CALLS = ("gemm", "gemm_segments", "conv2d", "flash_attn_fwd", "flash_attn_bwd", "gemm_tt_grouped")
@@ -244,7 +244,7 @@ class CallRecorder:
         return fam
 
 
-def build_world(device, dtype, rank, cfg_name):
+def build_world(device, dtype, rank, cfg_name, bs=1):
     from comat_amd import config, weights
     from comat_amd.blip import Blip
     from comat_amd.gan import D_sd
@@ -294,7 +294,7 @@ def build_world(device, dtype, rank, cfg_name):
     pipe = TrainableSDXLPipeline(unet, vae) if sdxl else TrainableSDPipeline(unet, vae)
     trainer = CoMatTrainer(pipe, bank, blip, disc, scfg, seed=rank)
     if scfg.total_step > scfg.K and os.environ.get("COMAT_PRECAPTURE", "1") != "0" and torch.device(device).type == "cuda":
-        trainer.pipe.prepare_graphs(1, scfg.resolution, scfg.resolution, 77, scfg.total_step)
+        trainer.pipe.prepare_graphs(bs, scfg.resolution, scfg.resolution, 77, scfg.total_step)
     # synthetic batch; per-rank seeds differ (each rank has its own prompt)
     g = torch.Generator().manual_seed(1000 + rank)
     L, T = (7, 9) if tiny else (77, 16)
@@ -305,25 +305,25 @@ def build_world(device, dtype, rank, cfg_name):
         ids = torch.cat([torch.tensor([101, 1037, 5855, 1997]), torch.randint(1000, 30522, (11,), generator=g),
                          torch.tensor([102])]).reshape(1, T)
     batch = dict(
-        prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
-        negative_prompt_embeds=torch.randn(1, L, ucfg.cross_attention_dim, generator=g),
-        gan_null_embeds=torch.randn(1, L, dcfg.cross_attention_dim, generator=g),
-        latents=torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(42 + rank)),
-        noises=[torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(100 + i)).to(device)
+        prompt_embeds=torch.randn(bs, L, ucfg.cross_attention_dim, generator=g),
+        negative_prompt_embeds=torch.randn(bs, L, ucfg.cross_attention_dim, generator=g),
+        gan_null_embeds=torch.randn(1, L, dcfg.cross_attention_dim, generator=g).expand(bs, -1, -1).contiguous(),
+        latents=torch.randn(bs, 4, hl, hl, generator=torch.Generator().manual_seed(42 + rank)),
+        noises=[torch.randn(bs, 4, hl, hl, generator=torch.Generator().manual_seed(100 + i)).to(device)
                 for i in range(scfg.total_step)],
-        real_latents=torch.randn(1, 4, hl, hl, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
-        blip_input_ids=ids, blip_attention_mask=torch.ones_like(ids))
+        real_latents=torch.randn(bs, 4, hl, hl, generator=torch.Generator().manual_seed(7)) * (0.2 / 0.18215),
+        blip_input_ids=ids.expand(bs, -1).contiguous(), blip_attention_mask=torch.ones_like(ids).expand(bs, -1).contiguous())
     if sdxl:
-        batch.update(pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
-                     negative_pooled_prompt_embeds=torch.randn(1, ucfg.pooled_dim, generator=g),
+        batch.update(pooled_prompt_embeds=torch.randn(bs, ucfg.pooled_dim, generator=g),
+                     negative_pooled_prompt_embeds=torch.randn(bs, ucfg.pooled_dim, generator=g),
                      add_time_ids=(res, res, 0, 0, res, res))
     if scfg.attrcon:
         import numpy as np
         m = np.zeros((2, res, res), dtype=bool)
         m[0, 60 * res // 512:250 * res // 512, 40 * res // 512:230 * res // 512] = True
         m[1, 280 * res // 512:480 * res // 512, 260 * res // 512:500 * res // 512] = True
-        batch["masks"] = [m]
-        batch["attributes"] = [[[2, 3], [6, 7]]]
+        batch["masks"] = [m] * bs
+        batch["attributes"] = [[[2, 3], [6, 7]]] * bs
     fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, res - 2, res - 2))
     if cfg_name == "c2":
         fixed["training_steps"] = [0, 1, 2, 3, 4]
@@ -555,6 +555,31 @@ def secondary_c4_own_process(timeout_s=400):
                    "own, started by the default line (the C2 / C3 worlds of the parent stay allocated and idle meanwhile)"}
 
 
+def secondary_c2_bs4_own_process(bs=4, timeout_s=300):
+    """The C2 workload at the reference's operating point, `--train_batch_size 4` per GPU (scripts/sd15.sh:4): every kernel of
+    the step sees 4x the rows (CFG batch 8).  Answers whether the kernels' fraction of peak at bs 1 is a property of the kernels
+    or of the bs-1 problem sizes.  `python bench.py --bs 4 --steps 2` in a process of its own (as C4): two
+    timed steps, the per-kernel family block from its own recorder step."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "c2", "--bs", str(bs), "--no-cpu-baseline", "--steps", "2",
+           "--warmup", "1"]
+    t0 = time.time()
+    env = dict(os.environ, COMAT_SECONDARY="0", COMAT_PROBE_EAGER="0", COMAT_ATTN_MAP_PROBE="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
+    if r.returncode != 0 or line is None:
+        raise RuntimeError(f"bench.py --bs {bs} exited with {r.returncode}: {r.stderr[-300:]}")
+    d = json.loads(line)
+    c, rf = d["config"], d.get("roofline") or {}
+    fams = {k: {kk: v[kk] for kk in ("ms", "launches", "TFLOP/s", "frac_of_peak")} for k, v in (rf.get("families") or {}).items()
+            if k.startswith("gemm2_kernel (") or k.startswith("flash")}
+    return {"workload": c["workload"], "per_gpu_batch": bs, "ms_per_step": round(d["ms_per_step"], 1),
+            "images_per_sec": round(d["value"], 3), "steps": d["steps"], "warmup": d["warmup"], "launch_mode": c.get("launch_mode"),
+            "step_algorithmic_tflop": rf.get("step_algorithmic_tflop"), "step_frac": rf.get("step_frac"), "families": fams,
+            "gpu_ms_per_step_by_piece": c.get("gpu_ms_per_step_by_piece"), "wall_s": round(time.time() - t0, 1),
+            "how": f"`python bench.py --config c2 --bs {bs} --no-cpu-baseline --steps 2 --warmup 1` in a process of its own"}
+
+
 def secondary_c4(device, dtype, rank, sync, steps=3):
     """BASELINE config C4 (SDXL generator 512^2, SD1.5 discriminator, the full loss set of scripts/sdxl.sh) in the default
     line, so that the driver's run carries an SDXL number: its own world (random-init SDXL UNet / VAE, ~75 s to build), the 45
@@ -628,6 +653,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--bs", type=int, default=1, help="prompts per GPU and step (the headline metric is quoted at 1; the reference "
+                                                      "trains SD1.5 at 4: scripts/sd15.sh:4)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -655,7 +682,7 @@ def main():
     if not args.selftest:
         torch.cuda.set_per_process_memory_fraction(0.92)  # an over-sized configuration must fail as a Python OOM
     trainer, batch, fixed, scfg, usd_cpu, t_build = build_world(device, dtype, rank,
-                                                                "selftest" if args.selftest else args.config)
+                                                                "selftest" if args.selftest else args.config, bs=args.bs)
 
     last_logs = {}
 
@@ -821,7 +848,7 @@ def main():
             sync()
             allreduce_ms = round((time.time() - t0a) / 5 * 1e3, 3)
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt  # one image (prompt) per rank per step
+    value = world * args.bs * args.steps / dt  # args.bs images (prompts) per rank per step
 
     pieces = None
     if seg_stepper is not None and world == 1 and not args.no_kernel_timing and not args.selftest:
@@ -860,8 +887,9 @@ def main():
     if rank == 0 and not args.no_kernel_timing and not args.selftest:
         dom = max(fam, key=lambda k: fam[k][4])
         t_rep, f_dom, n_dom, b_dom, t_dom = fam[dom]
-        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config in ("c4", "c5"), res=scfg.resolution)
-        pmc = load_pmc_summary()
+        total = step_tflop(scfg.total_step, scfg.K, scfg.gan_loss, sdxl=args.config in ("c4", "c5"), res=scfg.resolution,
+                           bs=args.bs)
+        pmc = load_pmc_summary() if args.bs == 1 else None  # the committed counter passes are of the bs-1 step
         n_other = sum(rec.other.values())
         peak_of = lambda family: PEAK_FP8_TFLOPS if "fp8" in family else PEAK_BF16_TFLOPS
         roofline = {
@@ -869,7 +897,8 @@ def main():
             "achieved": f_dom / t_dom / 1e12, "peak": peak_of(dom), "unit": "TFLOP/s",
             "frac": f_dom / t_dom / 1e12 / peak_of(dom),
             "traffic": pmc.get("traffic_bytes_per_launch") if pmc else None,
-            "traffic_note": pmc.get("note") if pmc else "no committed PMC pass found (profiles/r03_pmc_kernels.json)",
+            "traffic_note": pmc.get("note") if pmc else ("no committed PMC pass found (profiles/r0N_pmc_kernels.json)" if args.bs == 1
+                                                         else "the committed counter passes are of the bs-1 step"),
             "mfma_busy_frac": pmc.get("mfma_busy_frac") if pmc else None,
             "algorithmic_bytes_per_launch": int(b_dom / n_dom),
             "launches_per_step": n_dom, "avg_launch_ms": t_dom / n_dom * 1e3,
@@ -893,10 +922,10 @@ def main():
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][4])},
         }
     attn_map = None
-    if rank == 0 and not args.no_kernel_timing and not args.selftest:
+    if rank == 0 and not args.no_kernel_timing and not args.selftest and os.environ.get("COMAT_ATTN_MAP_PROBE", "1") != "0":
         attn_map = attn_map_probe()
     secondary = None
-    if (rank == 0 and world == 1 and args.config == "c2" and not args.selftest and not args.no_kernel_timing
+    if (rank == 0 and world == 1 and args.config == "c2" and args.bs == 1 and not args.selftest and not args.no_kernel_timing
             and os.environ.get("COMAT_SECONDARY", "1") != "0"):
         try:
             secondary = {"c3": secondary_c3(trainer, batch, rank, sync)}
@@ -913,6 +942,14 @@ def main():
                         secondary["c4"] = secondary_c4_own_process()
                 except Exception as e:  # noqa: BLE001
                     secondary["c4"] = {"error": f"{type(e).__name__}: {e}"}
+        if os.environ.get("COMAT_SECONDARY_BS4", "1") != "0":
+            if time.time() - T_PROCESS > 420:
+                secondary["c2_bs4"] = {"skipped": "the run had used more than 420 s before the batch-4 measurement"}
+            else:
+                try:
+                    secondary["c2_bs4"] = secondary_c2_bs4_own_process()
+                except Exception as e:  # noqa: BLE001
+                    secondary["c2_bs4"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
         cpu = cpu_baseline(usd_cpu, scfg)
@@ -921,7 +958,7 @@ def main():
     if rank == 0:
         out = {
             "metric": f"CoMat train-step images/sec ({'SDXL' if args.config in ('c4', 'c5') else 'SD1.5'} "
-                      f"{scfg.resolution}^2, bs=1/GPU)",
+                      f"{scfg.resolution}^2, bs={args.bs}/GPU)",
             "value": value, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -930,7 +967,7 @@ def main():
             "data": "SELFTEST (CPU simulator, tiny model): not a measurement" if args.selftest else "synthetic",
             "config": {"workload": f"{args.config.upper()}: "
                                    f"{'SDXL (SD1.5 discriminator' + (', fp8 UNet forward)' if args.config == 'c5' else ')') if args.config in ('c4', 'c5') else 'SD1.5'} "
-                                   f"{scfg.resolution}x{scfg.resolution} bs=1/GPU, N={scfg.total_step} denoise steps "
+                                   f"{scfg.resolution}x{scfg.resolution} bs={args.bs}/GPU, N={scfg.total_step} denoise steps "
                                    f"(K={scfg.K} with grad), CFG 7.5, LoRA r=128, concept-matching (BLIP-large) + GAN "
                                    f"fidelity (G+D step)" + (" + attribute concentration" if scfg.attrcon else "") +
                                    ", clip+AdamW for G and D",

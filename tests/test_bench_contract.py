@@ -17,12 +17,13 @@ def _json_line(out):
     return json.loads(lines[0])
 
 
-def _check(d, n, steps, warmup):
+def _check(d, n, steps, warmup, bs=1):
     assert REQUIRED <= set(d), REQUIRED - set(d)
     assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup
     assert d["unit"] == "images/sec" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
-    assert d["value"] > 0 and abs(d["value"] - n * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - n * bs * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert f"bs={bs}/GPU" in d["metric"] and f"bs={bs}/GPU" in d["config"]["workload"]
     assert "SELFTEST" in d["data"]  # a self-test line can never be mistaken for a measurement
 
 
@@ -40,6 +41,16 @@ def test_single_process_selftest():
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-3000:]
     _check(_json_line(p.stdout), 1, 2, 1)
+
+
+def test_single_process_selftest_with_a_per_gpu_batch():
+    """`--bs 2` (the `secondary.c2_bs4` line runs the real thing at 4): the batch the step sees has that many prompts and the
+    value counts every one of them"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest", "--steps", "2", "--warmup", "1", "--bs", "2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    _check(_json_line(p.stdout), 1, 2, 1, bs=2)
 
 
 def test_two_rank_launch_like_the_driver():

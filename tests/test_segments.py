@@ -126,6 +126,36 @@ def test_segmented_step_matches_eager(hip, dtype, attrcon):
 
 
 @pytest.mark.gpu
+def test_step_graphs_at_a_per_gpu_batch_of_four(hip):
+    """bs 4 per GPU (the reference's --train_batch_size 4, scripts/sd15.sh:4; CFG batch 8): the segment graphs and the
+    whole-step graph of `secondary.c2_bs4` replay bit-identically to eager launches at the size that line uses."""
+    from comat_amd.step import GraphedStep
+    dtype = torch.bfloat16
+    cfg, batch, W, tr_e = make_world(dtype, hip, False, bs=4)
+    cfg, _, _, tr_g = make_world(dtype, hip, False, bs=4)
+    assert batch["latents"].shape[0] == 4
+    tr_e.pipe.share_text_kv = False
+    st = SegmentedStep(tr_g)
+    run_plan(tr_e, st, batch, dtype, False, torch.equal)
+    assert st.failed is None and st.stats()["replays"] >= 10
+    # the whole-step graph (static topology: every denoise step trained)
+    cfg, _, _, tr_e2 = make_world(dtype, hip, False, bs=4)
+    cfg, _, _, tr_w = make_world(dtype, hip, False, bs=4)
+    gs = GraphedStep(tr_w)
+    gen = torch.Generator().manual_seed(3)
+    for it in range(4):
+        b = vary(batch, gen, dtype)
+        kw = dict(training_steps=[0, 1, 2], crop=(it % 2, 1, 63, 63))
+        le, lg = tr_e2.train_step(b, **kw), gs(b, **kw)
+        torch.cuda.synchronize()
+        assert gs.failed is None, gs.failed
+        for k in ("step_loss", "Blip", "G_loss", "D_loss"):
+            assert torch.equal(le[k], lg[k]), f"step {it}: {k}"
+        assert torch.equal(tr_e2.bank.flat, tr_w.bank.flat) and torch.equal(tr_e2.D.bank.flat, tr_w.D.bank.flat)
+    assert len(gs.graphs) == 1
+
+
+@pytest.mark.gpu
 def test_segmented_step_with_its_own_discriminator_graph(hip):
     """use_d="own": the discriminator step as a separate graph on the discriminator's stream (same bits, less overlap)"""
     dtype = torch.bfloat16

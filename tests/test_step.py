@@ -40,7 +40,7 @@ def report(name, dtype, dev, **vals):
                     + " ".join(f"{k}={v:.3e}" for k, v in vals.items()) + "\n")
 
 
-def make_world(dtype, dev, attrcon, gan=True, rank=None):
+def make_world(dtype, dev, attrcon, gan=True, rank=None, bs=2):
     """rank: LoRA rank of both UNets (default: the tiny configuration's 4; 8 makes every weight-gradient product eligible
     for the grouped k-major kernel, as all of them are at the real rank 128)"""
     tcfg = config.TINY_UNET if rank is None else dataclasses.replace(config.TINY_UNET, lora_rank=rank)
@@ -54,7 +54,7 @@ def make_world(dtype, dev, attrcon, gan=True, rank=None):
     cfg = StepConfig(resolution=64, total_step=3, K=2, gan_loss=gan, attrcon=attrcon, attrcon_train_steps=1,
                      train_layer_ls=("mid_2", "up_4", "up_8"), attn_reses=(8, 4, 2), lr=1e-2, lr_D=1e-2,
                      mask_token_loss_weight=0.5, mask_pixel_loss_weight=0.1)
-    bs, L, cd, T = 2, 7, config.TINY_UNET.cross_attention_dim, 9
+    L, cd, T = 7, config.TINY_UNET.cross_attention_dim, 9  # bs: prompts per step (even)
     r = lambda *s: torch.randn(*s, generator=g)
     ids = torch.randint(1, config.TINY_BLIP.vocab_size, (bs, T), generator=g)
     ids[1, 7:] = 0
@@ -68,7 +68,7 @@ def make_world(dtype, dev, attrcon, gan=True, rank=None):
                  gan_null_embeds=r(bs, L, cd).to(dtype).float(), latents=r(bs, 4, 8, 8),
                  noises=[r(bs, 4, 8, 8) for _ in range(3)], real_latents=r(bs, 4, 8, 8),
                  blip_input_ids=ids, blip_attention_mask=(ids != 0).long(), masks=masks,
-                 attributes=[[[2, 3], [5]], [[1], [4, 6]]])
+                 attributes=[[[2, 3], [5]], [[1], [4, 6]]] * (bs // 2))
     # oracle world
     ucfg, vcfg = oracle_cfgs(tcfg)
     W = dict(unet=usd, vae=vsd, blip=bsd, d_unet=dsd, ucfg=ucfg, vcfg=vcfg,
