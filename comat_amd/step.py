@@ -270,15 +270,20 @@ class CoMatTrainer:
             return self.d_runner(out, batch)
         return self._d_step_eager(out, batch)
 
-    def _d_step_eager(self, out, batch):
-        """D forward + backward on [fake.detach(); real] (training_script.py:683-690)."""
+    def _d_forward(self, out, batch):
+        """forward half of the D step: zero the discriminator's gradients, D_loss on [fake.detach(); real] with its autograd
+        graph (training_script.py:683-688)"""
         cfg = self.cfg
         h = w = cfg.resolution // 8
         self.D.zero_grad()
         real = ops.nchw_to_tokens(batch["real_latents"].to(self.device, torch.float32))
-        D_loss = self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
-                                              negative_prompt_embeds=batch["gan_null_embeds"],
-                                              num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
+        return self.D.D_sd_pipeline_forward(out["training_latents"].detach(), "D",
+                                            negative_prompt_embeds=batch["gan_null_embeds"],
+                                            num_inference_steps=cfg.total_step, h=h, w=w, real_latents=real)
+
+    def _d_step_eager(self, out, batch):
+        """D forward + backward on [fake.detach(); real] (training_script.py:683-690)."""
+        D_loss = self._d_forward(out, batch)
         D_loss.backward()
         return D_loss.detach()
 
