@@ -102,5 +102,6 @@ def test_c1_full_size_matches_oracle_golden(hip):
         est = float(np.sqrt(np.mean((p - gold["grad_proj"][i]) ** 2)))  # ~ |g - g_ref| for this tensor
         assert est <= 3e-3 * nref + 3e-6 * total_ref, f"{n}: estimated gradient error {est:.3e} vs norm {nref:.3e}"
         err_sq += est ** 2
-    assert np.sqrt(err_sq) <= 1e-3 * total_ref * 1.5, f"flat LoRA gradient: estimated rel. error {np.sqrt(err_sq) / total_ref:.3e}"
+    # measured 1.4e-5 (profiles/r04_z_grad_shrink_bisect.txt, row fff): an order of magnitude inside the north star's 1e-3
+    assert np.sqrt(err_sq) <= 1e-4 * total_ref, f"flat LoRA gradient: estimated rel. error {np.sqrt(err_sq) / total_ref:.3e}"
     assert NPROJ == gold["grad_proj"].shape[1]
