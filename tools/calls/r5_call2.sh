@@ -20,14 +20,9 @@ run() {  # label, env...
 {
 run "default" A=1
 run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0" DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-run "DEBUG_CLR_GRAPH_PACKET_CAPTURE=1" DEBUG_CLR_GRAPH_PACKET_CAPTURE=1
 run "DEBUG_HIP_FORCE_GRAPH_QUEUES=1" DEBUG_HIP_FORCE_GRAPH_QUEUES=1
 run "DEBUG_HIP_FORCE_GRAPH_QUEUES=2" DEBUG_HIP_FORCE_GRAPH_QUEUES=2
-run "DEBUG_HIP_FORCE_GRAPH_QUEUES=8" DEBUG_HIP_FORCE_GRAPH_QUEUES=8
 run "DEBUG_HIP_GRAPH_BATCH_SIZE=1" DEBUG_HIP_GRAPH_BATCH_SIZE=1
-run "DEBUG_HIP_GRAPH_BATCH_SIZE=64" DEBUG_HIP_GRAPH_BATCH_SIZE=64
-run "GPU_MAX_HW_QUEUES=8" GPU_MAX_HW_QUEUES=8
-run "default again" A=1
 } 2>&1 | tee $O/r5b_c2_runtime_knobs.txt
 for d in 1 0; do
   echo "== C3, COMAT_D_SPLIT=$d"
