@@ -68,7 +68,6 @@ _vp, _i32, _i64, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "comat_gemm": [C.POINTER(GemmParams), _vp],
     "comat_gemm_segments": [C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, _vp],
-    "comat_gemm_chain": [C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, C.POINTER(GemmParams), C.POINTER(GemmSegment), _i32, _vp],
     "comat_gemm_tt_grouped": [C.POINTER(TTProblem), _i32, _i32, _vp, _i64, _vp],
     "comat_conv2d": [C.POINTER(ConvParams), _vp],
     "comat_groupnorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp],
@@ -149,8 +148,7 @@ def load_library(path: str | None = None):
 GEMM_KERNEL_NAMES = {0: "gemm_kernel / conv_kernel (general 64x64)", 1: "gemm2_kernel (LDS-DMA pipelined)",
                      2: "gemm2_tt_kernel (pipelined, k-major operands)", 3: "gemm2_kernel fp8 (32x32x64 e4m3 MFMA)",
                      4: "gemm2_tt_group_kernel (grouped k-major products)",
-                     5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)",
-                     6: "gemm2_chain_kernel (producer + consumer of a chained call in one launch)"}
+                     5: "gemm3_kernel (lean: k-parallel waves, register-direct fragments)"}
 
 
 def build_id() -> str:
@@ -332,14 +330,6 @@ class HipKernels:
         batch > 1: that many problems in one launch; operands advance by sA / sB, Cout / R by sC / sR elements."""
         p, arr, n = self._segments_params(segs, Cout, M, N, ldc, bias, R, ldr, alpha, beta, batch, sC, sR)
         _check(_lib.comat_gemm_segments(C.byref(p), arr, n, _stream()), "comat_gemm_segments")
-
-    def gemm_chain(self, pre, main):
-        """Two dependent K-segmented GEMMs - `pre`, then `main`, whose LAST segment's A operand is pre's output - given as
-        the keyword sets of gemm_segments().  One launch where the library's lean kernel takes both (include/comat_hip.h:
-        comat_gemm_chain), else the two launches in stream order: same results either way."""
-        p0, a0, n0 = self._segments_params(**pre)
-        p1, a1, n1 = self._segments_params(**main)
-        _check(_lib.comat_gemm_chain(C.byref(p0), a0, n0, C.byref(p1), a1, n1, _stream()), "comat_gemm_chain")
 
     @staticmethod
     def tt_group_ok(A, B, Cacc, M, N, K, lda, ldb, ldc):

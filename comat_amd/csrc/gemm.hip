@@ -845,33 +845,6 @@ extern "C" int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_
     return comat_check_launch("comat_gemm_segments");
 }
 
-// Two dependent K-segmented GEMMs in stream order - as ONE launch when the lean kernel takes both (include/comat_hip.h)
-extern "C" int comat_gemm_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int32_t nseg0,
-                                const comat_gemm_params* p1, const comat_gemm_segment* segs1, int32_t nseg1, void* stream) {
-    COMAT_REQUIRE(p0 && p1 && segs0 && segs1 && nseg0 >= 1 && nseg1 >= 1, "comat_gemm_chain: null params");
-    COMAT_REQUIRE(segs1[nseg1 - 1].A != nullptr && p0->C != nullptr, "comat_gemm_chain: null operand");
-    {   // the consumer's last segment must read the producer's output buffer: [C0, C0 + M ldc) in elements
-        const char* c0 = (const char*)p0->C;
-        const char* a1 = (const char*)segs1[nseg1 - 1].A;
-        const int64_t esz = p0->out_dtype == COMAT_F32 ? 4 : 2;
-        const int64_t span = ((p0->batch1 > 1 ? p0->batch1 - 1 : 0) * p0->sC1 + p0->M * p0->ldc) * esz;
-        COMAT_REQUIRE(a1 >= c0 && a1 < c0 + span, "comat_gemm_chain: the consumer's last segment does not read the producer's output");
-    }
-    const int rc3 = comat_gemm3_try_chain(p0, segs0, nseg0, p1, segs1, nseg1, stream);
-    if (rc3 > 0) {
-        comat_note_gemm_kernel(rc3);
-        return comat_check_launch("comat_gemm_chain");
-    }
-    const int rc2 = comat_gemm2_try_chain(p0, segs0, nseg0, p1, segs1, nseg1, stream);
-    if (rc2 > 0) {
-        comat_note_gemm_kernel(6);
-        return comat_check_launch("comat_gemm_chain");
-    }
-    const int rc = comat_gemm_segments(p0, segs0, nseg0, stream);
-    if (rc != COMAT_OK) return rc;
-    return comat_gemm_segments(p1, segs1, nseg1, stream);
-}
-
 extern "C" int comat_conv2d(const comat_conv_params* p, void* stream) {
     COMAT_REQUIRE(p != nullptr, "comat_conv2d: null params");
     COMAT_REQUIRE(p->X && p->W && p->Y, "comat_conv2d: null operand");

@@ -79,42 +79,6 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
 // would read for bf16 k-steps 0 and 1 (chunks h and 2 + h of row r) as ONE 32-byte operand.  The instruction's own
 // lane -> k assignment is the same for A and B, so - as for bf16 - the k-permutation cancels.  Block scales are unused
 // (scale 0 selects the unscaled v_mfma_f32_32x32x64_f8f6f4 form); per-tensor scales are applied in the epilogue.
-// the same DMA with the sc1 policy (L1 bypass): rows that another workgroup of THIS launch produced (chained launches)
-__device__ __forceinline__ void dma16_sc1(const void* gsrc, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, /*sc1*/ 16);
-}
-
-// Chained launch (comat_gemm_chain, include/comat_hip.h): the workgroups with the lowest block ids compute a PRODUCER
-// problem, the others a CONSUMER problem whose LAST k-segment reads the producer's output rows.  One counter per consumer
-// row block: `done[tm]` counts finished producer tiles overlapping those rows, `seen[tm]` finished consumer tiles (the last
-// one re-arms both).  Producer tiles are stored write-through (sc1) and drained before the count; consumers poll relaxed
-// and fetch the rows with sc1 DMA (cdna_hip_programming.md guideline 16, R1 - the split-K protocol of gemm_shared.h).
-// A workgroup only ever waits for workgroups with LOWER block ids, which each XCD's dispatcher started before it; the spin is
-// bounded and a give-up raises `err` (checked by the tests).
-struct Chain2 {
-    unsigned* done;
-    unsigned* seen;
-    unsigned* err;
-    int need;      // producer tiles per consumer row block
-    int cons;      // consumer tiles per row block
-    int pre_per;   // producer row blocks per consumer row block (producer tile height <= consumer's: same kernel, so 1)
-};
-constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 24;
-
-__device__ __forceinline__ void chain_wait(const Chain2& c, int tm, int lane) {
-    if (lane == 0) {
-        unsigned n = 0;
-        while (__hip_atomic_load(c.done + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c.need) {
-            if (++n > CHAIN_SPIN_LIMIT) {
-                __hip_atomic_store(c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-}
-
 __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, const short8_t& w1, const short8_t& x0,
                                           const short8_t& x1) {
     typedef int v8i __attribute__((ext_vector_type(8)));
@@ -230,11 +194,9 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
 // bytes = two host k-tiles per barrier.  The k-loop of a problem with few rows is a latency chain (DMA wait, barrier,
 // LDS reads, MFMAs: ~0.11 us per 64-byte k-tile whatever the tile shape - 2 600 of the 4 000 launches of a C2 step);
 // doubling the tile halves the number of links.
-// CH: 0 = an ordinary launch; 1 = the PRODUCER part of a chained launch (write-through epilogue, then the row block's counter),
-// 2 = the CONSUMER part (waits for its row block's counter before the first DMA of its LAST segment, fetches that segment's A
-// rows with sc1 DMA, retires the row block).  `bid` / `nblk`: this block's index in, and the size of, its part of the grid.
-template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB, int KS, int CH>
-__device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, const unsigned nblk, char* smem, const Chain2& ch) {
+// `bid` / `nblk`: this block's index in, and the size of, the grid.
+template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB, int KS>
+__device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, const unsigned nblk, char* smem) {
     static_assert(KS == 2 || (KS == 4 && EB == 2), "128-byte k-tiles: bf16 only");
     constexpr int RBK = 32 * KS;   // bytes per LDS row
     constexpr int KSF = KS / 2;    // host k-tiles (64 bytes) per kernel k-tile
@@ -300,7 +262,6 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     bool rv[IA];
     int seg = 0, seg_left = 0;   // issue-side segment cursor
     int ky = 0, kx = 0, ci0 = 0;  // CONV: issue-side tap cursor
-    bool chained = false;        // CH == 2: the issue cursor is in the LAST segment (A rows come from the producer part)
 
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -346,12 +307,6 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + (int64_t)t0 * RBK + csrc * 16;
 #pragma unroll
         for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + (int64_t)t0 * RBK + csrc * 16;
-        if constexpr (CH == 2) {  // a k-slice that BEGINS inside the chained segment
-            if (seg == g.nseg - 1 && kt1 > kt0) {
-                chain_wait(ch, tm, lane);
-                chained = true;
-            }
-        }
     }
 
     // issue the DMA of the next k-tile of this block's range into ring stage `st`
@@ -385,30 +340,16 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
                 ++seg;
                 const Seg2 sg = g.seg[seg];
                 seg_left = sg.nkt / KSF;
-                if constexpr (CH == 2) {
-                    if (seg == g.nseg - 1) {  // the producer's rows: wait for this row block's counter, once per wave
-                        chain_wait(ch, tm, lane);
-                        chained = true;
-                    }
-                }
 #pragma unroll
                 for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + csrc * 16;
 #pragma unroll
                 for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + csrc * 16;
             }
             --seg_left;
-            if (CH == 2 && chained) {
 #pragma unroll
-                for (int i = 0; i < IA; ++i) {
-                    dma16_sc1(pa[i], sbase + i * NW * 1024);
-                    pa[i] += RBK;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < IA; ++i) {
-                    dma16(pa[i], sbase + i * NW * 1024);
-                    pa[i] += RBK;
-                }
+            for (int i = 0; i < IA; ++i) {
+                dma16(pa[i], sbase + i * NW * 1024);
+                pa[i] += RBK;
             }
         }
 #pragma unroll
@@ -541,42 +482,13 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         }
     }
 
-    const bool ran = g2_finish<TM, TN, WTM, WTN, NTH, CH == 1>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
-    if constexpr (CH == 1) {  // publish: this tile's write-through stores have left, then one count for its row block
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(ch.done + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if constexpr (CH == 2) {  // retire: the block that ran the epilogue is the tile's last (every k-slice is past its wait)
-        if (ran) {
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(ch.seen + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)(ch.cons - 1)) {  // the last consumer tile of this row block re-arms both counters
-                    __hip_atomic_store(ch.done + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(ch.seen + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
+    g2_finish<TM, TN, WTM, WTN, NTH, false>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2, int KS = 2>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 32 * KS];  // the ONLY LDS object of the kernel
-    gemm2_body<BM, BN, WM, WN, NST, CONV, EB, KS, 0>(g, blockIdx.x, gridDim.x, smem, Chain2{});
-}
-
-// chained launch: blocks [0, n_pre) run the producer problem, the others the consumer problem (same tile shape)
-struct ChainArgs2 {
-    Args2 main, pre;
-    Chain2 ch;
-    unsigned n_pre;
-};
-template <int BM, int BN, int WM, int WN, int NST, int KS>
-__global__ __launch_bounds__(WM* WN * 64) void gemm2_chain_kernel(ChainArgs2 a) {
-    __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 32 * KS];
-    if (blockIdx.x < a.n_pre) gemm2_body<BM, BN, WM, WN, NST, false, 2, KS, 1>(a.pre, blockIdx.x, a.n_pre, smem, a.ch);
-    else gemm2_body<BM, BN, WM, WN, NST, false, 2, KS, 2>(a.main, blockIdx.x - a.n_pre, gridDim.x - a.n_pre, smem, a.ch);
+    gemm2_body<BM, BN, WM, WN, NST, CONV, EB, KS>(g, blockIdx.x, gridDim.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1037,23 +949,6 @@ template <bool CONV> static void launch_cfg_k4(int c, const Args2& a, unsigned b
     }
 }
 
-// chained launches: the same block shapes (plain GEMM / K-segmented, bf16)
-static void launch_chain_cfg(int c, const ChainArgs2& a, unsigned blocks, hipStream_t st) {
-    switch (c) {
-        case CFG_128x64: hipLaunchKernelGGL((gemm2_chain_kernel<128, 64, 2, 2, 6, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_256x128: hipLaunchKernelGGL((gemm2_chain_kernel<256, 128, 4, 2, 4, 2>), dim3(blocks), dim3(512), 0, st, a); break;
-        case CFG_64x128: hipLaunchKernelGGL((gemm2_chain_kernel<64, 128, 2, 2, 6, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_D6: hipLaunchKernelGGL((gemm2_chain_kernel<128, 128, 2, 2, 6, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_64x64: hipLaunchKernelGGL((gemm2_chain_kernel<64, 64, 2, 2, 8, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_W8: hipLaunchKernelGGL((gemm2_chain_kernel<128, 128, 2, 4, 4, 2>), dim3(blocks), dim3(512), 0, st, a); break;
-        case CFG_64x64_K4: hipLaunchKernelGGL((gemm2_chain_kernel<64, 64, 2, 2, 4, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x64_K4: hipLaunchKernelGGL((gemm2_chain_kernel<128, 64, 2, 2, 4, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_64x128_K4: hipLaunchKernelGGL((gemm2_chain_kernel<64, 128, 2, 2, 4, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-        case CFG_128x128_K4: hipLaunchKernelGGL((gemm2_chain_kernel<128, 128, 2, 2, 4, 4>), dim3(blocks), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((gemm2_chain_kernel<128, 128, 2, 2, 4, 2>), dim3(blocks), dim3(256), 0, st, a); break;
-    }
-}
-
 // options (runtime.hip): gemm2 = 0 routes everything to gemm.hip's general kernel; g2_cfg / g2_splits force the block
 // tile and the split count (tools/mb_gemm2.py sweeps them)
 static bool g2_enabled() { return comat_option(COMAT_OPT_GEMM2) != 0; }
@@ -1344,58 +1239,6 @@ static bool fill_segments(Args2& a, const comat_gemm_params* p, const comat_gemm
     a.sC = p->sC1; a.sR = p->sR1; a.sBias = p->bias ? p->N : 0;
     fill_epi(a, p);
     return true;
-}
-
-// Two dependent K-segmented GEMMs (include/comat_hip.h: comat_gemm_chain) as ONE launch of the pipelined kernel: -> 1 when
-// taken, 0 when not eligible (the caller issues the two launches).  Option gemm2_chain: 0 never.
-int comat_gemm2_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
-                          const comat_gemm_segment* segs1, int nseg1, void* stream) {
-    if (!g2_enabled() || comat_option(COMAT_OPT_GEMM2_CHAIN) == 0 || !p1->ws) return 0;
-    ChainArgs2 a = {};
-    if (!fill_segments(a.pre, p0, segs0, nseg0) || !fill_segments(a.main, p1, segs1, nseg1)) return 0;
-    if (a.pre.M != a.main.M || p0->out_dtype != COMAT_BF16 || p0->bias2 || p1->bias2) return 0;
-    const int64_t b0 = p0->batch1 > 1 ? p0->batch1 : 1, b1 = p1->batch1 > 1 ? p1->batch1 : 1;
-    // the consumer's last segment reads rows of the producer's output with the producer's leading dimension
-    if (a.main.seg[nseg1 - 1].lda != p0->ldc * 2) return 0;
-    int c, s;
-    plan2(false, false, a.main.M, a.main.N, a.main.nkt, b1, p1->ws_bytes, &c, &s);
-    if (cfg_is_k4(c)) {
-        bool ok = true;
-        for (int i = 0; i < a.main.nseg; ++i) ok = ok && a.main.seg[i].nkt % 2 == 0;
-        for (int i = 0; i < a.pre.nseg; ++i) ok = ok && a.pre.seg[i].nkt % 2 == 0;
-        if (!ok) c = cfg_k2_twin(c);
-        else {
-            const int64_t n2 = a.main.nkt / 2;
-            if (s > n2) s = (int)(n2 > 0 ? n2 : 1);
-            s = (int)cdiv64(n2, cdiv64(n2, s));
-        }
-    }
-    const Cfg2 d = cfg_dims(c);
-    auto tiles = [&](Args2& x, int64_t batch, int splits) {
-        x.tiles_m = (int)cdiv64(x.M, d.bm);
-        x.tiles_n = (int)cdiv64(x.N, d.bn);
-        x.ntiles = (int64_t)x.tiles_m * x.tiles_n * batch;
-        x.splits = splits;
-        x.order = 0;
-        x.ws = (float*)p1->ws;
-        x.vec = epi_vec_ok(x.ep, x.N, x.sC, x.sR, x.sBias, x.M);
-    };
-    tiles(a.main, b1, s);
-    tiles(a.pre, b0, 1);
-    if (!a.pre.vec) return 0;  // the write-through epilogue exists in the 16-byte form only
-    const int64_t tm = a.main.tiles_m;
-    if (a.main.ntiles + 2 * tm + 2 > WS_COUNTERS) return 0;
-    unsigned* cnt = (unsigned*)p1->ws;
-    a.ch.done = cnt + WS_COUNTERS - 2 - 2 * tm;  // behind the consumer's split-K tickets [0, ntiles)
-    a.ch.seen = a.ch.done + tm;
-    a.ch.err = cnt + WS_COUNTERS - 1;
-    a.ch.need = (int)(a.pre.tiles_n * b0);
-    a.ch.cons = (int)(a.main.tiles_n * b1);
-    a.n_pre = (unsigned)a.pre.ntiles;
-    const int64_t blocks = (int64_t)a.n_pre + a.main.ntiles * s;
-    if (blocks >= (1ll << 31)) return 0;
-    launch_chain_cfg(c, a, (unsigned)blocks, (hipStream_t)stream);
-    return 1;
 }
 
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream) {

@@ -1,5 +1,4 @@
-// gemm3.hip — the "lean" MFMA GEMM for the launch-latency-bound products of the step, and CHAINED launches (a producer
-// GEMM and the K-segmented GEMM that consumes its output in ONE launch).
+// gemm3.hip — the "lean" MFMA GEMM for the launch-latency-bound products of the step with very few rows.
 //
 // Why a second kernel.  profiles/r03_z_gap_table.txt: 3 208 of the 4 876 MFMA launches of a C2 step have a roofline time
 // under 2 us and take 36.9 ms - the LoRA low-rank projections (M x 128 x C: 8 us for a 0.2 us problem), the K-segmented
@@ -21,18 +20,9 @@
 // The lane -> k assignment inside a chunk (lane (r, h) of MFMA k-step j holds k = 32 h + 8 j .. + 8 of row r) is the same
 // for both operands, so - as in gemm2.hip - the permutation cancels.
 //
-// CHAINED launch (comat_gemm_chain).  Every LoRA projection is two dependent products: h = s x D^T (M x r, tiny) and
-// y = [x | h] [W | U]^T (training_utils/pipeline.py:84-115: `up(down(x))` added to the frozen Linear); the backward pass
-// has the same shape (u = s g U, then dx = [g | u] [W^T | D^T]^T).  As two launches the small one costs 5 - 8 us plus a
-// kernel boundary, 1 100 times per step.  Here the workgroups with the lowest block ids compute the producer's tiles
-// (write-through stores, then one counter per 32/64-row block), the others compute the consumer's tiles and need the
-// producer's rows only for their LAST k-segment: by the time a consumer wave gets there - after the frozen part of its
-// range - the rows are long done, so the wait is a formality and the producer overlaps the consumer's main product.
-// Dispatch order makes it safe: a workgroup is only ever waiting for workgroups with LOWER block ids, which every XCD's
-// dispatcher has started before it (and the spin is bounded: a give-up raises a flag the host checks in tests).
-// Visibility: producer tiles are stored sc1 (write-through) and drained (vmcnt(0)) before the counter, consumers poll the
-// counter relaxed and read the rows with sc1 loads (cdna_hip_programming.md guideline 16, R1 - the split-K protocol of
-// gemm_shared.h).  The counters re-arm themselves (the last consumer of a row block zeroes them).
+// (Round 4 also ran "chained" launches on this kernel and on gemm2.hip - a producer GEMM and the K-segmented GEMM consuming its
+// output in one launch, for the LoRA pairs; measured no faster than two launches (profiles/r04_c_*), and the pairs themselves
+// left the dependent chain in round 5 (merged weights).  The code is on branch exp/gemm-chain.)
 #include "gemm_shared.h"
 
 namespace {
@@ -40,7 +30,6 @@ namespace {
 constexpr int CKB = 128;        // bytes of k per chunk and operand row (64 bf16)
 constexpr int CKE = 64;         // k elements per chunk
 constexpr int MAXSEG3 = 8;
-constexpr unsigned SPIN_LIMIT = 1u << 24;
 
 struct Seg3 {
     const char* A;
@@ -61,13 +50,6 @@ struct Prob3 {  // one (batched) K-segmented GEMM
 
 struct Args3 {
     Prob3 main;
-    Prob3 pre;          // producer of a chained launch (n_pre > 0): main's LAST segment reads pre's output rows
-    int n_pre;          // producer work items = the first n_pre workgroups
-    int need;           // producer tiles per row block (pre.tiles_n * pre.batch)
-    int cons;           // consumer tiles per row block (main.tiles_n * main.batch)
-    unsigned* done;     // [tiles_m] producer tiles finished, per row block (zero before the launch, re-armed by it)
-    unsigned* seen;     // [tiles_m] consumer tiles finished
-    unsigned* err;      // set to 1 when a spin gave up
 };
 
 template <int TM, int TN>
@@ -84,10 +66,9 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(Args3 g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const bool is_pre = (int)blockIdx.x < g.n_pre;  // wave-uniform
-    const Prob3& P = is_pre ? g.pre : g.main;
+    const Prob3& P = g.main;
 
-    unsigned lin = is_pre ? blockIdx.x : (unsigned)xcd_chunk_map((int64_t)blockIdx.x - g.n_pre, (int64_t)gridDim.x - g.n_pre);
+    unsigned lin = (unsigned)xcd_chunk_map((int64_t)blockIdx.x, (int64_t)gridDim.x);
     const int tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)P.tiles_n));
     lin /= (unsigned)P.tiles_n;
     const int tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)P.tiles_m));
@@ -112,16 +93,11 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(Args3 g) {
     }
 
     // ---- chunk cursor over the segment list ------------------------------------------------------------------------------------
-    // A consumer wave of a chained launch runs its chunks in two phases: the chunks of the ordinary segments (plain global
-    // loads), then the chunks of the LAST segment, whose A rows another workgroup of this launch produced (sc1 buffer loads,
-    // after the row block's counter says they are complete).  Each phase is its own software pipeline: the steady-state loop
-    // issues the loads of two chunks unconditionally (the compiler's vmcnt bookkeeping is exact only without branches
-    // around the loads).
+    // The steady-state loop issues the loads of two chunks unconditionally (the compiler's vmcnt bookkeeping is exact only
+    // without branches around the loads).
     int seg = 0, seg_left = 0;
     const char* pa[TM];
     const char* pb[TN];
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.seg[0].A, 0, 0x7ffffff0, 0x00020000);
-    int voff[TM];
     auto enter_segment = [&](int s, int skip) {  // position the cursor at chunk `skip` of segment s
         const Seg3& sg = P.seg[s];
         seg = s;
@@ -147,22 +123,6 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(Args3 g) {
             pb[b] += CKB;
         }
     };
-    auto load_chained = [&](Frags<TM, TN>& f) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                f.x[a][j] = __builtin_bit_cast(short8_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff[a] + 16 * j, 0, /*sc1*/ 16));
-            voff[a] += CKB;
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) f.w[b][j] = *(const short8_t*)(pb[b] + 16 * j);
-            pb[b] += CKB;
-        }
-    };
-
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -200,41 +160,14 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(Args3 g) {
     };
 
     // ---- main loop ------------------------------------------------------------------------------------------------------------
-    const bool has_chain = !is_pre && g.n_pre > 0;
-    const int tail = has_chain ? P.seg[P.nseg - 1].nch : 0;  // chunks of the chained segment (the LAST chunks of the list)
-    const int n_plain_all = P.nch - tail;
-    int n_plain = n_plain_all - c0;
-    n_plain = n_plain < 0 ? 0 : (n_plain > cnt ? cnt : n_plain);
-    const int n_chain = cnt - n_plain;
-    if (n_plain > 0) {
+    if (cnt > 0) {
         int s = 0, skip = c0;
         while (s + 1 < P.nseg && skip >= P.seg[s].nch) {
             skip -= P.seg[s].nch;
             ++s;
         }
         enter_segment(s, skip);
-        run(n_plain, load_plain);
-    }
-    if (n_chain > 0) {  // wave-uniform
-        const Seg3& sg = P.seg[P.nseg - 1];
-        const int skip = c0 + n_plain - n_plain_all;  // first chained chunk of this wave
-        // wait until the producer's tiles of this row block are complete (lane 0 polls: relaxed, agent scope)
-        if (lane == 0) {
-            unsigned n = 0;
-            while (__hip_atomic_load(g.done + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)g.need) {
-                if (++n > SPIN_LIMIT) {
-                    __hip_atomic_store(g.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.A + z * sg.sA), 0, 0x7ffffff0, 0x00020000);
-#pragma unroll
-        for (int a = 0; a < TM; ++a) voff[a] = (int)(arow[a] * sg.lda + (int64_t)skip * CKB + h * 64);
-#pragma unroll
-        for (int b = 0; b < TN; ++b) pb[b] = sg.B + z * sg.sB + brow[b] * sg.ldb + (int64_t)skip * CKB + h * 64;
-        run(n_chain, load_chained);
+        run(cnt, load_plain);
     }
 
     // ---- the NW partial tiles meet in LDS: image [wave][tile][quad][lane] of 16 bytes ----------------------------------------
@@ -272,29 +205,9 @@ __global__ __launch_bounds__(NW * 64) void gemm3_kernel(Args3 g) {
         const int a = t / TN, b = t % TN;
         const int64_t m = m0 + a * 32 + r;
         const int64_t nb = n0 + b * 32 + 16 * hf + 8 * h;
-        if (m < P.M && nb < P.N) {
-            if (is_pre) epilogue_run<true>(ep, v, m, nb, P.N, vec);
-            else epilogue_run<false>(ep, v, m, nb, P.N, vec);
-        }
+        if (m < P.M && nb < P.N) epilogue_run<false>(ep, v, m, nb, P.N, vec);
     }
 
-    // ---- chained launch: publish / retire ------------------------------------------------------------------------------------
-    if (g.n_pre > 0) {
-        if (is_pre) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(g.done + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __syncthreads();  // every wave of this tile is past its wait
-            if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(g.seen + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)(g.cons - 1)) {  // the last consumer of this row block re-arms both counters
-                    __hip_atomic_store(g.done + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(g.seen + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -414,35 +327,6 @@ int comat_gemm3_try(const comat_gemm_params* p, const comat_gemm_segment* segs, 
     const int c = pick_cfg(a.main);
     set_tiles(a.main, cfg3_dims(c));
     const int64_t blocks = (int64_t)a.main.tiles_m * a.main.tiles_n * a.main.batch;
-    if (blocks >= (1ll << 31)) return 0;
-    launch3(c, a, (unsigned)blocks, (hipStream_t)stream);
-    return 5;
-}
-
-// Two dependent K-segmented GEMMs (p0 / segs0, then p1 / segs1 whose LAST segment's A operand is p0's output) - in one launch
-// when the lean kernel takes both (-> 5), else 0: the caller issues them one after the other.
-int comat_gemm3_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
-                          const comat_gemm_segment* segs1, int nseg1, void* stream) {
-    if (comat_option(COMAT_OPT_GEMM3_CHAIN) == 0) return 0;
-    Args3 a = {};
-    if (!fill_prob(a.pre, p0, segs0, nseg0, true) || !fill_prob(a.main, p1, segs1, nseg1, true)) return 0;
-    if (a.pre.M != a.main.M || !a.pre.vec || a.pre.ep.out_dt != COMAT_BF16 || !p1->ws) return 0;
-    if (comat_option(COMAT_OPT_GEMM3_CHAIN) == 1 && !g3_wants(a.main)) return 0;
-    // the consumer's last segment must read inside the producer's output (batch items: column blocks of it)
-    const Seg3& last = a.main.seg[a.main.nseg - 1];
-    if (last.lda != a.pre.ep.ldc * 2 || a.pre.M * a.pre.ep.ldc * 2 >= (1ll << 31)) return 0;
-    const int c = pick_cfg(a.main);
-    const Cfg3 d = cfg3_dims(c);
-    set_tiles(a.main, d);
-    set_tiles(a.pre, d);
-    if (a.main.tiles_m != a.pre.tiles_m || 2 * (int64_t)a.main.tiles_m > WS_COUNTERS) return 0;
-    a.n_pre = a.pre.tiles_m * a.pre.tiles_n * a.pre.batch;
-    a.need = a.pre.tiles_n * a.pre.batch;
-    a.cons = a.main.tiles_n * a.main.batch;
-    a.done = (unsigned*)p1->ws;
-    a.seen = (unsigned*)p1->ws + WS_COUNTERS / 2;
-    a.err = (unsigned*)p1->ws + WS_COUNTERS - 1;
-    const int64_t blocks = (int64_t)a.n_pre + (int64_t)a.main.tiles_m * a.main.tiles_n * a.main.batch;
     if (blocks >= (1ll << 31)) return 0;
     launch3(c, a, (unsigned)blocks, (hipStream_t)stream);
     return 5;

@@ -99,8 +99,8 @@ union Pack16 {
 };
 
 // 8 consecutive output columns n .. n+7 of output row m
-// WT: the 16-byte stores are WRITE-THROUGH (sc1): the tile is read by other workgroups of the SAME launch (gemm3.hip: the
-// producer phase of a chained launch), whose sc1 loads then see it without any fence (cdna_hip_programming.md, guideline 16)
+// WT: the 16-byte stores are WRITE-THROUGH (sc1): for a tile that other workgroups of the SAME launch read with sc1 loads
+// (no fence needed: cdna_hip_programming.md, guideline 16).  No caller sets it today (the chained launches of round 4 did).
 template <bool WT = false>
 __device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m, int64_t n, int64_t N, bool vec) {
 #pragma unroll
@@ -205,9 +205,5 @@ constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters 
 int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream);
 int comat_gemm2_try_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, void* stream);
 int comat_gemm2_try_conv(const comat_conv_params* p, void* stream);
-int comat_gemm2_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
-                          const comat_gemm_segment* segs1, int nseg1, void* stream);
-// gemm3.hip: the lean k-parallel-wave kernel (-> 5 when it took the problem, 0 otherwise) and chained launches
+// gemm3.hip: the lean k-parallel-wave kernel (-> 5 when it took the problem, 0 otherwise)
 int comat_gemm3_try(const comat_gemm_params* p, const comat_gemm_segment* segs, int nseg, bool bias_per_batch, void* stream);
-int comat_gemm3_try_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int nseg0, const comat_gemm_params* p1,
-                          const comat_gemm_segment* segs1, int nseg1, void* stream);

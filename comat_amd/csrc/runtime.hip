@@ -86,10 +86,6 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // decoder), 2 every eligible problem (tests, microbenchmarks)
     {"g3_cfg", "COMAT_G3_CFG", 0, 0, false},              // force its tile shape: 1 32x32 / 8 waves, 2 64x32 / 8, 3 32x64 / 8,
                                                           // 4 64x64 / 4, 5 64x64 / 8, 6 32x32 / 4, 7 64x32 / 4, 8 32x32 / 16, 9 64x32 / 16
-    {"gemm3_chain", "COMAT_GEMM3_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch on the lean kernel: 0 never (two
-                                                          // launches), 1 where the lean kernel's rule wants the consumer, 2 always
-    {"gemm2_chain", "COMAT_GEMM2_CHAIN", 0, 0, false},    // comat_gemm_chain as ONE launch of the pipelined kernel (producer
-                                                          // tiles first, the consumer's last segment waits for its row block)
 };
 }  // namespace
 

@@ -975,17 +975,6 @@ def _uniform_stride(ts):
     return step // t0.element_size()
 
 
-# The two dependent products of a LoRA projection - h = s x D^T then y = [x | h] [W | U]^T, and in the backward pass u = s g U
-# then dx = [g | u] [W^T | D^T]^T - handed to the library as ONE chained call (comat_gemm_chain: one launch where its lean
-# kernel takes both, else the two launches).  COMAT_LORA_CHAIN=0 keeps the separate calls of rounds 1-3.
-_lora_chain = os.environ.get("COMAT_LORA_CHAIN", "0") == "1"
-
-
-def set_lora_chain(flag: bool):
-    global _lora_chain
-    _lora_chain = bool(flag)
-
-
 class _LoRAGroupLinear(Function):
     """(y_1 .. y_G) with y_i = x W_i^T + b_i + (h_i) U_i^T (+ residual),  h = s * x [D_1; ..; D_G]^T.
     Forward: one GEMM for h, then ONE K-segmented GEMM per projection ([x | h_i] . [W_i | U_i]^T).
@@ -1008,25 +997,8 @@ class _LoRAGroupLinear(Function):
             residual = _c(residual)
         sw, su = _uniform_stride([lin.w for lin in lins]), _uniform_stride(ucs)
         use8 = [_use_fp8(lin, Kd) for lin in lins]
-        down = dict(segs=[(x, dc, Kd, Kd, Kd)], Cout=h, M=M, N=Gr, ldc=Gr, alpha=grp.scale)
-        batched = sw is not None and su is not None and residual is None and all(lin.bias is None for lin in lins)
-        chain = _lora_chain and not any(use8) and hasattr(k, "gemm_chain") and (batched or G == 1)
-        if not chain:
-            k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
-        if chain and batched:
-            N = lins[0].out_features
-            ys = x.new_empty((G, M, N))
-            k.gemm_chain(down, dict(segs=[(x, lins[0].w, Kd, Kd, Kd, 0, sw), (h, ucs[0], r, Gr, r, r, su)], Cout=ys, M=M, N=N,
-                                    ldc=N, batch=G, sC=M * N))
-            ys = list(ys.unbind(0))
-        elif chain:
-            lin = lins[0]
-            N = lin.out_features
-            y = x.new_empty((M, N))
-            k.gemm_chain(down, dict(segs=[(x, lin.w, Kd, Kd, Kd), (h, ucs[0], r, Gr, r)], Cout=y, M=M, N=N, ldc=N, bias=lin.bias,
-                                    R=residual, ldr=N, beta=1.0 if residual is not None else 0.0))
-            ys = [y]
-        elif any(use8):
+        k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
+        if any(use8):
             # frozen part on the fp8 MFMA (x quantised once for the whole group), low-rank part added in the storage dtype
             x8, sx = k.fp8_quantize(x)
             ys = []
@@ -1086,14 +1058,7 @@ class _LoRAGroupLinear(Function):
         segs = [(gs[i], lin.wt, lin.out_features, lin.out_features, lin.out_features) for i, lin in enumerate(lins)]
         segs.append((u, dct, Gr, Gr, Gr))
         dx = x.new_empty((M, Kd)) if ctx.needs_input_grad[0] else None
-        chain = _lora_chain and dx is not None and hasattr(k, "gemm_chain") and (batched or G == 1)
-        if chain:  # u = s * g U and dx = [g | u] [W^T | D^T]^T as one chained call
-            if batched:
-                up = dict(segs=[(gs[0], uts[0], N0, N0, N0, sg, su)], Cout=u, M=M, N=r, ldc=Gr, alpha=grp.scale, batch=G, sC=r)
-            else:
-                up = dict(segs=[(gs[0], uts[0], N0, N0, N0)], Cout=u, M=M, N=r, ldc=Gr, alpha=grp.scale)
-            k.gemm_chain(up, dict(segs=segs, Cout=dx, M=M, N=Kd, ldc=Kd))
-        elif batched:  # u[:, i*r:(i+1)*r] = s * g_i U_i for all i
+        if batched:  # u[:, i*r:(i+1)*r] = s * g_i U_i for all i
             k.gemm(gs[0], uts[0], u, M, r, N0, N0, N0, Gr, alpha=grp.scale, batch=(G, 1), sA=(sg, 0), sB=(su, 0),
                    sC=(r, 0))
         else:
@@ -1142,7 +1107,7 @@ class _LoRAGroupLinear(Function):
                     _side_dirty.append((x.device, side))
                 _side_keep.append((gs, h, u, x))  # keep the operands alive until join_side_streams()
                 _queue_join()
-        if dx is not None and not chain:
+        if dx is not None:
             k.gemm_segments(segs, dx, M, Kd, Kd)
         return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
 

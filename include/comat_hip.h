@@ -123,20 +123,6 @@ typedef struct {
 } comat_gemm_segment;
 int comat_gemm_segments(const comat_gemm_params* p, const comat_gemm_segment* segs, int32_t nseg, void* stream);
 
-/* Chained K-segmented GEMMs:  comat_gemm_segments(p0, segs0)  followed by  comat_gemm_segments(p1, segs1)  whose LAST
- * segment's A operand lies inside p0's output - the same results as the two calls in stream order (the library falls back to
- * exactly that), in ONE launch when its lean kernel takes both problems (bf16 k-contiguous operands, every segment a multiple
- * of 64 long, 16-byte aligned rows, equal M, p0's output bf16 with 16-byte aligned rows, p1->ws given).  Row m of the
- * consumer's last segment may depend on row m of the producer's output only (all of the producer's columns / batch items).
- * Every LoRA projection of the step is such a pair (training_utils/pipeline.py:84-115: `up(down(x))` added to a frozen
- * nn.Linear):  h = s x D^T, then  y = [x | h] [W | U]^T;  and its backward:  u = s g U, then  dx = [g | u] [W^T | D^T]^T -
- * ~1 100 pairs per SD1.5 step whose small first product otherwise costs a launch of its own (5 - 8 us + a kernel
- * boundary for a 0.2 us problem).  In the chained launch the first workgroups compute the producer's tiles (write-through
- * stores + one counter per row block, re-armed by the launch: `p1->ws` as for comat_gemm, counters zeroed once by the caller),
- * the others the consumer's tiles, waiting for their row block's counter only before their last segment. */
-int comat_gemm_chain(const comat_gemm_params* p0, const comat_gemm_segment* segs0, int32_t nseg0,
-                     const comat_gemm_params* p1, const comat_gemm_segment* segs1, int32_t nseg1, void* stream);
-
 /* Grouped k-major products:  C_p[M_p, N_p] += A_p^T B_p  for nprob INDEPENDENT problems, fp32 accumulation in place.
  *   A_p is stored [K_p, M_p] (lda = element stride between k-rows), B_p is stored [K_p, N_p], both bf16; C_p is fp32
  *   row-major with leading dimension ldc.  M_p, N_p multiples of 8 (>= 8); any K_p >= 1; lda, ldb multiples of 8, ldc of 4;

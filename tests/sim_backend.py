@@ -96,10 +96,6 @@ class SimKernels:
             acc = acc + beta * _v(R, (batch, M, N), (sR, ldr, 1)).float()
         _v(Cout, (batch, M, N), (sC, ldc, 1)).copy_(acc.to(Cout.dtype))
 
-    def gemm_chain(self, pre, main):
-        self.gemm_segments(**pre)
-        self.gemm_segments(**main)
-
     @staticmethod
     def tt_group_ok(A, B, Cacc, M, N, K, lda, ldb, ldc):
         return (A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and Cacc.dtype == torch.float32

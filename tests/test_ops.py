@@ -779,7 +779,7 @@ def test_adamw_with_clip(dev):
 
 
 # the library's defaults for the options whose default moved in round 4 (runtime.hip)
-DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, gemm3_chain=0, gemm2_chain=0)
+DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1)
 
 
 def _set_opts(**kw):
@@ -793,8 +793,7 @@ def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
     _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=DEFAULT_OPTS['flash_xcd'],
-              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0, gemm3_chain=DEFAULT_OPTS['gemm3_chain'],
-              gemm2_chain=DEFAULT_OPTS['gemm2_chain'])
+              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
@@ -1214,175 +1213,6 @@ def test_gemm3_lean_kernel(hip, cfg, default_opts):
     out2 = torch.empty_like(outs[1])
     k.gemm_segments([(x, W[0], K_, K_, K_, 0, N * K_), (H_, U[0], r, G * r, r, r, N * r)], out2, M, N, N, batch=G, sC=M * N)
     assert torch.equal(out2, outs[1])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 4, 5, 7, 8])
-def test_gemm_chain_in_one_launch(hip, cfg, default_opts):
-    """comat_gemm_chain on the lean kernel (option gemm3_chain = 2): the producer's tiles and the consumer's in ONE launch,
-    the consumer's last segment reading the producer's rows through the in-launch hand-off - the LoRA forward pair (plain and
-    batched q / k / v form, with bias + residual) and the backward pair (batched producer, G + 1 segments), at the step's shapes
-    and at ragged ones.  Same bits as the two lean launches in stream order (same tiles, same summation order), over repeated
-    calls with changing data (the counters re-arm), and the give-up flag of the bounded spin stays clear."""
-    dtype = torch.bfloat16
-    k = ops.kernels()
-    from comat_amd import _hip
-    r = 128
-    for it, (M, Kd, N, G) in enumerate(((512, 1280, 1280, 3), (2048, 640, 640, 1), (8192, 320, 320, 3), (154, 768, 1280, 2), (4096, 320, 320, 1),
-                                        (512, 1280, 1280, 1))):
-        Gr = G * r
-        x = dv(rnd(M, Kd, dtype=dtype, seed=10 + it, scale=0.3), hip, dtype)
-        D = dv(rnd(Gr, Kd, dtype=dtype, seed=20 + it, scale=0.05), hip, dtype)
-        W = dv(rnd(G, N, Kd, dtype=dtype, seed=30 + it, scale=0.05), hip, dtype)
-        U = dv(rnd(G, N, r, dtype=dtype, seed=40 + it, scale=0.1), hip, dtype)
-        bias = dv(rnd(N, seed=3), hip, torch.float32) if G == 1 else None
-        R = dv(rnd(M, N, dtype=dtype, seed=4), hip, dtype) if G == 1 else None
-        got = {}
-        for mode in (0, 2, 2):
-            _set_opts(gemm3=2, g3_cfg=cfg, gemm3_chain=mode)
-            h = torch.full((M, Gr), float("nan"), dtype=dtype, device=hip)
-            y = torch.full((G, M, N), float("nan"), dtype=dtype, device=hip)
-            k.gemm_chain(dict(segs=[(x, D, Kd, Kd, Kd)], Cout=h, M=M, N=Gr, ldc=Gr, alpha=0.5),
-                         dict(segs=[(x, W[0], Kd, Kd, Kd, 0, N * Kd), (h, U[0], r, Gr, r, r, N * r)], Cout=y, M=M, N=N, ldc=N, batch=G,
-                              sC=M * N, bias=bias, R=R, ldr=N, beta=1.0 if R is not None else 0.0))
-            assert _hip.last_gemm_kernel() == 5
-            torch.cuda.synchronize()
-            if mode in got:
-                assert torch.equal(got[mode][0], h) and torch.equal(got[mode][1], y), "chained launch is not reproducible"
-            got[mode] = (h, y)
-        assert torch.isfinite(got[2][1].float()).all()
-        if cfg:  # forced tile shape: the chained launch runs the very tiles of the two launches
-            assert torch.equal(got[0][0], got[2][0]), f"forward pair {M}x{Kd}->{N} G={G}: producer output differs"
-            assert torch.equal(got[0][1], got[2][1]), f"forward pair {M}x{Kd}->{N} G={G}: chained result differs from two launches"
-        else:    # chosen per problem: the producer alone may get another k-split than inside the chain (summation order)
-            check(got[2][0], got[0][0].float(), dtype, "chained producer vs its own launch")
-            check(got[2][1], got[0][1].float(), dtype, "chained consumer vs its own launch", factor=2)
-        href = 0.5 * x.float() @ D.float().t()
-        check(got[2][0], href, dtype, "chained producer")
-        yref = torch.einsum("mk,gnk->gmn", x.float(), W.float()) + torch.einsum("mgr,gnr->gmn", got[2][0].float().reshape(M, G, r), U.float())
-        if bias is not None:
-            yref = yref + bias + R.float()
-        check(got[2][1], yref, dtype, "chained consumer", factor=2)
-        # backward pair: u_i = s g_i U_i (batched producer), dx = sum_i g_i W_i^T' + u D^T' (G + 1 segments)
-        g = dv(rnd(G, M, N, dtype=dtype, seed=50 + it, scale=0.3), hip, dtype)
-        Ut = dv(rnd(G, r, N, dtype=dtype, seed=60 + it, scale=0.1), hip, dtype)
-        Wt = dv(rnd(G, Kd, N, dtype=dtype, seed=70 + it, scale=0.05), hip, dtype)
-        Dt = dv(rnd(Kd, Gr, dtype=dtype, seed=80 + it, scale=0.05), hip, dtype)
-        got = {}
-        for mode in (0, 2):
-            _set_opts(gemm3=2, g3_cfg=cfg, gemm3_chain=mode)
-            u = torch.full((M, Gr), float("nan"), dtype=dtype, device=hip)
-            dx = torch.full((M, Kd), float("nan"), dtype=dtype, device=hip)
-            segs = [(g[i], Wt[i], N, N, N) for i in range(G)] + [(u, Dt, Gr, Gr, Gr)]
-            k.gemm_chain(dict(segs=[(g[0], Ut[0], N, N, N, M * N, r * N)], Cout=u, M=M, N=r, ldc=Gr, alpha=0.5, batch=G, sC=r),
-                         dict(segs=segs, Cout=dx, M=M, N=Kd, ldc=Kd))
-            assert _hip.last_gemm_kernel() == 5
-            got[mode] = (u, dx)
-        torch.cuda.synchronize()
-        if cfg:
-            assert torch.equal(got[0][0], got[2][0]) and torch.equal(got[0][1], got[2][1]), f"backward pair {M} G={G}: chained result differs"
-        uref = 0.5 * torch.einsum("gmn,grn->mgr", g.float(), Ut.float()).reshape(M, Gr)
-        check(got[2][0], uref, dtype, "chained backward producer")
-        dref = torch.einsum("gmn,gkn->mk", g.float(), Wt.float()) + got[2][0].float() @ Dt.float().t()
-        check(got[2][1], dref, dtype, "chained backward consumer", factor=2)
-    ws = k._workspace(hip)
-    assert int(ws.view(torch.int32)[_hip.WS_COUNTER_BYTES // 4 - 1]) == 0, "a consumer's bounded spin gave up"
-    assert int(ws.view(torch.int32)[: _hip.WS_COUNTER_BYTES // 4].abs().sum()) == 0, "the chained launches left counters armed"
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("g2cfg", [0, 1, 6, 8, 10])
-def test_gemm_chain_on_the_pipelined_kernel(hip, g2cfg, default_opts):
-    """comat_gemm_chain as ONE launch of the pipelined kernel (option gemm2_chain = 1; kernel id 6): producer tiles first, the
-    consumer's last segment waits for its row block's counter and fetches the rows with sc1 DMA.  Against the fp32 reference
-    and against the two launches (the producer runs with the consumer's tile shape and without a k-split inside the chain, so
-    the comparison is to rounding, not to the bit); repeated calls give the same bits (counters re-arm, no stale rows), the
-    give-up flag stays clear and no counter is left armed.  LoRA forward pairs (plain / batched, bias + residual) and backward
-    pairs at the step's shapes and ragged ones, with the block shape chosen by the plan table (0) or forced."""
-    dtype = torch.bfloat16
-    k = ops.kernels()
-    from comat_amd import _hip
-    r = 128
-    for it, (M, Kd, N, G) in enumerate(((512, 1280, 1280, 3), (2048, 640, 640, 1), (8192, 320, 320, 3), (154, 768, 1280, 2), (4096, 320, 320, 1),
-                                        (512, 1280, 1280, 1), (100, 320, 640, 1))):
-        Gr = G * r
-        x = dv(rnd(M, Kd, dtype=dtype, seed=10 + it, scale=0.3), hip, dtype)
-        D = dv(rnd(Gr, Kd, dtype=dtype, seed=20 + it, scale=0.05), hip, dtype)
-        W = dv(rnd(G, N, Kd, dtype=dtype, seed=30 + it, scale=0.05), hip, dtype)
-        U = dv(rnd(G, N, r, dtype=dtype, seed=40 + it, scale=0.1), hip, dtype)
-        bias = dv(rnd(N, seed=3), hip, torch.float32) if G == 1 else None
-        R = dv(rnd(M, N, dtype=dtype, seed=4), hip, dtype) if G == 1 else None
-        g = dv(rnd(G, M, N, dtype=dtype, seed=50 + it, scale=0.3), hip, dtype)
-        Ut = dv(rnd(G, r, N, dtype=dtype, seed=60 + it, scale=0.1), hip, dtype)
-        Wt = dv(rnd(G, Kd, N, dtype=dtype, seed=70 + it, scale=0.05), hip, dtype)
-        Dt = dv(rnd(Kd, Gr, dtype=dtype, seed=80 + it, scale=0.05), hip, dtype)
-        got = {}
-        for rep, mode in enumerate((0, 1, 1)):
-            _set_opts(gemm3=0, gemm3_chain=0, gemm2_chain=mode, g2_cfg=g2cfg)
-            h = torch.full((M, Gr), float("nan"), dtype=dtype, device=hip)
-            y = torch.full((G, M, N), float("nan"), dtype=dtype, device=hip)
-            k.gemm_chain(dict(segs=[(x, D, Kd, Kd, Kd)], Cout=h, M=M, N=Gr, ldc=Gr, alpha=0.5),
-                         dict(segs=[(x, W[0], Kd, Kd, Kd, 0, N * Kd), (h, U[0], r, Gr, r, r, N * r)], Cout=y, M=M, N=N, ldc=N, batch=G,
-                              sC=M * N, bias=bias, R=R, ldr=N, beta=1.0 if R is not None else 0.0))
-            assert _hip.last_gemm_kernel() == (6 if mode else 1), _hip.last_gemm_kernel()
-            u = torch.full((M, Gr), float("nan"), dtype=dtype, device=hip)
-            dx = torch.full((M, Kd), float("nan"), dtype=dtype, device=hip)
-            segs = [(g[i], Wt[i], N, N, N) for i in range(G)] + [(u, Dt, Gr, Gr, Gr)]
-            k.gemm_chain(dict(segs=[(g[0], Ut[0], N, N, N, M * N, r * N)], Cout=u, M=M, N=r, ldc=Gr, alpha=0.5, batch=G, sC=r),
-                         dict(segs=segs, Cout=dx, M=M, N=Kd, ldc=Kd))
-            assert _hip.last_gemm_kernel() == (6 if mode else 1), _hip.last_gemm_kernel()
-            torch.cuda.synchronize()
-            if rep == 2:
-                for a_, b_ in zip(got[1], (h, y, u, dx)):
-                    assert torch.equal(a_, b_), "chained launch is not reproducible"
-            got[mode] = (h, y, u, dx)
-        h, y, u, dx = got[1]
-        assert all(torch.isfinite(t.float()).all() for t in got[1])
-        check(h, 0.5 * x.float() @ D.float().t(), dtype, "chained producer (forward)")
-        yref = torch.einsum("mk,gnk->gmn", x.float(), W.float()) + torch.einsum("mgr,gnr->gmn", h.float().reshape(M, G, r), U.float())
-        if bias is not None:
-            yref = yref + bias + R.float()
-        check(y, yref, dtype, f"chained consumer (forward) M={M} G={G}", factor=2)
-        check(u, 0.5 * torch.einsum("gmn,grn->mgr", g.float(), Ut.float()).reshape(M, Gr), dtype, "chained producer (backward)")
-        check(dx, torch.einsum("gmn,gkn->mk", g.float(), Wt.float()) + u.float() @ Dt.float().t(), dtype,
-              f"chained consumer (backward) M={M} G={G}", factor=2)
-        for name, a_, b_ in zip(("h", "y", "u", "dx"), got[0], got[1]):
-            check(b_, a_.float(), dtype, f"chained vs two launches: {name}", factor=2)
-    ws = k._workspace(hip)
-    cnt = ws.view(torch.int32)[: _hip.WS_COUNTER_BYTES // 4]
-    assert int(cnt[-1]) == 0, "a consumer's bounded spin gave up"
-    assert int(cnt.abs().sum()) == 0, "the chained launches left counters armed"
-
-
-@pytest.mark.gpu
-def test_lora_group_linear_chain_matches_separate_calls(hip, default_opts):
-    """ops.lora_group_linear with the chained library call (lean kernel, one launch per pair) against the separate calls of
-    rounds 1-3 on the pipelined kernel: outputs, input gradient and the LoRA weight gradients agree to bf16 accuracy."""
-    dtype = torch.bfloat16
-    g = torch.Generator().manual_seed(3)
-    M, K, N, r = 512, 1280, 1280, 128
-    ws = [torch.randn(N, K, generator=g) * K ** -0.5 for _ in range(3)]
-    lins = ops.frozen_linear_group(ws, [None] * 3, dtype, hip)
-    out_lin = ops.FrozenLinear(torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), dtype, hip)
-    spec = [[(f"d{i}", f"u{i}", torch.randn(r, K, generator=g) * K ** -0.5, torch.randn(N, r, generator=g) * 0.05) for i in range(3)],
-            [("do", "uo", torch.randn(r, K, generator=g) * K ** -0.5, torch.randn(N, r, generator=g) * 0.05)]]
-    res = {}
-    for chain in (False, True, "pipelined"):
-        ops.set_lora_chain(bool(chain))
-        _set_opts(gemm3=2 if chain is True else 0, gemm3_chain=2 if chain is True else 0, gemm2_chain=1 if chain == "pipelined" else 0)
-        store = ops.LoRAStore(spec, dtype, hip)
-        x = (torch.randn(M, K, generator=torch.Generator().manual_seed(9))).to(hip, dtype).requires_grad_(True)
-        q, k_, v = ops.lora_group_linear(x, lins, store.groups[0])
-        o = ops.lora_group_linear(q + k_ * 0.5 + v * 0.25, (out_lin,), store.groups[1], residual=x)[0]
-        go = (torch.randn(M, N, generator=torch.Generator().manual_seed(10))).to(hip, dtype)
-        o.backward(go)
-        ops.join_side_streams()
-        torch.cuda.synchronize()
-        res[chain] = (o.detach(), x.grad.detach(), store.flat_grad.clone())
-    ops.set_lora_chain(True)
-    for which in (True, "pipelined"):
-        for name, a, b in zip(("output", "input gradient", "LoRA gradients"), res[False], res[which]):
-            assert rel_l2(b, a) < 2e-2, f"{name}: chained ({which}) {rel_l2(b, a):.3e}"
 
 
 @pytest.mark.gpu

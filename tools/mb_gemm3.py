@@ -1,5 +1,5 @@
 """Microbenchmark of the lean kernel (gemm3.hip) against the pipelined one (gemm2.hip) on the launch-latency-bound problems of
-the step, and of chained launches (comat_gemm_chain) against the two launches they replace.
+the step.  (The chained-launch part of round 4 lives with its kernels on branch exp/gemm-chain.)
 
     python tools/mb_gemm3.py > gpurun_out/mb_gemm3.txt
 
@@ -45,7 +45,7 @@ def timeit(fn, n=20):
 
 
 def opts(**kw):
-    base = dict(gemm3=0, g3_cfg=0, gemm3_chain=0, gemm2_chain=0, g2_cfg=0, g2_splits=0)
+    base = dict(gemm3=0, g3_cfg=0, g2_cfg=0, g2_splits=0)
     base.update(kw)
     for k_, v_ in base.items():
         _hip.set_option(k_, v_)
@@ -89,33 +89,4 @@ for M, N, K_, r, G in [(512, 1280, 1280, 128, 1), (512, 1280, 1280, 128, 3), (20
         row.append(timeit(fn))
     print(f"seg {M}x{N}x({K_}+{r}) b={G:<18d} {t2:9.1f} {ta:5.1f} | " + " ".join(f"{t:8.1f}" for t in row), flush=True)
 
-print("# LoRA pairs (forward: h = s x D^T, y = [x | h][W | U]^T; backward: u = s g U, dx = [g | u][W^T | D^T]^T): us per pair")
-print(f"# {'pair':40s} 2 x pipelined | chained pipelined | 2 x lean (auto) | chained lean (auto) | chained lean per tile shape: " + " ".join(NAMES))
-for M, Kd, N, G in [(512, 1280, 1280, 3), (512, 1280, 1280, 1), (2048, 640, 640, 3), (2048, 640, 640, 1), (8192, 320, 320, 3), (8192, 320, 320, 1),
-                    (154, 768, 1280, 2), (128, 1280, 1280, 3), (128, 1280, 1280, 1)]:
-    r = 128
-    Gr = G * r
-    x, D, W, U = R(M, Kd), R(Gr, Kd), R(G, N, Kd), R(G, N, r)
-    h, y = torch.empty(M, Gr, device=dev, dtype=T), torch.empty(G, M, N, device=dev, dtype=T)
-    pre = dict(segs=[(x, D, Kd, Kd, Kd)], Cout=h, M=M, N=Gr, ldc=Gr, alpha=0.5)
-    main = dict(segs=[(x, W[0], Kd, Kd, Kd, 0, N * Kd), (h, U[0], r, Gr, r, r, N * r)], Cout=y, M=M, N=N, ldc=N, batch=G, sC=M * N)
-    g_, Ut, Wt, Dt = R(G, M, N), R(G, r, N), R(G, Kd, N), R(Kd, Gr)
-    u, dx = torch.empty(M, Gr, device=dev, dtype=T), torch.empty(M, Kd, device=dev, dtype=T)
-    bpre = dict(segs=[(g_[0], Ut[0], N, N, N, M * N, r * N)], Cout=u, M=M, N=r, ldc=Gr, alpha=0.5, batch=G, sC=r)
-    bmain = dict(segs=[(g_[i], Wt[i], N, N, N) for i in range(G)] + [(u, Dt, Gr, Gr, Gr)], Cout=dx, M=M, N=Kd, ldc=Kd)
-    for tag, p0, p1 in (("fwd", pre, main), ("bwd", bpre, bmain)):
-        fn = lambda: K.gemm_chain(p0, p1)
-        opts()
-        t22 = timeit(fn)
-        opts(gemm2_chain=1)
-        t2c = timeit(fn)
-        opts(gemm3=2)
-        t33 = timeit(fn)
-        opts(gemm3=2, gemm3_chain=2)
-        tc = timeit(fn)
-        row = []
-        for c in CFGS:
-            opts(gemm3=2, gemm3_chain=2, g3_cfg=c)
-            row.append(timeit(fn))
-        print(f"{tag} pair M={M} {Kd}->{N} G={G:<20d} {t22:9.1f} | {t2c:9.1f} | {t33:9.1f} | {tc:9.1f} | " + " ".join(f"{t:8.1f}" for t in row), flush=True)
 opts()
