@@ -266,9 +266,13 @@ class HipKernels:
              sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None):
         """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h);
         geglu = (C2 [M, N / 2], keep_pre): the GEGLU epilogue over interleaved value / gate columns (comat_gemm_params::epi2):
-        C2 receives value * gelu(gate); Cout receives the pre-activations only when keep_pre (it may be None otherwise)"""
+        C2 receives value * gelu(gate); Cout receives the pre-activations only when keep_pre (it may be None otherwise);
+        geglu = (pre [M, 2 N], "bwd"): the GEGLU backward epilogue (epi2 = 3): Cout [M, 2 N] = gradient of the pre-activations"""
         p = GemmParams()
-        if geglu is not None:
+        if geglu is not None and geglu[1] == "bwd":  # epi2 = 3: geglu[0] = the saved pre-activations [M, 2 N], Cout [M, 2 N] their gradient
+            p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 3
+            assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous() and Cout.dtype == torch.bfloat16
+        elif geglu is not None:
             p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 1 if geglu[1] else 2
             assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous()
         p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(Cout)

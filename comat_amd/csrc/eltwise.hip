@@ -75,13 +75,18 @@ template <> struct V8<bf16_t> {
     __device__ __forceinline__ void set(int e, float v) { ((bf16_t*)&u)[e] = f32_to_bf16(v); }
 };
 template <> struct V8<float> {
-    float4 a, b;
-    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
-    __device__ __forceinline__ void store(float* p) const { *(float4*)p = a; *(float4*)(p + 4) = b; }
-    __device__ __forceinline__ float get(int e) const { return ((const float*)&a)[e]; }
-    __device__ __forceinline__ void set(int e, float v) { ((float*)&a)[e] = v; }
+    float v[8];  // (one array: indexing past a float4 member into its neighbour was undefined behaviour - ADVICE r4)
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    __device__ __forceinline__ float get(int e) const { return v[e]; }
+    __device__ __forceinline__ void set(int e, float x) { v[e] = x; }
 };
-static_assert(sizeof(V8<float>) == 32, "V8<float>: a and b are adjacent");
 
 template <typename T>
 __global__ __launch_bounds__(NT) void geglu_il_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t M, int D) {

@@ -713,7 +713,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
                   "comat_gemm: leading dimension too small");
-    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && (p->epi2 == 1 || p->epi2 == 2)), "comat_gemm: bad second epilogue");
+    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && p->epi2 >= 1 && p->epi2 <= 3), "comat_gemm: bad second epilogue");
     if (p->epi2 == 0 && p->in_dtype == COMAT_BF16 && !p->transA && !p->transB && p->batch2 == 1) {  // lean kernel first (option gemm3)
         const comat_gemm_segment one = {p->A, p->B, p->K, p->lda, p->ldb, p->sA1, p->sB1};
         const int rc3 = comat_gemm3_try(p, &one, 1, false, stream);
@@ -725,6 +725,24 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
+    if (p->epi2 == 3) {  // GEGLU backward epilogue, two-launch form: dF into the workspace, then the elementwise kernel
+        COMAT_REQUIRE(p->in_dtype == COMAT_BF16 && p->out_dtype == COMAT_BF16 && p->N % 16 == 0 && p->batch1 * p->batch2 == 1 &&
+                          !p->R && !p->bias && !p->bias2 && p->act == COMAT_ACT_NONE && p->ldc == 2 * p->N && p->ldc2 == 2 * p->N,
+                      "comat_gemm: the GEGLU backward epilogue needs bf16 operands and output, N %% 16 == 0, ldc == ldc2 == 2 N, nothing else fused");
+        const int64_t need = p->M * p->N * 2;
+        COMAT_REQUIRE(p->ws && p->ws_bytes >= COMAT_WS_COUNTER_BYTES + need,
+                      "comat_gemm: the two-launch form of the GEGLU backward epilogue needs M * N * 2 bytes of workspace behind the counters");
+        comat_gemm_params q = *p;
+        q.epi2 = 0;
+        q.C2 = nullptr;
+        q.C = (char*)p->ws + COMAT_WS_COUNTER_BYTES;
+        q.ldc = p->N;
+        q.ws = nullptr;
+        q.ws_bytes = 0;
+        const int rc = comat_gemm(&q, stream);
+        if (rc) return rc;
+        return comat_geglu_il_bwd(q.C, p->C2, p->C, p->M, (int32_t)p->N, COMAT_BF16, stream);
+    }
     if (p->epi2 != 0) {
         // The pipelined kernel declined (option gemm2 = 0, or a shape it does not take): the GEGLU epilogue is a fast path, not
         // a different function - compute the same thing as two launches: the plain product into C (epi2 == 2: into

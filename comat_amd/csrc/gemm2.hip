@@ -176,7 +176,12 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                 half_swap(v[8 + j], v[12 + j]);
             }
             const int64_t nt = n0 + wc * WTN + b * 32, nb = nt + 8 * h;
-            if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
+            if (ep.epi2 == 3) {  // GEGLU backward: the lane's two 8-column pieces of dF -> d value / d gate (N % 16 == 0)
+                if (m < g.M) {
+                    if (nb < g.N) epilogue_geglu_bwd(ep, v, m, nb);
+                    if (nb + 16 < g.N) epilogue_geglu_bwd(ep, v + 8, m, nb + 16);
+                }
+            } else if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
                 if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
             } else if (m < g.M) {
                 if (nb < g.N) epilogue_run<WT>(ep, v, m, nb, g.N, vec);
@@ -1186,7 +1191,11 @@ int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
     a.scale_a = fp8 ? p->scale_a : nullptr;
     a.scale_b = fp8 ? p->scale_b : nullptr;
     fill_epi(a, p);
-    if (p->epi2) {  // GEGLU epilogue: bf16 output, 16-byte rows, whole 32-column tiles, nothing else fused
+    if (p->epi2 == 3) {  // GEGLU backward epilogue: C, C2 [M, 2 N] bf16 with 16-byte rows, nothing else fused
+        if (p->out_dtype != COMAT_BF16 || p->N % 16 || p->R || p->bias || p->bias2 || p->act != COMAT_ACT_NONE || p->batch1 > 1 || !p->C ||
+            !p->C2 || !al16(p->C) || !al16(p->C2) || p->ldc % 8 || p->ldc2 % 8 || p->ldc < 2 * p->N || p->ldc2 < 2 * p->N)
+            return -1;
+    } else if (p->epi2) {  // GEGLU epilogue: bf16 output, 16-byte rows, whole 32-column tiles, nothing else fused
         if ((p->epi2 != 1 && p->epi2 != 2) || p->out_dtype != COMAT_BF16 || p->N % 32 || p->R || p->bias2 || p->act != COMAT_ACT_NONE ||
             p->batch1 > 1 || !p->C2 || !al16(p->C2) || p->ldc2 % 8 || p->ldc2 < p->N / 2 || (p->bias && !al16(p->bias)))
             return -1;

@@ -197,6 +197,27 @@ __device__ __forceinline__ void epilogue_geglu(const Epi& ep, const float* v, in
     *(uint4*)((bf16_t*)ep.C2 + m * ep.ldc2 + (nt >> 1) + 8 * h) = po.u;
 }
 
+// GEGLU BACKWARD epilogue (epi2 == 3): `v` = 8 consecutive columns d .. d + 7 of row m of the product dF = g W2 (the gradient of the
+// feed-forward's hidden activations f = value * gelu(gate), [M, D]).  C2 holds the saved pre-activations [M, 2 D] in the interleaved
+// layout (value channels 16 t .. at columns 32 t .., their gates 16 columns further), C receives their gradient in the same layout:
+//   d value = dF * gelu(gate),   d gate = dF * value * gelu'(gate)
+// dF is rounded to bf16 first - the bits the two-launch form (GEMM, then comat_geglu_il_bwd) computes.
+__device__ __forceinline__ void epilogue_geglu_bwd(const Epi& ep, const float* v, int64_t m, int64_t d) {
+    const int64_t cv = ((d >> 4) << 5) + (d & 15), cg = cv + 16;
+    Pack16 pa, pg, oa, og;
+    pa.u = *(const uint4*)((const bf16_t*)ep.C2 + m * ep.ldc2 + cv);
+    pg.u = *(const uint4*)((const bf16_t*)ep.C2 + m * ep.ldc2 + cg);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float go = bf16_to_f32(f32_to_bf16(v[e] * ep.alpha));
+        const float a = bf16_to_f32(pa.h[e]), g = bf16_to_f32(pg.h[e]);
+        oa.h[e] = f32_to_bf16(go * gelu_f(g));
+        og.h[e] = f32_to_bf16(go * a * gelu_grad_f(g));
+    }
+    *(uint4*)((bf16_t*)ep.C + m * ep.ldc + cv) = oa.u;
+    *(uint4*)((bf16_t*)ep.C + m * ep.ldc + cg) = og.u;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 constexpr int64_t WS_COUNTERS = COMAT_WS_COUNTER_BYTES / 4;  // ticket counters at the head of the workspace
 

@@ -790,35 +790,38 @@ def set_geglu_fused(flag: bool):
     _geglu_fused = bool(flag)
 
 
+def _geglu_linear_fwd(x, lin, need_pre):
+    """(GEGLU(x W^T + b), pre-activations or None): ONE launch (the product leaves the GEMM epilogue; the pre-activations are
+    stored only when a backward pass will read them) where the library's pipelined kernel takes the problem, else the GEMM and
+    the interleaved-layout GEGLU kernel."""
+    M, Kd = x.shape
+    D, N2 = lin.out_features, lin.pre_features
+    k = kernels()
+    y = x.new_empty((M, D))
+    if _use_fp8(lin, Kd):
+        a, (w, sw) = k.fp8_quantize(x), fp8_weight(lin)
+        a, scales = a[0], (a[1], sw)
+    else:
+        a, w, scales = x, lin.w, None
+    if _geglu_fused and y.dtype == torch.bfloat16 and k.geglu_gemm_ok(a, w, M, N2, Kd):
+        pre = x.new_empty((M, N2)) if need_pre else None
+        k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales, geglu=(y, need_pre))
+    else:
+        pre = x.new_empty((M, N2))
+        k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales)
+        k.geglu_il_fwd(pre, y, M, D)
+    return y, (pre if need_pre else None)
+
+
 class _GegluLinear(Function):
-    """y = GEGLU(x W^T + b) with the interleaved weight of FrozenGegluLinear: ONE launch (the product leaves the GEMM epilogue;
-    the pre-activations are stored only when a backward pass will read them) where the library's pipelined kernel takes the
-    problem, else the GEMM and the interleaved-layout GEGLU kernel."""
+    """y = GEGLU(x W^T + b) with the interleaved weight of FrozenGegluLinear (see _geglu_linear_fwd)."""
 
     @staticmethod
     def forward(ctx, x, lin):
         x = _c(x)
-        M, Kd = x.shape
-        D, N2 = lin.out_features, lin.pre_features
-        k = kernels()
-        need_pre = ctx.needs_input_grad[0]
-        y = x.new_empty((M, D))
-        use8 = _use_fp8(lin, Kd)
-        if use8:
-            a, (w, sw) = k.fp8_quantize(x), fp8_weight(lin)
-            a, scales = a[0], (a[1], sw)
-        else:
-            a, w, scales = x, lin.w, None
-        pre = None
-        if _geglu_fused and y.dtype == torch.bfloat16 and k.geglu_gemm_ok(a, w, M, N2, Kd):
-            pre = x.new_empty((M, N2)) if need_pre else None
-            k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales, geglu=(y, need_pre))
-        else:
-            pre = x.new_empty((M, N2))
-            k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales)
-            k.geglu_il_fwd(pre, y, M, D)
+        y, pre = _geglu_linear_fwd(x, lin, ctx.needs_input_grad[0])
         ctx.lin = lin
-        if need_pre:
+        if pre is not None:
             ctx.save_for_backward(pre)
         return y
 
@@ -833,6 +836,64 @@ class _GegluLinear(Function):
         dx = pre.new_empty((M, lin.in_features))
         k.gemm(dpre, lin.wt, dx, M, lin.in_features, N2, N2, N2, lin.in_features)
         return dx, None
+
+
+class _GegluFeedForward(Function):
+    """h = GEGLU(x W1^T + b1) W2^T + b2 + residual - the feed-forward of a BasicTransformerBlock (`ff.net.0.proj` + GEGLU,
+    `ff.net.2`; 3P diffusers FeedForward, reached from TrainableSDPipeline.py:144-150) as one autograd node, so that the
+    backward pass can run the GEGLU's gradient in the epilogue of `ff.net.2`'s data-gradient GEMM (comat_gemm_params::epi2 = 3):
+        forward   two launches (projection + GEGLU epilogue, projection + residual epilogue)  - as before
+        backward  d pre = geglu'(g W2; pre) in ONE launch (was: the GEMM, a [M, D] round trip, the elementwise kernel), then
+                  dx = d pre W1."""
+
+    @staticmethod
+    def forward(ctx, x, residual, ff1, ff2):
+        x = _c(x)
+        need = ctx.needs_input_grad[0]
+        f, pre = _geglu_linear_fwd(x, ff1, need)
+        M, D = f.shape
+        N = ff2.out_features
+        y = x.new_empty((M, N))
+        k = kernels()
+        residual = _c(residual) if residual is not None else None
+        beta = 1.0 if residual is not None else 0.0
+        if _use_fp8(ff2, D):
+            f8, sf = k.fp8_quantize(f)
+            w8, sw = fp8_weight(ff2)
+            k.gemm(f8, w8, y, M, N, D, D, D, N, bias=ff2.bias, R=residual, ldr=N, beta=beta, scales=(sf, sw))
+        else:
+            k.gemm(f, ff2.w, y, M, N, D, D, D, N, bias=ff2.bias, R=residual, ldr=N, beta=beta)
+        ctx.ff1, ctx.ff2 = ff1, ff2
+        ctx.has_res = residual is not None
+        if need:
+            ctx.save_for_backward(pre)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        ff1, ff2 = ctx.ff1, ctx.ff2
+        dx = None
+        if ctx.needs_input_grad[0]:
+            (pre,) = ctx.saved_tensors
+            M, N2 = pre.shape
+            D, N = ff1.out_features, ff2.out_features
+            k = kernels()
+            dpre = torch.empty_like(pre)
+            if _geglu_fused and pre.dtype == torch.bfloat16 and k.geglu_gemm_ok(g, ff2.wt, M, 2 * D, N):
+                k.gemm(g, ff2.wt, dpre, M, D, N, N, N, N2, geglu=(pre, "bwd"))
+            else:
+                df = pre.new_empty((M, D))
+                k.gemm(g, ff2.wt, df, M, D, N, N, N, D)
+                k.geglu_il_bwd(df, pre, dpre, M, D)
+            dx = pre.new_empty((M, ff1.in_features))
+            k.gemm(dpre, ff1.wt, dx, M, ff1.in_features, N2, N2, N2, ff1.in_features)
+        return dx, (g if ctx.has_res else None), None, None
+
+
+def geglu_feed_forward(x, ff1: "FrozenGegluLinear", ff2: "FrozenLinear", residual=None):
+    """GEGLU(x W1^T + b1) W2^T + b2 (+ residual): see _GegluFeedForward"""
+    return _GegluFeedForward.apply(x, residual, ff1, ff2)
 
 
 def geglu_linear(x, lin: "FrozenGegluLinear"):

@@ -195,8 +195,7 @@ class CrossAttnBlock:
             o, probs = self._cross_attn(att, y, ctx, B, N, L, want_probs, kv_cache)
             h = ops.lora_group_linear(o, *att[("attn2", "out")], residual=h)[0]
             y, h = ops.layer_norm_fork(h, *ln[2])
-            f = ops.geglu_linear(y, Lr["ff1"])  # projection + GEGLU: one launch
-            h = ops.linear(f, Lr["ff2"], residual=h)
+            h = ops.geglu_feed_forward(y, Lr["ff1"], Lr["ff2"], residual=h)  # fwd: 2 launches; bwd: GEGLU' in ff2's dgrad epilogue
             if want_probs:
                 probs_all.append(probs)
         return ops.linear(h, self.proj_out, residual=x), probs_all

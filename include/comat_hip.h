@@ -87,6 +87,11 @@ typedef struct {
      *   the rows of B and the bias once); C2 [M, D] (leading dimension ldc2) receives value * gelu(gate), both rounded to bf16
      *   first.  epi2 = 1 also stores the pre-activations to C (what the backward pass reads), epi2 = 2 does not (C may be
      *   NULL).  bf16 output, N % 32 == 0, 16-byte aligned rows; no residual, bias2, activation or batch.
+     *   epi2 = 3 (ABI 6): the GEGLU BACKWARD.  The product is dF [M, N] (the data-gradient of `ff.net.2`: the gradient of the hidden
+     *   activations f = value * gelu(gate)); C2 [M, 2 N] holds the saved pre-activations in the interleaved layout (input), C
+     *   [M, 2 N] receives their gradient in the same layout: d value = dF * gelu(gate), d gate = dF * value * gelu'(gate), dF
+     *   rounded to bf16 first (the bits of the two-launch form).  bf16, N % 16 == 0, ldc, ldc2 >= 2 N, 16-byte aligned rows,
+     *   no bias / residual / activation / batch.
      * Replaces the separate GEGLU kernel behind `ff.net.0.proj` of every BasicTransformerBlock (3P diffusers GEGLU, reached
      * from TrainableSDPipeline.py:144-150): one launch and one [M, 2 D] read less per block, and no [M, 2 D] write at all in
      * the no-grad denoise steps. */

@@ -57,6 +57,12 @@ class SimKernels:
         acc = _act(acc, act)
         if R is not None:
             acc = acc + beta * _v(R, (b1, b2, M, N), (sR[0], sR[1], ldr, 1)).float()
+        if geglu is not None and geglu[1] == "bwd":  # epi2 = 3: dF (rounded) -> gradient of the interleaved pre-activations
+            pre = geglu[0]
+            assert b1 == b2 == 1 and N % 16 == 0 and R is None and act == ACT_NONE and bias is None and bias2 is None
+            dF = acc.reshape(M, N).to(pre.dtype)
+            self.geglu_il_bwd(dF, pre, Cout, M, N)
+            return
         if geglu is not None:  # comat_gemm_params::epi2: value / gate columns interleaved in sixteens, both rounded first
             y, keep = geglu
             assert b1 == b2 == 1 and N % 32 == 0 and R is None and act == ACT_NONE and bias2 is None

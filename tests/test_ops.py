@@ -1127,6 +1127,41 @@ def test_geglu_linear(dev, dtype, shape):
     assert torch.equal(y3, y) and torch.equal(xs.grad, xd.grad), "fused and two-launch GEGLU differ"
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(64, 96, 64, 80), (300, 320, 1280, 320), (16, 64, 32, 64), (2048, 640, 2560, 640)])
+def test_geglu_feed_forward(dev, dtype, shape):
+    """ops.geglu_feed_forward = GEGLU(x W1^T + b1) W2^T + b2 + residual as one autograd node: output, input and residual
+    gradients against torch on the ORIGINAL weights; its backward (the GEGLU's gradient in the epilogue of the second
+    projection's data-gradient GEMM, comat_gemm_params::epi2 = 3) gives the bits of the two separate operators."""
+    M, K, D, N = shape
+    if dev.type != "cuda" and M * D > 300 * 1280:
+        pytest.skip("large shape: GPU only")
+    w1, b1 = rnd(2 * D, K, dtype=dtype, seed=1, scale=K ** -0.5), rnd(2 * D, seed=2)
+    w2, b2 = rnd(N, D, dtype=dtype, seed=5, scale=D ** -0.5), rnd(N, seed=6)
+    ff1, ff2 = ops.FrozenGegluLinear(w1, b1, dtype, dev), ops.FrozenLinear(w2, b2, dtype, dev)
+    x, res, go = rnd(M, K, dtype=dtype, seed=3), rnd(M, N, dtype=dtype, seed=7), rnd(M, N, dtype=dtype, seed=4)
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    pre = xr @ w1.t() + b1
+    ref = (pre[:, :D] * F.gelu(pre[:, D:])) @ w2.t() + b2 + rr
+    ref.backward(go)
+    xd, rd = dv(x, dev, dtype, grad=True), dv(res, dev, dtype, grad=True)
+    y = ops.geglu_feed_forward(xd, ff1, ff2, residual=rd)
+    y.backward(dv(go, dev, dtype))
+    check(y, ref, dtype, "feed-forward", factor=3)
+    check(xd.grad, xr.grad, dtype, "feed-forward dx", factor=4)
+    check(rd.grad, rr.grad, dtype, "feed-forward dresidual")
+    xs, rs = dv(x, dev, dtype, grad=True), dv(res, dev, dtype, grad=True)
+    y2 = ops.linear(ops.geglu_linear(xs, ff1), ff2, residual=rs)
+    y2.backward(dv(go, dev, dtype))
+    assert torch.equal(y2, y), "one node vs two operators: outputs differ"
+    if dtype == torch.bfloat16:
+        assert torch.equal(xs.grad, xd.grad) and torch.equal(rs.grad, rd.grad), "GEGLU' in the epilogue differs from the two-launch form"
+    else:
+        check(xd.grad, xs.grad, dtype, "fp32: one node vs two operators")
+    with torch.no_grad():
+        assert torch.equal(ops.geglu_feed_forward(dv(x, dev, dtype), ff1, ff2, residual=dv(res, dev, dtype)), y.detach())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(300, 320, 1280), (2048, 640, 2560)])
 def test_geglu_linear_without_the_pipelined_kernel(hip, shape, default_opts):
@@ -1139,6 +1174,7 @@ def test_geglu_linear_without_the_pipelined_kernel(hip, shape, default_opts):
     lin = ops.FrozenGegluLinear(w, b, dtype, hip)
     x, go = rnd(M, K, dtype=dtype, seed=3), rnd(M, D, dtype=dtype, seed=4)
     res = []
+    w2 = ops.FrozenLinear(rnd(K, D, dtype=dtype, seed=8, scale=D ** -0.5), None, dtype, hip)
     for g2 in (1, 0):
         _set_opts(gemm2=g2, gemm3=0)
         xd = dv(x, hip, dtype, grad=True)
@@ -1146,9 +1182,11 @@ def test_geglu_linear_without_the_pipelined_kernel(hip, shape, default_opts):
         y.backward(dv(go, hip, dtype))
         with torch.no_grad():
             y2 = ops.geglu_linear(dv(x, hip, dtype), lin)
-        res.append((y.detach(), xd.grad, y2))
+        xf = dv(x, hip, dtype, grad=True)  # the backward epilogue (epi2 = 3) and its two-launch form
+        ops.geglu_feed_forward(xf, lin, w2).backward(dv(rnd(M, K, dtype=dtype, seed=9), hip, dtype))
+        res.append((y.detach(), xd.grad, y2, xf.grad))
     # the general kernel accumulates in another order: equal up to bf16 rounding of the pre-activations
-    for a, b_, name in zip(res[0], res[1], ("output", "input gradient", "no-grad output")):
+    for a, b_, name in zip(res[0], res[1], ("output", "input gradient", "no-grad output", "feed-forward input gradient")):
         assert rel_l2(b_, a) < 1e-2, f"{name}: {rel_l2(b_, a):.2e}"
     assert torch.equal(res[1][0], res[1][2]), "gemm2 = 0: no-grad call differs from the grad-mode call"
 
