@@ -326,6 +326,10 @@ class SegmentedStep:
                             return tr._d_forward(dict(training_latents=seg.si[0].detach()), d_batch())
 
                     def d_bwd():
+                        # (the generator-side loss, recorded after the D forward, switched the discriminator's parameters to
+                        # requires_grad = False; autograd's AccumulateGrad checks the flag when it RUNS: without this the head's
+                        # weight and bias would silently get no gradient)
+                        tr.D.set_D_sd_pipeline_lora(True)
                         with ops.no_side_streams():
                             loss = seg.fwd_side_out
                             loss.backward()
