@@ -785,6 +785,10 @@ def geglu(x):
 _geglu_fused = os.environ.get("COMAT_GEGLU_FUSED", "1") != "0"
 
 
+# COMAT_GEGLU_BWD_FUSED=0: the GEGLU's gradient as its own launch behind ff.net.2's data-gradient GEMM (A/B runs)
+_geglu_bwd_fused = os.environ.get("COMAT_GEGLU_BWD_FUSED", "1") != "0"
+
+
 def set_geglu_fused(flag: bool):
     global _geglu_fused
     _geglu_fused = bool(flag)
@@ -880,7 +884,7 @@ class _GegluFeedForward(Function):
             D, N = ff1.out_features, ff2.out_features
             k = kernels()
             dpre = torch.empty_like(pre)
-            if _geglu_fused and pre.dtype == torch.bfloat16 and k.geglu_gemm_ok(g, ff2.wt, M, 2 * D, N):
+            if _geglu_fused and _geglu_bwd_fused and pre.dtype == torch.bfloat16 and k.geglu_gemm_ok(g, ff2.wt, M, 2 * D, N):
                 k.gemm(g, ff2.wt, dpre, M, D, N, N, N, N2, geglu=(pre, "bwd"))
             else:
                 df = pre.new_empty((M, D))
