@@ -87,6 +87,7 @@ SIGNATURES = {
     "comat_geglu_il_fwd": [_vp, _vp, _i64, _i32, _i32, _vp],
     "comat_geglu_il_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "comat_copy2d": [_vp, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
+    "comat_copy2d_pair": [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp],
     "comat_add_rowvec": [_vp, _vp, _vp, _i64, _i64, _i32, _vp],
     "comat_sumpool2x2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "comat_permute_nchw_nhwc": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -499,6 +500,20 @@ class HipKernels:
     def copy2d(self, src, ld_src, dst, ld_dst, rows, cols):
         _check(_lib.comat_copy2d(_ptr(src), ld_src, _ptr(dst), ld_dst, rows, cols, dt(src), dt(dst), _stream()),
                "comat_copy2d")
+
+    @staticmethod
+    def copy2d_pair_ok(items):
+        """what comat_copy2d_pair takes: one dtype, whole 16-byte vectors, aligned pointers; items = [(src, ld_src, dst, ld_dst, cols)] x 2"""
+        d0 = items[0][0].dtype
+        epv = 16 // items[0][0].element_size()
+        return (d0 in (torch.float32, torch.bfloat16)
+                and all(s.dtype == d0 and d.dtype == d0 and c % epv == 0 and ls % epv == 0 and ld % epv == 0
+                        and s.data_ptr() % 16 == 0 and d.data_ptr() % 16 == 0 for s, ls, d, ld, c in items))
+
+    def copy2d_pair(self, items, rows):
+        (s0, ls0, d0, ld0, c0), (s1, ls1, d1, ld1, c1) = items
+        _check(_lib.comat_copy2d_pair(_ptr(s0), ls0, _ptr(d0), ld0, c0, _ptr(s1), ls1, _ptr(d1), ld1, c1, rows, dt(s0), _stream()),
+               "comat_copy2d_pair")
 
     def add_rowvec(self, x, v, out, rows, cols):
         _check(_lib.comat_add_rowvec(_ptr(x), _ptr(v), _ptr(out), rows, cols, dt(x), _stream()), "comat_add_rowvec")

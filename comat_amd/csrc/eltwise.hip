@@ -137,6 +137,26 @@ __global__ __launch_bounds__(NT) void copy2d_kernel(const void* __restrict__ src
     }
 }
 
+// two strided 2-D copies in ONE launch, 16 bytes per thread and step: the channel concat of a skip connection (out[:, :Ca] = a,
+// out[:, Ca:] = b) and its backward split - twice per up-path ResnetBlock and direction (336 two-copy pairs per C2 step)
+struct Copy2dPair {
+    const char* src[2];
+    char* dst[2];
+    int64_t lds[2], ldd[2];  // bytes between rows
+    int vpr[2];              // 16-byte vectors per row
+};
+__global__ __launch_bounds__(NT) void copy2d_pair_kernel(Copy2dPair p, int64_t rows) {
+    const int vt = p.vpr[0] + p.vpr[1];
+    const int64_t n = rows * vt;
+    GRID_STRIDE(i, n) {
+        const int64_t r = i / vt;
+        int v = (int)(i - r * vt);
+        const int w = v >= p.vpr[0] ? 1 : 0;
+        v -= w * p.vpr[0];
+        *(uint4*)(p.dst[w] + r * p.ldd[w] + (int64_t)v * 16) = *(const uint4*)(p.src[w] + r * p.lds[w] + (int64_t)v * 16);
+    }
+}
+
 __global__ __launch_bounds__(NT) void add_rowvec_kernel(const void* __restrict__ x, const void* __restrict__ v,
                                                         void* __restrict__ out, int64_t rows, int64_t cols, int dt) {
     const int64_t n = rows * cols;
@@ -300,6 +320,25 @@ extern "C" int comat_copy2d(const void* src, int64_t ld_src, void* dst, int64_t 
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_1d(rows * cols, NT)), dim3(NT), 0, ST, src, ld_src, dst, ld_dst, rows,
                        cols, src_dtype, dst_dtype);
     return comat_check_launch("comat_copy2d");
+}
+
+extern "C" int comat_copy2d_pair(const void* src0, int64_t ld_src0, void* dst0, int64_t ld_dst0, int64_t cols0, const void* src1,
+                                 int64_t ld_src1, void* dst1, int64_t ld_dst1, int64_t cols1, int64_t rows, int32_t dtype,
+                                 void* stream) {
+    COMAT_REQUIRE(src0 && dst0 && src1 && dst1 && rows > 0 && cols0 > 0 && cols1 > 0, "comat_copy2d_pair: bad args");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_copy2d_pair: bad dtype");
+    const int eb = dtype == COMAT_F32 ? 4 : 2, epv = 16 / eb;
+    COMAT_REQUIRE(ld_src0 >= cols0 && ld_dst0 >= cols0 && ld_src1 >= cols1 && ld_dst1 >= cols1, "comat_copy2d_pair: leading dimension too small");
+    COMAT_REQUIRE(cols0 % epv == 0 && cols1 % epv == 0 && ld_src0 % epv == 0 && ld_dst0 % epv == 0 && ld_src1 % epv == 0 &&
+                      ld_dst1 % epv == 0 && (((uintptr_t)src0 | (uintptr_t)dst0 | (uintptr_t)src1 | (uintptr_t)dst1) & 15) == 0 &&
+                      (cols0 + cols1) / epv < (1 << 30),
+                  "comat_copy2d_pair: 16-byte rows only (columns and leading dimensions in whole 16-byte vectors, aligned pointers)");
+    Copy2dPair p;
+    p.src[0] = (const char*)src0; p.src[1] = (const char*)src1; p.dst[0] = (char*)dst0; p.dst[1] = (char*)dst1;
+    p.lds[0] = ld_src0 * eb; p.lds[1] = ld_src1 * eb; p.ldd[0] = ld_dst0 * eb; p.ldd[1] = ld_dst1 * eb;
+    p.vpr[0] = (int)(cols0 / epv); p.vpr[1] = (int)(cols1 / epv);
+    hipLaunchKernelGGL(copy2d_pair_kernel, dim3(grid_1d(rows * (p.vpr[0] + p.vpr[1]), NT, 1 << 16)), dim3(NT), 0, ST, p, rows);
+    return comat_check_launch("comat_copy2d_pair");
 }
 
 extern "C" int comat_add_rowvec(const void* x, const void* v, void* out, int64_t rows, int64_t cols, int32_t dtype,

@@ -905,6 +905,16 @@ def geglu_linear(x, lin: "FrozenGegluLinear"):
     return _GegluLinear.apply(x, lin)
 
 
+def _copy_pair(items, rows):
+    """two strided 2-D copies [(src, ld_src, dst, ld_dst, cols)] in one launch where the library takes them (16-byte rows)"""
+    k = kernels()
+    if hasattr(k, "copy2d_pair") and k.copy2d_pair_ok(items):
+        k.copy2d_pair(items, rows)
+    else:
+        for src, ld_src, dst, ld_dst, cols in items:
+            k.copy2d(src, ld_src, dst, ld_dst, rows, cols)
+
+
 class _ConcatCols(Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -912,9 +922,7 @@ class _ConcatCols(Function):
         M, Ca = a.shape
         Cb = b.shape[1]
         out = a.new_empty((M, Ca + Cb))
-        k = kernels()
-        k.copy2d(a, Ca, out, Ca + Cb, M, Ca)
-        k.copy2d(b, Cb, out[:, Ca:], Ca + Cb, M, Cb)
+        _copy_pair([(a, Ca, out, Ca + Cb, Ca), (b, Cb, out[:, Ca:], Ca + Cb, Cb)], M)
         ctx.ca, ctx.cb = Ca, Cb
         return out
 
@@ -925,10 +933,13 @@ class _ConcatCols(Function):
         Ca, Cb = ctx.ca, ctx.cb
         k = kernels()
         ga = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            ga, gb = g.new_empty((M, Ca)), g.new_empty((M, Cb))
+            _copy_pair([(g, Ca + Cb, ga, Ca, Ca), (g[:, Ca:], Ca + Cb, gb, Cb, Cb)], M)
+        elif ctx.needs_input_grad[0]:
             ga = g.new_empty((M, Ca))
             k.copy2d(g, Ca + Cb, ga, Ca, M, Ca)
-        if ctx.needs_input_grad[1]:
+        elif ctx.needs_input_grad[1]:
             gb = g.new_empty((M, Cb))
             k.copy2d(g[:, Ca:], Ca + Cb, gb, Cb, M, Cb)
         return ga, gb

@@ -253,6 +253,12 @@ int comat_geglu_il_bwd(const void* dy, const void* x, void* dx, int64_t M, int32
 /* strided 2-D copy (channel concat / split): dst[r, c] = src[r, c] for r < rows, c < cols */
 int comat_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
                  int32_t src_dtype, int32_t dst_dtype, void* stream);
+/* Two strided 2-D copies of the same row count in ONE launch (ABI 6): dst_i[r, c] = src_i[r, c] for c < cols_i.  The channel
+ * concat of a UNet skip connection (`torch.cat([hidden_states, res_hidden_states], dim=1)` in every up-path ResnetBlock of the 3P
+ * UNet, reached from TrainableSDPipeline.py:144-150) and its backward split.  16-byte accesses: cols_i and every leading dimension
+ * in whole 16-byte vectors, 16-byte aligned pointers (else COMAT_EINVAL: use comat_copy2d twice). */
+int comat_copy2d_pair(const void* src0, int64_t ld_src0, void* dst0, int64_t ld_dst0, int64_t cols0, const void* src1,
+                      int64_t ld_src1, void* dst1, int64_t ld_dst1, int64_t cols1, int64_t rows, int32_t dtype, void* stream);
 /* out[r, c] = x[r, c] + v[c] broadcast over rows (positional embeddings) */
 int comat_add_rowvec(const void* x, const void* v, void* out, int64_t rows, int64_t cols, int32_t dtype,
                      void* stream);

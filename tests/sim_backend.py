@@ -302,6 +302,14 @@ class SimKernels:
     def copy2d(self, src, ld_src, dst, ld_dst, rows, cols):
         _v(dst, (rows, cols), (ld_dst, 1)).copy_(_v(src, (rows, cols), (ld_src, 1)).to(dst.dtype))
 
+    @staticmethod
+    def copy2d_pair_ok(items):
+        return True
+
+    def copy2d_pair(self, items, rows):
+        for src, ld_src, dst, ld_dst, cols in items:
+            self.copy2d(src, ld_src, dst, ld_dst, rows, cols)
+
     def add_rowvec(self, x, v, out, rows, cols):
         out.copy_((x.float() + v.float().reshape(1, cols)).to(out.dtype))
 

@@ -1128,6 +1128,23 @@ def test_geglu_linear(dev, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(130, 320, 640), (4096, 640, 320), (77, 24, 8), (50, 7, 9)])
+def test_concat_cols_pair_copy(dev, dtype, shape):
+    """ops.concat_cols and its backward split: both halves in ONE launch (comat_copy2d_pair) where the rows are whole 16-byte
+    vectors, two comat_copy2d launches otherwise (odd column counts) - exact copies either way."""
+    M, Ca, Cb = shape
+    a, b, g = rnd(M, Ca, dtype=dtype, seed=1), rnd(M, Cb, dtype=dtype, seed=2), rnd(M, Ca + Cb, dtype=dtype, seed=3)
+    ad, bd = dv(a, dev, dtype, grad=True), dv(b, dev, dtype, grad=True)
+    out = ops.concat_cols(ad, bd)
+    out.backward(dv(g, dev, dtype))
+    assert torch.equal(out.detach().float().cpu(), torch.cat([a, b], 1))
+    assert torch.equal(ad.grad.float().cpu(), g[:, :Ca]) and torch.equal(bd.grad.float().cpu(), g[:, Ca:])
+    a2 = dv(a, dev, dtype, grad=True)  # only one side needs a gradient
+    ops.concat_cols(a2, dv(b, dev, dtype)).backward(dv(g, dev, dtype))
+    assert torch.equal(a2.grad.float().cpu(), g[:, :Ca])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(64, 96, 64, 80), (300, 320, 1280, 320), (16, 64, 32, 64), (2048, 640, 2560, 640)])
 def test_geglu_feed_forward(dev, dtype, shape):
     """ops.geglu_feed_forward = GEGLU(x W1^T + b1) W2^T + b2 + residual as one autograd node: output, input and residual
