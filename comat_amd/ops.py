@@ -958,8 +958,13 @@ class _ConcatRows(Function):
         a, b = _c(a), _c(b)
         out = a.new_empty((a.shape[0] + b.shape[0], a.shape[1]))
         k = kernels()
-        k.unary(UN_COPY, a, out[: a.shape[0]], a.numel())
-        k.unary(UN_COPY, b, out[a.shape[0]:], b.numel())
+        na, nb = a.numel(), b.numel()
+        items = [(a, na, out[: a.shape[0]], na, na), (b, nb, out[a.shape[0]:], nb, nb)]
+        if a.dtype == b.dtype and hasattr(k, "copy2d_pair") and k.copy2d_pair_ok(items):
+            k.copy2d_pair(items, 1)  # both halves in one launch (one "row" each)
+        else:
+            k.unary(UN_COPY, a, out[: a.shape[0]], na)
+            k.unary(UN_COPY, b, out[a.shape[0]:], nb)
         ctx.ma = a.shape[0]
         return out
 
