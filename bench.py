@@ -430,7 +430,7 @@ def load_pmc_summary():
     if have != want:
         out["traffic_bytes_per_launch"] = out["mfma_busy_frac"] = None
         out["note"] = (f"{os.path.basename(files[-1])} was measured on build {have or '(not recorded: before round 4)'}, the loaded "
-                       f"library is build {want}: counter figures withheld (re-run tools/calls/r4_final.sh pmc)")
+                       f"library is build {want}: counter figures withheld (re-run tools/calls/r5_final.sh pmc)")
     else:
         out["note"] = f"{out.get('note', '')} [{os.path.basename(files[-1])}, build {have}]".strip()
     return out
