@@ -39,7 +39,9 @@ class Recorder:
             if name == "gemm" and a[0].dtype == torch.bfloat16 and not kw.get("transA") and not kw.get("transB"):
                 b = kw.get("batch", (1, 1))
                 if b[1] == 1 and a[5] % 32 == 0 and a[3] >= 48:
-                    sig = ("gemm", a[3], a[4], a[5] // 32, b[0], a[5], kw.get("R") is not None, str(a[2].dtype))
+                    # (a[2] is None for the GEGLU epilogue of a no-grad call: no pre-activations are stored)
+                    sig = ("gemm", a[3], a[4], a[5] // 32, b[0], a[5], kw.get("R") is not None,
+                           str(a[2].dtype) if a[2] is not None else "torch.bfloat16")
             elif name == "gemm_segments" and a[0][0][0].dtype == torch.bfloat16 and a[2] >= 48:
                 ks = tuple(sg[2] for sg in a[0])
                 if all(k_ % 32 == 0 for k_ in ks):
