@@ -207,6 +207,10 @@ class SegmentedStep:
             return True
         except Exception as e:  # noqa: BLE001 - see `failed`
             self.failed = f"{seg.name}: {type(e).__name__}: {e}"
+            import sys
+            # said once, loudly: from here on every step of this trainer launches eagerly (~10 us of host time per kernel)
+            print(f"[comat_amd] capture of segment '{seg.name}' failed ({type(e).__name__}: {e}); this SegmentedStep runs "
+                  "eagerly from now on", file=sys.stderr, flush=True)
             dev = self.tr.device
             ops.reset_capture_stream(dev)
             self.tr.drop_forked_streams()
