@@ -662,6 +662,8 @@ def main():
                     help="control-flow check of this script WITHOUT a GPU (tests/test_bench_contract.py): tiny model, "
                          "ABI simulator, gloo; its numbers mean nothing and the output is marked as such")
     args = ap.parse_args()
+    import faulthandler
+    faulthandler.enable()  # a native crash (GPU runtime, extension) leaves the Python stack of every thread on stderr
 
     from comat_amd import dist, ops
     rank, world, device = dist.init()
@@ -921,12 +923,18 @@ def main():
                              "TFLOP/s_replayed": round(v[1] / v[0] / 1e12, 1)}
                          for k, v in sorted(fam.items(), key=lambda kv: -kv[1][4])},
         }
+    def stage(what):  # progress markers on stderr (rank 0): which part of the run a log ends in
+        if rank == 0:
+            print(f"[bench] {time.time() - T_PROCESS:6.1f} s: {what}", file=sys.stderr, flush=True)
+
+    stage(f"timed region done: {ms_per_step:.1f} ms per step")
     attn_map = None
     if rank == 0 and not args.no_kernel_timing and not args.selftest and os.environ.get("COMAT_ATTN_MAP_PROBE", "1") != "0":
         attn_map = attn_map_probe()
     secondary = None
     if (rank == 0 and world == 1 and args.config == "c2" and args.bs == 1 and not args.selftest and not args.no_kernel_timing
             and os.environ.get("COMAT_SECONDARY", "1") != "0"):
+        stage("secondary c3")
         try:
             secondary = {"c3": secondary_c3(trainer, batch, rank, sync)}
         except Exception as e:  # noqa: BLE001 - the headline number must not depend on the secondary one
@@ -935,6 +943,7 @@ def main():
             if time.time() - T_PROCESS > 300:  # keep the default run within minutes whatever the box
                 secondary["c4"] = {"skipped": "the run had used more than 300 s before the SDXL measurement"}
             else:
+                stage("secondary c4")
                 try:
                     if os.environ.get("COMAT_SECONDARY_C4", "1") == "inproc":
                         secondary["c4"] = secondary_c4(device, dtype, rank, sync)
@@ -946,13 +955,16 @@ def main():
             if time.time() - T_PROCESS > 420:
                 secondary["c2_bs4"] = {"skipped": "the run had used more than 420 s before the batch-4 measurement"}
             else:
+                stage("secondary c2_bs4")
                 try:
                     secondary["c2_bs4"] = secondary_c2_bs4_own_process()
                 except Exception as e:  # noqa: BLE001
                     secondary["c2_bs4"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
+        stage("cpu baseline")
         cpu = cpu_baseline(usd_cpu, scfg)
+    stage("done")
     if rank == 0 and os.environ.get("COMAT_BENCH_LOGS"):  # loss terms of the last timed step (sanity evidence)
         print({k: (float(v) if torch.is_tensor(v) else v) for k, v in last_logs.items()}, file=sys.stderr)
     if rank == 0:
