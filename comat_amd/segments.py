@@ -319,12 +319,16 @@ class SegmentedStep:
                 # backward (~11 ms) instead of the whole step (~19 ms) under the backward alone (round 4: head backward + D
                 # step 25 ms; two graphs launched on two streams do not overlap on this runtime: measured 176 vs 153 ms per C2
                 # step).  A fork from a forked stream crashes hipStreamEndCapture on ROCm 7.2, so its weight gradients stay
-                # on that stream.  COMAT_D_SPLIT=0: the whole step inside the backward graph (rounds 3-4).
+                # on that stream.  OPT-IN (COMAT_D_SPLIT=1; default: the whole step inside the backward graph, as in rounds 3-4): it buys
+                # 3 ms of the head's two graphs and ~1 ms of a C3 step (profiles/r05_d_bench_c3_dsplit*.log), and inside the
+                # default bench line's process - which already holds the C2 graphs when the C3 world captures its head -
+                # hipStreamEndCapture of the forward graph with its two forked streams segfaults on ROCm 7.2
+                # (profiles/r05_y_bench_default_dsplit_crash.txt); a process that captures only this world is fine.
                 if tr._d_stream is None:
                     tr._d_stream = torch.cuda.Stream(device=tr.device)
                 ops.prepare_capture_stream(tr.device, tr._d_stream)
                 d_batch = lambda: dict(batch, real_latents=seg.si[-1], gan_null_embeds=seg.si[3])
-                if os.environ.get("COMAT_D_SPLIT", "1") != "0":
+                if os.environ.get("COMAT_D_SPLIT", "0") == "1":
                     def d_fwd():
                         with ops.no_side_streams():
                             return tr._d_forward(dict(training_latents=seg.si[0].detach()), d_batch())
