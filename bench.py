@@ -542,6 +542,7 @@ def secondary_c4_own_process(timeout_s=400):
            "--steps", "4", "--warmup", "1"]
     t0 = time.time()
     env = dict(os.environ, COMAT_SECONDARY="0")
+    env.pop("COMAT_BENCH_DUMP", None)  # the parent's per-problem dump is the parent's
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
     if r.returncode != 0 or line is None:
@@ -565,6 +566,7 @@ def secondary_c2_bs4_own_process(bs=4, timeout_s=300):
            "--warmup", "1"]
     t0 = time.time()
     env = dict(os.environ, COMAT_SECONDARY="0", COMAT_PROBE_EAGER="0", COMAT_ATTN_MAP_PROBE="0")
+    env.pop("COMAT_BENCH_DUMP", None)  # the parent's per-problem dump is the parent's
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
     if r.returncode != 0 or line is None:

@@ -150,7 +150,7 @@ def main():
                 "mfma_busy_frac": dom.get("mfma_busy_frac"), "launches_in_pass": dom["launches"],
                 "note": "HBM-side bytes per gemm2_kernel launch averaged over every launch of whole eager C2 steps under "
                         "rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE and the SQ/GRBM counters in separate passes; "
-                        "tools/calls/r4_final.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE calibrated on a known stream"}
+                        "tools/calls/r5_final.sh); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE calibrated on a known stream"}
     json.dump(out, sys.stdout, indent=1)
     print()
 
