@@ -67,7 +67,7 @@ class GraphedSegment:
     def __init__(self, fn, name, stream=None, pool=None):
         self.fn, self.name, self.stream, self.pool = fn, name, stream, pool
         self.fg = self.bg = None
-        self.side_out = self.fwd_side_out = None
+        self.side_out = None
         self.replays = 0
         self.timing = None  # [] -> (kind, start event, end event) per replay (SegmentedStep(timing=True))
 
@@ -75,13 +75,10 @@ class GraphedSegment:
     def captured(self):
         return self.fg is not None
 
-    def capture(self, inputs, bwd_side=None, fwd_side=None):
+    def capture(self, inputs, bwd_side=None):
         """bwd_side = (fn, stream): fn() is captured INSIDE the backward graph on `stream`, forked at its beginning and
         joined at its end (work that is independent of this backward and should overlap it: the discriminator step);
-        its result is kept in `self.side_out`.  fwd_side = (fn, stream): the same inside the FORWARD graph, result in
-        `self.fwd_side_out` (the discriminator step's forward half: it reads the segment's input latents and nothing of the
-        head, so it overlaps VAE + BLIP; its backward half is then the bwd_side).  `stream` needs its own workspaces
-        (ops.prepare_capture_stream)."""
+        its result is kept in `self.side_out`.  `stream` needs its own workspaces (ops.prepare_capture_stream)."""
         dev = inputs[0].device
         st = self.stream or ops.capture_stream(dev)
         if self.pool is None:
@@ -93,14 +90,7 @@ class GraphedSegment:
         kw = _capture_kwargs()
         self.fg = torch.cuda.CUDAGraph()
         with ops.graph_capture(self.fg, pool=self.pool, stream=st, **kw):
-            if fwd_side is not None:
-                side_fn, side_st = fwd_side
-                side_st.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side_st):
-                    self.fwd_side_out = side_fn()
             outs = self.fn(*self.si)
-            if fwd_side is not None:
-                torch.cuda.current_stream(dev).wait_stream(side_st)
         outs = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
         self.out_req = [bool(o.requires_grad) for o in outs]
         self.sgo = [torch.zeros_like(o) if r else None for o, r in zip(outs, self.out_req)]
@@ -311,43 +301,25 @@ class SegmentedStep:
             seg = GraphedSegment(fn, "head")
             outs = fn(*inputs)
             self._img_hw = tr._last_image_hw
-            side = fside = None
+            side = None
             if d_in_head:
-                # The discriminator step reads the (detached) final latents and nothing of the generator's head or backward.
-                # Its FORWARD half is captured inside the head's forward graph and its BACKWARD half inside the head's backward
-                # graph, each on the discriminator's stream: ~8.5 ms under VAE + BLIP forward (11 ms) and ~10.7 ms under their
-                # backward (~11 ms) instead of the whole step (~19 ms) under the backward alone (round 4: head backward + D
-                # step 25 ms; two graphs launched on two streams do not overlap on this runtime: measured 176 vs 153 ms per C2
-                # step).  A fork from a forked stream crashes hipStreamEndCapture on ROCm 7.2, so its weight gradients stay
-                # on that stream.  OPT-IN (COMAT_D_SPLIT=1; default: the whole step inside the backward graph, as in rounds 3-4): it buys
-                # 3 ms of the head's two graphs and ~1 ms of a C3 step (profiles/r05_d_bench_c3_dsplit*.log), and inside the
-                # default bench line's process - which already holds the C2 graphs when the C3 world captures its head -
-                # hipStreamEndCapture of the forward graph with its two forked streams segfaults on ROCm 7.2
-                # (profiles/r05_y_bench_default_dsplit_crash.txt); a process that captures only this world is fine.
+                # The discriminator step reads the (detached) final latents and nothing of the generator's backward: it is
+                # captured INSIDE the head's backward graph on the discriminator's stream and overlaps it (two graphs
+                # launched on two streams do not overlap on this runtime: measured 176 vs 153 ms per C2 step).  A fork
+                # from a forked stream crashes hipStreamEndCapture on ROCm 7.2, so its weight gradients stay on that stream.
+                # (Round 5 also split the step - forward half inside the head's FORWARD graph, backward half here: head forward +
+                # backward 36.9 -> 33.7 ms per C3 step, ~1 ms of the step - but hipStreamEndCapture of a forward graph with two
+                # forked streams segfaults when the capturing process already holds the C2 graphs, as the default bench line's
+                # does (profiles/r05_y_bench_default_dsplit_crash.txt).  Branch exp/d-split.)
                 if tr._d_stream is None:
                     tr._d_stream = torch.cuda.Stream(device=tr.device)
                 ops.prepare_capture_stream(tr.device, tr._d_stream)
-                d_batch = lambda: dict(batch, real_latents=seg.si[-1], gan_null_embeds=seg.si[3])
-                if os.environ.get("COMAT_D_SPLIT", "0") == "1":
-                    def d_fwd():
-                        with ops.no_side_streams():
-                            return tr._d_forward(dict(training_latents=seg.si[0].detach()), d_batch())
 
-                    def d_bwd():
-                        # (the generator-side loss, recorded after the D forward, switched the discriminator's parameters to
-                        # requires_grad = False; autograd's AccumulateGrad checks the flag when it RUNS: without this the head's
-                        # weight and bias would silently get no gradient)
-                        tr.D.set_D_sd_pipeline_lora(True)
-                        with ops.no_side_streams():
-                            loss = seg.fwd_side_out
-                            loss.backward()
-                            return loss.detach()
-                    fside, side = (d_fwd, tr._d_stream), (d_bwd, tr._d_stream)
-                else:
-                    def d_side():
-                        with ops.no_side_streams():
-                            return tr._d_step_eager(dict(training_latents=seg.si[0].detach()), d_batch())
-                    side = (d_side, tr._d_stream)
+                def d_side():
+                    with ops.no_side_streams():
+                        return tr._d_step_eager(dict(training_latents=seg.si[0].detach()),
+                                                dict(batch, real_latents=seg.si[-1], gan_null_embeds=seg.si[3]))
+                side = (d_side, tr._d_stream)
                 # the capture must find every host-side memo of the discriminator's D-side call filled (its time embedding,
                 # targets): run that step once eagerly now.  It leaves nothing behind - the step's real D step, which
                 # follows in this same optimisation step, starts by zeroing the discriminator's gradients.
@@ -356,7 +328,7 @@ class SegmentedStep:
                 with torch.cuda.stream(tr._d_stream), ops.no_side_streams():
                     tr._d_step_eager(dict(training_latents=lat.detach()), batch)
                 cur.wait_stream(tr._d_stream)
-            if self._capture(seg, inputs, bwd_side=side, fwd_side=fside):
+            if self._capture(seg, inputs, bwd_side=side):
                 self.head_seg = seg
         else:
             outs = self.head_seg(*inputs)
