@@ -589,7 +589,7 @@ class LoRAStore:
 
     def _merge_entries(self, ents=None):
         """refresh the merged weights: every entry (ents None: one grouped launch + the entries it cannot take) or just
-        `ents` (a new entry)"""
+        `ents` (a new entry).  One scale per store (LoRAStore(scale=...) hands the same value to every group)."""
         k = kernels()
         if ents is None:
             if getattr(self, "_merge_table", None) is not None:
@@ -599,7 +599,7 @@ class LoRAStore:
             return
         for ent in ents:
             rows = self._entry_problems(ent)
-            if rows is None or any(g.scale != self.groups[0].scale for g in (ent["grp"],)):
+            if rows is None:
                 self._merge_into(ent)
                 continue
             import numpy as np
