@@ -105,3 +105,58 @@ def test_c1_full_size_matches_oracle_golden(hip):
     # measured 1.4e-5 (profiles/r04_z_grad_shrink_bisect.txt, row fff): an order of magnitude inside the north star's 1e-3
     assert np.sqrt(err_sq) <= 1e-4 * total_ref, f"flat LoRA gradient: estimated rel. error {np.sqrt(err_sq) / total_ref:.3e}"
     assert NPROJ == gold["grad_proj"].shape[1]
+
+
+def test_c2_full_size_gan_leg_matches_oracle_golden(hip):
+    """The GAN leg at FULL size ("full-size parity exists for C1's loss set only"): C2's loss set - concept matching +
+    generator-side discriminator loss, then the discriminator step on [fake.detach(); real] - on the SD1.5 generator and the SD1.5
+    discriminator in fp32 (exact-f32 MFMA) against tests/golden/c2_full.npz = the CPU oracle on the same seeded world
+    (tests/golden/make_c2_golden.py).  Scalars, the generator's and the discriminator's LoRA gradients (per-tensor norms + 8
+    Rademacher projections each) within the north star's 1e-3, the discriminator head's gradient element by element."""
+    from make_c2_golden import c2_inputs
+    from make_c1_golden import rademacher
+
+    from comat_amd.blip import Blip
+    from comat_amd.gan import D_sd
+    from comat_amd.pipeline import TrainableSDPipeline
+    from comat_amd.step import CoMatTrainer
+    from comat_amd.unet import LoRABank, UNet, VAEDecoder
+    path = os.path.join(HERE, "golden", "c2_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/c2_full.npz not generated")
+    gold = np.load(path)
+    (ucfg, vcfg, bcfg), sd, batch, scfg, ts, crop = c2_inputs()
+    dtype = torch.float32
+    bank = LoRABank(ucfg, sd["lora"], dtype, hip)
+    pipe = TrainableSDPipeline(UNet(ucfg, sd["unet"], dtype, hip, bank), VAEDecoder(vcfg, sd["vae"], dtype, hip))
+    dbank = LoRABank(ucfg, sd["d_lora"], dtype, hip)
+    disc = D_sd(UNet(ucfg, sd["d_unet"], dtype, hip, dbank), dbank, sd["head_w"], sd["head_b"])
+    trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], dtype, hip), disc, scfg, seed=0)
+    logs = trainer.train_step(batch, training_steps=ts, crop=crop)  # the gradients stay in the flat buffers after the update
+    torch.cuda.synchronize()
+    for key, gk in (("step_loss", "loss"), ("Blip", "blip_reward"), ("G_loss", "G_loss"), ("D_loss", "D_loss")):
+        assert abs(float(logs[key]) - float(gold[gk])) < 2e-4 * max(abs(float(gold[gk])), 1e-3), (key, float(logs[key]), float(gold[gk]))
+
+    def flat_error(bk, names, norms, projs, what):
+        total_ref = float(np.sqrt((norms ** 2).sum()))
+        err_sq = 0.0
+        for i, n in enumerate(names):
+            gr = bk.params[n].grad.detach().double().cpu().reshape(-1)
+            nref = float(norms[i])
+            assert abs(float(gr.norm()) - nref) <= 1e-3 * nref + 1e-6 * total_ref, f"{what} {n}: gradient norm"
+            p = (rademacher(n, gr.numel()).double() @ gr).numpy()
+            est = float(np.sqrt(np.mean((p - projs[i]) ** 2)))
+            assert est <= 3e-3 * nref + 3e-6 * total_ref, f"{what} {n}: estimated gradient error {est:.3e} vs norm {nref:.3e}"
+            err_sq += est ** 2
+        return float(np.sqrt(err_sq)) / total_ref
+
+    g_err = flat_error(bank, [str(n) for n in gold["names"]], gold["grad_norm"], gold["grad_proj"], "generator")
+    d_err = flat_error(dbank, [str(n) for n in gold["d_names"]], gold["d_grad_norm"], gold["d_grad_proj"], "discriminator")
+    path = os.environ.get("COMAT_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"c2_full float32 cuda g_grad_rel_err={g_err:.3e} d_grad_rel_err={d_err:.3e}\n")
+    assert g_err <= 1e-3 and d_err <= 1e-3, f"flat LoRA gradients: generator {g_err:.3e}, discriminator {d_err:.3e}"
+    hg = trainer.D.head_grad.detach().double().cpu().numpy()
+    assert np.abs(hg - gold["head_grad"]).max() <= 3e-3 * np.abs(gold["head_grad"]).max(), (hg, gold["head_grad"])
+
