@@ -156,7 +156,9 @@ def test_c2_full_size_gan_leg_matches_oracle_golden(hip):
     if path:
         with open(path, "a") as f:
             f.write(f"c2_full float32 cuda g_grad_rel_err={g_err:.3e} d_grad_rel_err={d_err:.3e}\n")
-    assert g_err <= 1e-3 and d_err <= 1e-3, f"flat LoRA gradients: generator {g_err:.3e}, discriminator {d_err:.3e}"
+    # measured on an MI355X: generator 1.2e-5, discriminator 1.5e-6 (profiles/r05_f_fullsize_c2.txt) - bounded an order of
+    # magnitude inside the north star's 1e-3, as the C1 check above
+    assert g_err <= 1e-4 and d_err <= 1e-4, f"flat LoRA gradients: generator {g_err:.3e}, discriminator {d_err:.3e}"
     hg = trainer.D.head_grad.detach().double().cpu().numpy()
     assert np.abs(hg - gold["head_grad"]).max() <= 3e-3 * np.abs(gold["head_grad"]).max(), (hg, gold["head_grad"])
 
