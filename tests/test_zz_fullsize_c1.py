@@ -162,3 +162,50 @@ def test_c2_full_size_gan_leg_matches_oracle_golden(hip):
     hg = trainer.D.head_grad.detach().double().cpu().numpy()
     assert np.abs(hg - gold["head_grad"]).max() <= 3e-3 * np.abs(gold["head_grad"]).max(), (hg, gold["head_grad"])
 
+
+def test_c3_full_size_attribute_concentration_leg_matches_oracle_golden(hip):
+    """The attribute-concentration leg at FULL size: concept matching + token-level and pixel-level concentration losses on the
+    cross-attention maps captured at one of two trained denoise steps (mid_8, up_16, up_32, up_64), SD1.5 generator, fp32, against
+    tests/golden/c3_full.npz = the CPU oracle on the same seeded world (tests/golden/make_c3_golden.py): loss terms and the LoRA
+    gradient (per-tensor norms + 8 Rademacher projections each)."""
+    from make_c1_golden import rademacher
+    from make_c3_golden import c3_inputs
+
+    from comat_amd.blip import Blip
+    from comat_amd.pipeline import TrainableSDPipeline
+    from comat_amd.step import CoMatTrainer
+    from comat_amd.unet import LoRABank, UNet, VAEDecoder
+    path = os.path.join(HERE, "golden", "c3_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/c3_full.npz not generated")
+    gold = np.load(path)
+    (ucfg, vcfg, bcfg), sd, batch, scfg, ts, crop, acs = c3_inputs()
+    dtype = torch.float32
+    bank = LoRABank(ucfg, sd["lora"], dtype, hip)
+    pipe = TrainableSDPipeline(UNet(ucfg, sd["unet"], dtype, hip, bank), VAEDecoder(vcfg, sd["vae"], dtype, hip))
+    trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], dtype, hip), None, scfg, seed=0)
+    bank.set_requires_grad(True)
+    bank.zero_grad()
+    out = trainer.compute_losses(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for key, gk in (("loss", "loss"), ("Blip", "blip_reward"), ("token_loss", "token_loss"), ("pixel_loss", "pixel_loss")):
+        assert abs(float(out[key]) - float(gold[gk])) < 2e-4 * max(abs(float(gold[gk])), 1e-3), (key, float(out[key]), float(gold[gk]))
+    names = [str(n) for n in gold["names"]]
+    total_ref = float(np.sqrt((gold["grad_norm"] ** 2).sum()))
+    err_sq = 0.0
+    for i, n in enumerate(names):
+        gr = bank.params[n].grad.detach().double().cpu().reshape(-1)
+        nref = float(gold["grad_norm"][i])
+        assert abs(float(gr.norm()) - nref) <= 1e-3 * nref + 1e-6 * total_ref, f"{n}: gradient norm"
+        p = (rademacher(n, gr.numel()).double() @ gr).numpy()
+        est = float(np.sqrt(np.mean((p - gold["grad_proj"][i]) ** 2)))
+        assert est <= 3e-3 * nref + 3e-6 * total_ref, f"{n}: estimated gradient error {est:.3e} vs norm {nref:.3e}"
+        err_sq += est ** 2
+    rel = float(np.sqrt(err_sq)) / total_ref
+    path = os.environ.get("COMAT_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"c3_full float32 cuda grad_rel_err={rel:.3e}\n")
+    assert rel <= 1e-3, f"flat LoRA gradient: estimated rel. error {rel:.3e}"
+
