@@ -190,7 +190,7 @@ def test_c3_full_size_attribute_concentration_leg_matches_oracle_golden(hip):
     out["loss"].backward()
     torch.cuda.synchronize()
     for key, gk in (("loss", "loss"), ("Blip", "blip_reward"), ("token_loss", "token_loss"), ("pixel_loss", "pixel_loss")):
-        assert abs(float(out[key]) - float(gold[gk])) < 2e-4 * max(abs(float(gold[gk])), 1e-3), (key, float(out[key]), float(gold[gk]))
+        assert abs(float(out[key].detach()) - float(gold[gk])) < 2e-4 * max(abs(float(gold[gk])), 1e-3), (key, float(out[key].detach()), float(gold[gk]))
     names = [str(n) for n in gold["names"]]
     total_ref = float(np.sqrt((gold["grad_norm"] ** 2).sum()))
     err_sq = 0.0
@@ -207,5 +207,6 @@ def test_c3_full_size_attribute_concentration_leg_matches_oracle_golden(hip):
     if path:
         with open(path, "a") as f:
             f.write(f"c3_full float32 cuda grad_rel_err={rel:.3e}\n")
-    assert rel <= 1e-3, f"flat LoRA gradient: estimated rel. error {rel:.3e}"
+    # measured on an MI355X: 1.0e-5 (profiles/r05_f_fullsize_c2.txt)
+    assert rel <= 1e-4, f"flat LoRA gradient: estimated rel. error {rel:.3e}"
 
