@@ -324,6 +324,9 @@ def build_world(device, dtype, rank, cfg_name, bs=1):
         m[1, 280 * res // 512:480 * res // 512, 260 * res // 512:500 * res // 512] = True
         batch["masks"] = [m] * bs
         batch["attributes"] = [[[2, 3], [6, 7]]] * bs
+    # inputs resident in HBM before anything is timed (the bench contract): the step's staging copies are then device-to-device
+    # and asynchronous, instead of fourteen pageable host-to-device copies that each wait for the stream to drain
+    batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, res - 2, res - 2))
     if cfg_name == "c2":
         fixed["training_steps"] = [0, 1, 2, 3, 4]
