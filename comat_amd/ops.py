@@ -163,7 +163,6 @@ class no_side_streams:
 
 _join_queued = False
 _side_dirty = []  # side streams that received work since the last join
-_dw_pending = []  # LoRAStores whose accumulated full weight gradients (COMAT_LORA_DW) await their projection
 
 
 def join_side_streams():
@@ -178,8 +177,6 @@ def join_side_streams():
         torch.cuda.current_stream(dev).wait_stream(st)
     _side_dirty.clear()
     _side_keep.clear()
-    for store in list(_dw_pending):  # COMAT_LORA_DW: factor gradients from the accumulated full weight gradients
-        store.project_factor_grads()
 
 
 def _queue_join():
@@ -207,8 +204,6 @@ def drop_side_stream_state():
     _ttq.clear()
     _side_dirty.clear()
     _side_keep.clear()
-    for store in list(_dw_pending):
-        store.discard_dw()
     _join_queued = False
 
 
@@ -483,7 +478,6 @@ class LoRAStore:
         self.flat_t = torch.empty(toff, dtype=dtype, device=device)
         self._fresh = False
         self._merged = {}
-        self._dw, self._dw_flat, self._dw_flat_c = {}, None, None
 
         def leaf(o, shp):
             n = shp[0] * shp[1]
@@ -641,91 +635,7 @@ class LoRAStore:
                 k.gemm(dct[:, i * r:(i + 1) * r], ucs[i], wmt[i], Kd, N, r, Gr, r, N, R=lin.wt, ldr=N, alpha=grp.scale,
                        beta=1.0)
 
-    # ---- COMAT_LORA_DW (experiment, round 5): factor gradients from the full weight gradient -----------------------------------
-    # dU = g^T (s x D^T) = s (g^T x) D^T and dD = (s g U)^T x = s U^T (g^T x): both are projections of dW = g^T x [N, K].  The
-    # backward pass then queues ONE k-major product per projection (accumulated in fp32 over every trained call of the step)
-    # instead of two rank-r GEMMs (h, u) plus two k-major products, and the projections run once per backward pass:
-    # cast dW to the compute dtype (one launch), dD += U^T dW (grouped k-major launches), dU += dW D^T (one GEMM per group),
-    # zero dW (one launch).  Needs s = 1 (the grouped kernel has no scale) - every configuration of the step has it.
-    def dw_buffers(self, grp, lins):
-        """fp32 [N_i, K] accumulators of the projections `lins` of group `grp` (views of one flat buffer once the store has seen
-        a whole backward pass: project_factor_grads compacts them - eagerly, never inside a capture)"""
-        key = (grp.index, tuple(id(l) for l in lins))
-        ent = self._dw.get(key)
-        if ent is None:
-            if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("full-weight-gradient buffers must exist before a capture begins (run the backward pass eagerly once)")
-            ent = self._dw[key] = dict(grp=grp, lins=tuple(lins),
-                                       dw=[torch.zeros(l.w.shape, dtype=torch.float32, device=self.device) for l in lins])
-            self._dw_flat = None  # layout changed: compact at the next projection
-        if self not in _dw_pending:
-            _dw_pending.append(self)
-        return ent["dw"]
-
-    def _compact_dw(self):
-        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("full-weight-gradient buffers changed inside a capture")
-        total = sum(d.numel() for ent in self._dw.values() for d in ent["dw"])
-        flat = torch.zeros(total, dtype=torch.float32, device=self.device)
-        off = 0
-        for ent in self._dw.values():
-            new = []
-            for d in ent["dw"]:
-                v = flat[off:off + d.numel()].view(d.shape)
-                v.copy_(d)
-                new.append(v)
-                off += d.numel()
-            ent["dw"] = new
-        self._dw_flat = flat
-        self._dw_flat_c = flat if self.dtype == torch.float32 else torch.empty(total, dtype=self.dtype, device=self.device)
-
-    def project_factor_grads(self):
-        """dU_i += dW_i D_i^T, dD_i += U_i^T dW_i for every accumulated projection, then dW = 0 (see above)"""
-        if self in _dw_pending:
-            _dw_pending.remove(self)
-        if not self._dw:
-            return
-        if getattr(self, "_dw_flat", None) is None:
-            self._compact_dw()
-        k = kernels()
-        flat, flat_c = self._dw_flat, self._dw_flat_c
-        if flat_c is not flat:
-            k.unary(UN_COPY, flat, flat_c, flat.numel())
-        self.ensure_compute_copy()
-        tt, rest, off = [], [], 0
-        for ent in self._dw.values():
-            grp, lins = ent["grp"], ent["lins"]
-            dc, ucs, _, _ = self.group_views[grp.index]
-            r = grp.rank
-            for i, (lin, d) in enumerate(zip(lins, ent["dw"])):
-                N, Kd = lin.w.shape
-                dwc = flat_c[off:off + d.numel()].view(N, Kd)
-                off += d.numel()
-                gd = grp.down_cat.grad[i * r:(i + 1) * r]
-                pr = (ucs[i], dwc, gd, r, Kd, N, r, Kd, Kd)  # dD_i [r, K] += U_i^T dW_i (contraction over the N rows of both)
-                (tt if (self.dtype != torch.float32 and k.tt_group_ok(*pr)) else rest).append(pr)
-                gu = grp.ups[i].grad                      # dU_i [N, r] += dW_i D_i^T (k-contiguous operands)
-                k.gemm(dwc, dc[i * r:(i + 1) * r], gu, N, r, Kd, Kd, Kd, r, R=gu, ldr=r, beta=1.0)
-        if tt:
-            k.gemm_tt_grouped(tt)
-        for A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc in rest:
-            k.gemm(A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc, transA=True, transB=True, R=Cacc, ldr=ldc, beta=1.0)
-        flat.zero_()  # dW = 0 for the next backward pass
-
-    def discard_dw(self):
-        """forget accumulated full weight gradients (an aborted backward pass / capture)"""
-        if self in _dw_pending:
-            _dw_pending.remove(self)
-        if getattr(self, "_dw_flat", None) is not None:
-            self._dw_flat.zero_()
-        else:
-            for ent in self._dw.values():
-                for d in ent["dw"]:
-                    d.zero_()
-
     def zero_grad(self):
-        if self in _dw_pending:  # a backward pass that never reached its join
-            self.discard_dw()
         self.flat_grad.zero_()
         for p in self._leaves:  # keep the views bound (the GEMM epilogues accumulate into them in place)
             if p.grad is None:
@@ -1318,16 +1228,6 @@ def set_train_merged(flag: bool):
     _train_merged = bool(flag)
 
 
-# COMAT_LORA_DW=1 (experiment, default 0; needs COMAT_TRAIN_MERGED): the factor gradients of the merged trained calls as projections
-# of the accumulated full weight gradient (LoRAStore.project_factor_grads) instead of rank-r products per call
-_lora_dw = os.environ.get("COMAT_LORA_DW", "0") == "1"
-
-
-def set_lora_dw(flag: bool):
-    global _lora_dw
-    _lora_dw = bool(flag)
-
-
 class _LoRAMergedLinear(Function):
     """(y_1 .. y_G) with y_i = x W_eff,i^T + b_i (+ residual),  W_eff,i = W_i + s U_i D_i  (LoRAStore.merged_weights: both
     orientations refreshed once per optimizer step) - the same function as _LoRAGroupLinear
@@ -1368,16 +1268,7 @@ class _LoRAMergedLinear(Function):
                 k.gemm_segments([(gs[i], wmt[i], lin.out_features, lin.out_features, lin.out_features)
                                  for i, lin in enumerate(lins)], dx, M, Kd, Kd)
         want_down, want_ups = ctx.needs_input_grad[4], ctx.needs_input_grad[5:]
-        if _lora_dw and want_down and all(want_ups) and grp.scale == 1.0:
-            dws = grp.store.dw_buffers(grp, lins)
-            probs = [(gs[i], x, dws[i], lin.out_features, Kd, M, lin.out_features, Kd, Kd) for i, lin in enumerate(lins)]
-            if _tt_grouping and all(k.tt_group_ok(*pr) for pr in probs):
-                _tt_enqueue(x.device, probs, (gs, x))
-            else:  # fp32 parity mode, odd shapes: one k-major product per projection on the issuing stream
-                for A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc in probs:
-                    k.gemm(A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc, transA=True, transB=True, R=Cacc, ldr=ldc, beta=1.0)
-                _queue_join()
-        elif want_down or any(want_ups):
+        if want_down or any(want_ups):
             dc, _, _, uts = grp.compute_copies()
             h = x.new_empty((M, Gr)) if any(want_ups) else None
             u = x.new_empty((M, Gr)) if want_down else None

@@ -478,20 +478,17 @@ def test_transpose_cast_tiles(dev, dtype):
 def train_merged_default():
     yield
     ops.set_train_merged(os.environ.get("COMAT_TRAIN_MERGED", "1") != "0")
-    ops.set_lora_dw(os.environ.get("COMAT_LORA_DW", "0") == "1")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("G", [1, 3])
-@pytest.mark.parametrize("merged", [True, False, "dw"])
+@pytest.mark.parametrize("merged", [True, False])
 def test_lora_group_linear(dev, dtype, G, merged, train_merged_default):
     """Projections sharing one input, each frozen Linear + LoRA branch (+ residual for a single projection):
     outputs, dx, dresidual and the fp32 LoRA gradients accumulated in place into the store's flat buffer - in the merged-weight
     form of round 5 (one plain GEMM forward, dx through the transposed merged weight, factor gradients on the side) and in the
-    low-rank form of rounds 1-4, against the same torch reference.  "dw" (COMAT_LORA_DW, an opt-in experiment): the merged form
-    with the factor gradients projected from the accumulated full weight gradient g^T x at the end of the backward pass."""
-    ops.set_train_merged(bool(merged))
-    ops.set_lora_dw(merged == "dw")
+    low-rank form of rounds 1-4, against the same torch reference."""
+    ops.set_train_merged(merged)
     M, K, r = 130, 64, 8
     Ns = [96, 64, 80][:G]
     x = rnd(M, K, dtype=dtype, seed=1)
