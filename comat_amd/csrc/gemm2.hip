@@ -27,6 +27,7 @@
 // Fragment rule (as gemm.hip): lane (r = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h .. + 8 of row r for
 // both operands, so the k-permutation inside the MFMA cancels.
 #include "gemm_shared.h"
+#include <type_traits>
 
 namespace {
 
@@ -92,11 +93,13 @@ __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, con
 
 // split-K combine (inside the launch) + fused epilogue of one block tile; shared by the k-contiguous and the k-major kernel
 // -> true for the block that ran the tile's epilogue (every block when the problem is not split)
-template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false>
+// SPLITK = false compiles the in-launch combine out (the 256 x 256 ping-pong shape: its 128 accumulator registers per lane leave
+// no room for the slab double buffer, and its problems have tiles enough; the host never splits it)
+template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false, bool SPLITK = true>
 __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
                                           int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
     // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
-    if (g.splits > 1) {
+    if (SPLITK && g.splits > 1) {
         constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
         const SlabIO io(g.ws + WS_COUNTERS);
         const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 32 * KS];  // the ONLY LDS object of the kernel
     gemm2_body<BM, BN, WM, WN, NST, CONV, EB, KS>(g, blockIdx.x, gridDim.x, smem);
 }
+
+#include "gemm2_pp.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
 // k-major operands: C[M, N] (+)= A^T B with A stored [K, M] and B stored [K, N] (rows = k).  This is every LoRA weight
@@ -901,7 +906,9 @@ template <int NST> __global__ __launch_bounds__(256, 2) void gemm2_tt_group_kern
 enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
        CFG_128x128_W8 = 7,
        // 128-byte k-tiles (KS = 4): half as many barrier / wait / issue rounds along k, for latency-bound problems
-       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11, CFG_LAST = 11 };
+       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11,
+       // ping-pong main loop (gemm2_pp.inc): 8 waves in two groups, 128-byte k-tiles
+       CFG_PP_256x256 = 12, CFG_PP_128x128 = 13, CFG_LAST = 13 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -916,16 +923,21 @@ static Cfg2 cfg_dims(int c) {
         case CFG_64x64_K4: return {64, 64, 256};
         case CFG_128x64_K4: return {128, 64, 256};
         case CFG_64x128_K4: return {64, 128, 256};
+        case CFG_PP_256x256: return {256, 256, 512};
+        case CFG_PP_128x128: return {128, 128, 512};
         default: return {128, 128, 256};
     }
 }
-static bool cfg_is_k4(int c) { return c >= CFG_64x64_K4 && c <= CFG_128x128_K4; }
+static bool cfg_is_pp(int c) { return c == CFG_PP_256x256 || c == CFG_PP_128x128; }
+static bool cfg_is_k4(int c) { return (c >= CFG_64x64_K4 && c <= CFG_128x128_K4) || cfg_is_pp(c); }  // 128-byte k-tiles
 static int cfg_k2_twin(int c) {  // the same block shape with 64-byte k-tiles
     switch (c) {
         case CFG_64x64_K4: return CFG_64x64;
         case CFG_128x64_K4: return CFG_128x64;
         case CFG_64x128_K4: return CFG_64x128;
         case CFG_128x128_K4: return CFG_128x128;
+        case CFG_PP_256x256: return CFG_256x128;
+        case CFG_PP_128x128: return CFG_128x128_W8;
         default: return c;
     }
 }
@@ -952,6 +964,12 @@ template <bool CONV> static void launch_cfg_k4(int c, const Args2& a, unsigned b
         case CFG_64x128_K4: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
     }
+}
+
+// ping-pong main loop: 256 x 256 (ring of 2 k-tile buffers = 128 KiB) and 128 x 128 (ring of 4 = 128 KiB), bf16
+template <bool CONV> static void launch_cfg_pp(int c, const Args2& a, unsigned blocks, hipStream_t st) {
+    if (c == CFG_PP_256x256) hipLaunchKernelGGL((gemm2_pp_kernel<256, 256, 2, 4, 2, CONV>), dim3(blocks), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm2_pp_kernel<128, 128, 2, 4, 4, CONV>), dim3(blocks), dim3(512), 0, st, a);
 }
 
 // options (runtime.hip): gemm2 = 0 routes everything to gemm.hip's general kernel; g2_cfg / g2_splits force the block
@@ -1094,6 +1112,7 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
             const int64_t n2 = a.nkt / 2;
             if (s > n2) s = (int)(n2 > 0 ? n2 : 1);
             s = (int)cdiv64(n2, cdiv64(n2, s));
+            if (c == CFG_PP_256x256) s = 1;
         }
     }
     const Cfg2 d = cfg_dims(c);
@@ -1110,6 +1129,11 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
         if (conv) launch_cfg<true, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
         else launch_cfg<false, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
         return 3;
+    }
+    if (cfg_is_pp(c)) {
+        if (conv) launch_cfg_pp<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        else launch_cfg_pp<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
+        return 1;
     }
     if (cfg_is_k4(c)) {
         if (conv) launch_cfg_k4<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
