@@ -71,9 +71,13 @@ template <int L, int MAXT> __device__ __forceinline__ void wait_tiles(int tiles)
     else if constexpr (MAXT > 0) wait_tiles<L, MAXT - 1>(tiles);
 }
 
+// COMAT_G2_AUX: cache-policy bits of the LDS-DMA loads (1 = sc0, 2 = nt, 16 = sc1); build-time, for A/B runs of two libraries
+#ifndef COMAT_G2_AUX
+#define COMAT_G2_AUX 0
+#endif
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, COMAT_G2_AUX);
 }
 
 // fp8 (OCP e4m3): one 32x32x64 MFMA consumes the whole 64-byte k-tile; lane (r, h) supplies the two 16-byte chunks it
@@ -1146,6 +1150,12 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
 }
 
 }  // namespace
+
+#ifdef COMAT_PP_TIMELINE
+extern "C" int cmt_dbg_pp_timeline(unsigned* dst) {  // diagnostic build only: the stamps of the last ping-pong launch
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp_tl), sizeof(unsigned) * 2 * TL_MAX, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // k-major x k-major (LoRA weight gradients): C[M, N] = A^T B, A stored [K, M], B stored [K, N]
 static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
