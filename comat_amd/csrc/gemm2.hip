@@ -27,7 +27,6 @@
 // Fragment rule (as gemm.hip): lane (r = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h .. + 8 of row r for
 // both operands, so the k-permutation inside the MFMA cancels.
 #include "gemm_shared.h"
-#include <type_traits>
 
 namespace {
 
@@ -71,13 +70,9 @@ template <int L, int MAXT> __device__ __forceinline__ void wait_tiles(int tiles)
     else if constexpr (MAXT > 0) wait_tiles<L, MAXT - 1>(tiles);
 }
 
-// COMAT_G2_AUX: cache-policy bits of the LDS-DMA loads (1 = sc0, 2 = nt, 16 = sc1); build-time, for A/B runs of two libraries
-#ifndef COMAT_G2_AUX
-#define COMAT_G2_AUX 0
-#endif
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, COMAT_G2_AUX);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // fp8 (OCP e4m3): one 32x32x64 MFMA consumes the whole 64-byte k-tile; lane (r, h) supplies the two 16-byte chunks it
@@ -97,13 +92,11 @@ __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, con
 
 // split-K combine (inside the launch) + fused epilogue of one block tile; shared by the k-contiguous and the k-major kernel
 // -> true for the block that ran the tile's epilogue (every block when the problem is not split)
-// SPLITK = false compiles the in-launch combine out (the 256 x 256 ping-pong shape: its 128 accumulator registers per lane leave
-// no room for the slab double buffer, and its problems have tiles enough; the host never splits it)
-template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false, bool SPLITK = true>
+template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false>
 __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
                                           int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
     // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
-    if (SPLITK && g.splits > 1) {
+    if (g.splits > 1) {
         constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
         const SlabIO io(g.ws + WS_COUNTERS);
         const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
@@ -502,8 +495,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(Args2 g) {
     __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 32 * KS];  // the ONLY LDS object of the kernel
     gemm2_body<BM, BN, WM, WN, NST, CONV, EB, KS>(g, blockIdx.x, gridDim.x, smem);
 }
-
-#include "gemm2_pp.inc"
 
 // ---------------------------------------------------------------------------------------------------------------
 // k-major operands: C[M, N] (+)= A^T B with A stored [K, M] and B stored [K, N] (rows = k).  This is every LoRA weight
@@ -910,9 +901,7 @@ template <int NST> __global__ __launch_bounds__(256, 2) void gemm2_tt_group_kern
 enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
        CFG_128x128_W8 = 7,
        // 128-byte k-tiles (KS = 4): half as many barrier / wait / issue rounds along k, for latency-bound problems
-       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11,
-       // ping-pong main loop (gemm2_pp.inc): 8 waves in two groups, 128-byte k-tiles
-       CFG_PP_256x256 = 12, CFG_PP_128x128 = 13, CFG_LAST = 13 };
+       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11, CFG_LAST = 11 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -927,21 +916,16 @@ static Cfg2 cfg_dims(int c) {
         case CFG_64x64_K4: return {64, 64, 256};
         case CFG_128x64_K4: return {128, 64, 256};
         case CFG_64x128_K4: return {64, 128, 256};
-        case CFG_PP_256x256: return {256, 256, 512};
-        case CFG_PP_128x128: return {128, 128, 512};
         default: return {128, 128, 256};
     }
 }
-static bool cfg_is_pp(int c) { return c == CFG_PP_256x256 || c == CFG_PP_128x128; }
-static bool cfg_is_k4(int c) { return (c >= CFG_64x64_K4 && c <= CFG_128x128_K4) || cfg_is_pp(c); }  // 128-byte k-tiles
+static bool cfg_is_k4(int c) { return c >= CFG_64x64_K4 && c <= CFG_128x128_K4; }
 static int cfg_k2_twin(int c) {  // the same block shape with 64-byte k-tiles
     switch (c) {
         case CFG_64x64_K4: return CFG_64x64;
         case CFG_128x64_K4: return CFG_128x64;
         case CFG_64x128_K4: return CFG_64x128;
         case CFG_128x128_K4: return CFG_128x128;
-        case CFG_PP_256x256: return CFG_256x128;
-        case CFG_PP_128x128: return CFG_128x128_W8;
         default: return c;
     }
 }
@@ -968,12 +952,6 @@ template <bool CONV> static void launch_cfg_k4(int c, const Args2& a, unsigned b
         case CFG_64x128_K4: hipLaunchKernelGGL((gemm2_kernel<64, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, 2, 4>), dim3(blocks), dim3(256), 0, st, a); break;
     }
-}
-
-// ping-pong main loop: 256 x 256 (ring of 2 k-tile buffers = 128 KiB) and 128 x 128 (ring of 4 = 128 KiB), bf16
-template <bool CONV> static void launch_cfg_pp(int c, const Args2& a, unsigned blocks, hipStream_t st) {
-    if (c == CFG_PP_256x256) hipLaunchKernelGGL((gemm2_pp_kernel<256, 256, 2, 4, 2, CONV>), dim3(blocks), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((gemm2_pp_kernel<128, 128, 2, 4, 4, CONV>), dim3(blocks), dim3(512), 0, st, a);
 }
 
 // options (runtime.hip): gemm2 = 0 routes everything to gemm.hip's general kernel; g2_cfg / g2_splits force the block
@@ -1116,7 +1094,6 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
             const int64_t n2 = a.nkt / 2;
             if (s > n2) s = (int)(n2 > 0 ? n2 : 1);
             s = (int)cdiv64(n2, cdiv64(n2, s));
-            if (c == CFG_PP_256x256) s = 1;
         }
     }
     const Cfg2 d = cfg_dims(c);
@@ -1134,11 +1111,6 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
         else launch_cfg<false, 1>(c, a, (unsigned)blocks, (hipStream_t)stream);
         return 3;
     }
-    if (cfg_is_pp(c)) {
-        if (conv) launch_cfg_pp<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
-        else launch_cfg_pp<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
-        return 1;
-    }
     if (cfg_is_k4(c)) {
         if (conv) launch_cfg_k4<true>(c, a, (unsigned)blocks, (hipStream_t)stream);
         else launch_cfg_k4<false>(c, a, (unsigned)blocks, (hipStream_t)stream);
@@ -1150,12 +1122,6 @@ static int finish_launch(Args2& a, bool conv, bool fp8, int64_t batch, void* ws,
 }
 
 }  // namespace
-
-#ifdef COMAT_PP_TIMELINE
-extern "C" int cmt_dbg_pp_timeline(unsigned* dst) {  // diagnostic build only: the stamps of the last ping-pong launch
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_pp_tl), sizeof(unsigned) * 2 * TL_MAX, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 // k-major x k-major (LoRA weight gradients): C[M, N] = A^T B, A stored [K, M], B stored [K, N]
 static int try_gemm_tt(const comat_gemm_params* p, void* stream) {
