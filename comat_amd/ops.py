@@ -569,6 +569,8 @@ class LoRAStore:
         """device tables of ONE comat_lora_merge launch over every merged entry the grouped kernel takes (rebuilt whenever
         an entry is added - eagerly: the refresh inside a captured step only reads them)"""
         import numpy as np
+        # one launch, one scale: the groups of a store share it (LoRAStore(scale=...) hands the same value to every group)
+        assert all(g.scale == self.groups[0].scale for g in self.groups), "LoRA groups of one store must share their scale"
         probs, tiles, rest = [], [], []
         for ent in self._merged.values():
             rows = self._entry_problems(ent)
@@ -581,6 +583,11 @@ class LoRAStore:
                 n0, k0 = np.meshgrid(np.arange(0, N, 64), np.arange(0, Kd, 64), indexing="ij")
                 tiles.append(np.stack([np.full(n0.size, pi), n0.reshape(-1), k0.reshape(-1)], 1))
         self._merge_rest = rest
+        # a graph captured earlier replays comat_lora_merge with the addresses of the table it saw: superseded tables stay alive
+        # (a few KB each; entries are only ever added while the model's first eager step runs)
+        old = getattr(self, "_merge_table", None)
+        if old is not None:
+            self._merge_tables_kept = getattr(self, "_merge_tables_kept", []) + [old]
         if probs:
             self._merge_table = (torch.tensor(probs, dtype=torch.int64).to(self.device),
                                  torch.from_numpy(np.concatenate(tiles).astype(np.int32)).to(self.device))
@@ -1243,6 +1250,7 @@ class _LoRAMergedLinear(Function):
         ys = _merged_forward(x, lins, grp, residual)
         ctx.save_for_backward(x)
         ctx.grp, ctx.lins = grp, lins
+        ctx.epoch = getattr(grp.store, "epoch", 0)  # the merged weights this forward multiplied by
         ctx.has_res = residual is not None
         assert down_cat.grad is not None and all(u.grad is not None for u in ups), \
             "LoRA factors need preallocated .grad views"
@@ -1260,6 +1268,10 @@ class _LoRAMergedLinear(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             _, wmt = grp.store.merged_weights(grp, lins)
+            # (merged_weights refreshes lazily: an optimizer step of this store between a forward and its backward would hand
+            # the backward other weights than the forward used)
+            assert getattr(grp.store, "epoch", 0) == ctx.epoch, \
+                "LoRA factors were updated between a trained call's forward and its backward"
             dx = x.new_empty((M, Kd))
             if G == 1:
                 N = lins[0].out_features
