@@ -34,6 +34,7 @@ class GemmParams(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
         ("C2", C.c_void_p), ("ldc2", C.c_int64), ("epi2", C.c_int32),
+        ("B2", C.c_void_p), ("n2", C.c_int64), ("sB2_tail", C.c_int64), ("sC2_tail", C.c_int64), ("alpha2", C.c_float),  # epi2 = 4 (ABI 7)
     ]
 
 
@@ -115,7 +116,7 @@ SIGNATURES = {
     "comat_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
-ABI_VERSION = 6
+ABI_VERSION = 7
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
 
 _lib = None
@@ -264,12 +265,19 @@ class HipKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
              sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
-             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None):
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None):
         """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h);
         geglu = (C2 [M, N / 2], keep_pre): the GEGLU epilogue over interleaved value / gate columns (comat_gemm_params::epi2):
         C2 receives value * gelu(gate); Cout receives the pre-activations only when keep_pre (it may be None otherwise);
-        geglu = (pre [M, 2 N], "bwd"): the GEGLU backward epilogue (epi2 = 3): Cout [M, 2 N] = gradient of the pre-activations"""
+        geglu = (pre [M, 2 N], "bwd"): the GEGLU backward epilogue (epi2 = 3): Cout [M, 2 N] = gradient of the pre-activations;
+        tail = (B2 [n2, K], C2, n2, ldc2, sB2, sC2, alpha2): tail columns (epi2 = 4): N counts the n2 extra columns, whose rows of
+        B come from B2 (batch stride sB2) and which are written to C2 (leading dimension ldc2, batch stride sC2) as alpha2 * A B2^T"""
         p = GemmParams()
+        if tail is not None:
+            assert geglu is None and not transA and not transB
+            B2, C2t, n2, ldc2, sB2t, sC2t, alpha2 = tail
+            assert B2.dtype == B.dtype and C2t.dtype == Cout.dtype
+            p.B2, p.C2, p.n2, p.ldc2, p.sB2_tail, p.sC2_tail, p.alpha2, p.epi2 = _ptr(B2), _ptr(C2t), n2, ldc2, sB2t, sC2t, alpha2, 4
         if geglu is not None and geglu[1] == "bwd":  # epi2 = 3: geglu[0] = the saved pre-activations [M, 2 N], Cout [M, 2 N] their gradient
             p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 3
             assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous() and Cout.dtype == torch.bfloat16

@@ -711,9 +711,13 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->batch1 >= 1 && p->batch2 >= 1 && p->batch1 * p->batch2 <= 65535, "comat_gemm: bad batch");
     COMAT_REQUIRE(!p->bias2 || p->rows_per_bias2 > 0, "comat_gemm: bias2 needs rows_per_bias2");
     COMAT_REQUIRE(p->K < (1ll << 30), "comat_gemm: K too large");
-    COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) && p->ldc >= p->N,
+    COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) &&
+                      p->ldc >= p->N - (p->epi2 == 4 ? p->n2 : 0),  // (tail columns, epi2 = 4: C holds the first N - n2 columns)
                   "comat_gemm: leading dimension too small");
-    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && p->epi2 >= 1 && p->epi2 <= 3), "comat_gemm: bad second epilogue");
+    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && p->epi2 >= 1 && p->epi2 <= 4), "comat_gemm: bad second epilogue");
+    if (p->epi2 == 4)
+        COMAT_REQUIRE(p->B2 != nullptr && p->n2 > 0 && p->n2 < p->N && p->ldc2 >= p->n2 && !p->transA && !p->transB && p->batch2 == 1,
+                      "comat_gemm: tail columns (epi2 = 4) need B2, 0 < n2 < N, ldc2 >= n2, k-contiguous operands, one batch level");
     if (p->epi2 == 0 && p->in_dtype == COMAT_BF16 && !p->transA && !p->transB && p->batch2 == 1) {  // lean kernel first (option gemm3)
         const comat_gemm_segment one = {p->A, p->B, p->K, p->lda, p->ldb, p->sA1, p->sB1};
         const int rc3 = comat_gemm3_try(p, &one, 1, false, stream);
@@ -725,6 +729,17 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
+    if (p->epi2 == 4) {  // tail columns outside the pipelined kernel: the two products one after the other, same results
+        comat_gemm_params q = *p;
+        q.epi2 = 0; q.C2 = nullptr; q.B2 = nullptr; q.n2 = 0;
+        q.N = p->N - p->n2;
+        int rc = comat_gemm(&q, stream);
+        if (rc) return rc;
+        q.B = p->B2; q.sB1 = p->sB2_tail; q.N = p->n2;
+        q.C = p->C2; q.ldc = p->ldc2; q.sC1 = p->sC2_tail;
+        q.bias = nullptr; q.bias2 = nullptr; q.R = nullptr; q.act = COMAT_ACT_NONE; q.alpha = p->alpha2; q.beta = 0.0f;
+        return comat_gemm(&q, stream);
+    }
     if (p->epi2 == 3) {  // GEGLU backward epilogue, two-launch form: dF into the workspace, then the elementwise kernel
         COMAT_REQUIRE(p->in_dtype == COMAT_BF16 && p->out_dtype == COMAT_BF16 && p->N % 16 == 0 && p->batch1 * p->batch2 == 1 &&
                           !p->R && !p->bias && !p->bias2 && p->act == COMAT_ACT_NONE && p->ldc == 2 * p->N && p->ldc2 == 2 * p->N,

@@ -61,6 +61,9 @@ struct Args2 {
     int vec;  // 16-byte epilogue accesses are legal (alignment / divisibility checked by the host)
     const float* scale_a;  // fp8 operands: device pointers to the per-tensor dequantisation scales (NULL = 1)
     const float* scale_b;
+    // epi2 == 4 (tail columns, single-segment GEMM only): rows >= N - ep.n2 of B come from B2 (leading dimension seg[0].ldb)
+    const char* B2;
+    int64_t sB2t, sC2t;  // batch strides of B2 (bytes) and C2 (elements)
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -161,6 +164,8 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
     if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
     if (ep.bias) ep.bias += z * g.sBias;
+    if (ep.epi2 == 4) ep.C2 = (char*)ep.C2 + z * g.sC2t * (ep.out_dt == COMAT_F32 ? 4 : 2);
+    const int64_t nmain = g.N - (ep.epi2 == 4 ? ep.n2 : 0);  // tail columns: [nmain, N) go to C2 (8-column pieces never straddle)
     const bool vec = g.vec != 0;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
@@ -180,6 +185,13 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                 if (m < g.M) {
                     if (nb < g.N) epilogue_geglu_bwd(ep, v, m, nb);
                     if (nb + 16 < g.N) epilogue_geglu_bwd(ep, v + 8, m, nb + 16);
+                }
+            } else if (ep.epi2 == 4) {  // tail columns: the first epilogue for columns < nmain, alpha2 * product into C2 behind
+                if (m < g.M) {
+                    if (nb < nmain) epilogue_run<WT>(ep, v, m, nb, nmain, vec);
+                    else if (nb < g.N) epilogue_tail(ep, v, m, nb - nmain);
+                    if (nb + 16 < nmain) epilogue_run<WT>(ep, v + 8, m, nb + 16, nmain, vec);
+                    else if (nb + 16 < g.N) epilogue_tail(ep, v + 8, m, nb + 16 - nmain);
                 }
             } else if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
                 if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
@@ -311,7 +323,11 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
 #pragma unroll
         for (int i = 0; i < IA; ++i) pa[i] = sg.A + z * sg.sA + arow_[i] * sg.lda + (int64_t)t0 * RBK + csrc * 16;
 #pragma unroll
-        for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + (int64_t)t0 * RBK + csrc * 16;
+        for (int i = 0; i < IB; ++i) {
+            const int64_t ntail = g.B2 ? g.N - g.ep.n2 : g.N;  // rows of B from here on live in B2 (tail columns, one segment only)
+            const char* bb2 = brow_[i] < ntail ? sg.B + z * sg.sB + brow_[i] * sg.ldb : g.B2 + z * g.sB2t + (brow_[i] - ntail) * sg.ldb;
+            pb[i] = bb2 + (int64_t)t0 * RBK + csrc * 16;
+        }
     }
 
     // issue the DMA of the next k-tile of this block's range into ring stage `st`
@@ -1034,6 +1050,7 @@ static void fill_epi(Args2& a, const comat_gemm_params* p) {
     a.ep.alpha = p->alpha; a.ep.beta = p->beta; a.ep.act = p->act;
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
     a.ep.C2 = p->C2; a.ep.ldc2 = p->ldc2; a.ep.epi2 = p->epi2;
+    a.ep.n2 = p->epi2 == 4 ? p->n2 : 0; a.ep.alpha2 = p->alpha2;
 }
 
 // 16-byte epilogue accesses: 8 columns per lane must stay inside a row and every row start must be 16-byte aligned
@@ -1191,7 +1208,16 @@ int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
     a.scale_a = fp8 ? p->scale_a : nullptr;
     a.scale_b = fp8 ? p->scale_b : nullptr;
     fill_epi(a, p);
-    if (p->epi2 == 3) {  // GEGLU backward epilogue: C, C2 [M, 2 N] bf16 with 16-byte rows, nothing else fused
+    if (p->epi2 == 4) {  // tail columns: 8-column pieces on both sides of the seam, 16-byte rows of C2 and B2; else two launches
+        const int es = p->out_dtype == COMAT_F32 ? 4 : 8;
+        if (fp8 || !p->B2 || !p->C2 || p->n2 <= 0 || p->n2 >= p->N || p->n2 % 8 || (p->N - p->n2) % 8 || !al16(p->C2) || !al16(p->B2) ||
+            p->ldc2 % es || p->sC2_tail % es || p->sB2_tail % ch || p->ldc2 < p->n2 ||
+            !epi_vec_ok(a.ep, p->N, a.sC, a.sR, a.sBias, a.M))
+            return 0;
+        a.B2 = (const char*)p->B2;
+        a.sB2t = p->sB2_tail * eb;
+        a.sC2t = p->sC2_tail;
+    } else if (p->epi2 == 3) {  // GEGLU backward epilogue: C, C2 [M, 2 N] bf16 with 16-byte rows, nothing else fused
         if (p->out_dtype != COMAT_BF16 || p->N % 16 || p->R || p->bias || p->bias2 || p->act != COMAT_ACT_NONE || p->batch1 > 1 || !p->C ||
             !p->C2 || !al16(p->C) || !al16(p->C2) || p->ldc % 8 || p->ldc2 % 8 || p->ldc < 2 * p->N || p->ldc2 < 2 * p->N)
             return -1;

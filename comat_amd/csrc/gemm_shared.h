@@ -17,6 +17,9 @@ struct Epi {
     void* C2;
     int64_t ldc2;
     int epi2;
+    // epi2 == 4 (tail columns): the last n2 columns of the product go to C2 as alpha2 * product
+    int64_t n2;
+    float alpha2;
 };
 
 // XCD-aware workgroup -> work-item map.  Workgroup b is dispatched to XCD b % 8 (MI355X: 8 XCDs, a private 4 MiB L2
@@ -162,6 +165,20 @@ __device__ __forceinline__ void epilogue_run(const Epi& ep, float* v, int64_t m,
                 st_dt(ep.C, m * ep.ldc + col, x, ep.out_dt);
             }
         }
+    }
+}
+
+// epi2 == 4: 8 consecutive TAIL columns c .. c + 7 (column index inside C2) of output row m: C2[m, c ..] = alpha2 * v
+__device__ __forceinline__ void epilogue_tail(const Epi& ep, const float* v, int64_t m, int64_t c) {
+    if (ep.out_dt == COMAT_F32) {
+        float* pc = (float*)ep.C2 + m * ep.ldc2 + c;
+        *(float4*)pc = make_float4(v[0] * ep.alpha2, v[1] * ep.alpha2, v[2] * ep.alpha2, v[3] * ep.alpha2);
+        *(float4*)(pc + 4) = make_float4(v[4] * ep.alpha2, v[5] * ep.alpha2, v[6] * ep.alpha2, v[7] * ep.alpha2);
+    } else {
+        Pack16 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pk.h[e] = f32_to_bf16(v[e] * ep.alpha2);
+        *(uint4*)((bf16_t*)ep.C2 + m * ep.ldc2 + c) = pk.u;
     }
 }
 

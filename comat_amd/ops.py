@@ -1200,27 +1200,51 @@ class _LoRAGroupLinear(Function):
         return (dx, (gs[0] if ctx.has_res else None), None, None, None) + (None,) * G
 
 
-def _merged_forward(x, lins, grp, residual):
+# COMAT_LORA_TAIL (default 1, round 6): the rank-r products the factor gradients need ride in the launch that shares their A operand
+# (comat_gemm_params::epi2 = 4, "tail columns"): h = s x D^T as r extra output columns of the forward projection, u = s g U as r
+# extra columns of a single projection's data-gradient.  0 = both as launches of their own in front of the weight-gradient group
+# (round 5).  Same operands, fp32 accumulation, same rounding: the results differ at most in summation order.
+_lora_tail = os.environ.get("COMAT_LORA_TAIL", "1") != "0"
+
+
+def set_lora_tail(flag: bool):
+    global _lora_tail
+    _lora_tail = bool(flag)
+
+
+def _merged_forward(x, lins, grp, residual, h=None):
     """y_i = x (W_i + s U_i D_i)^T + b_i (+ residual): one plain GEMM per projection or one batched GEMM for a co-allocated
-    group; no low-rank activations, no segments."""
+    group; no segments.  h [M, G r] (optional): receives s x [D_1; ..; D_G]^T from the SAME launches (tail columns of the
+    products: the down factors' compute copies are the extra rows of B)."""
     x = _c(x)
     M, Kd = x.shape
     wm, _ = grp.store.merged_weights(grp, lins)
     k = kernels()
-    G = len(lins)
+    G, r = len(lins), grp.rank
+    Gr = G * r
+    dc = grp.compute_copies()[0] if h is not None else None
     sm = _uniform_stride(wm)
     if G > 1 and sm is not None and residual is None and all(l.bias is None for l in lins):
         N = lins[0].out_features
         ys = x.new_empty((G, M, N))
-        k.gemm(x, wm[0], ys, M, N, Kd, Kd, Kd, N, batch=(G, 1), sA=(0, 0), sB=(sm, 0), sC=(M * N, 0))
+        if h is None:
+            k.gemm(x, wm[0], ys, M, N, Kd, Kd, Kd, N, batch=(G, 1), sA=(0, 0), sB=(sm, 0), sC=(M * N, 0))
+        else:
+            k.gemm(x, wm[0], ys, M, N + r, Kd, Kd, Kd, N, batch=(G, 1), sA=(0, 0), sB=(sm, 0), sC=(M * N, 0),
+                   tail=(dc, h, r, Gr, r * Kd, r, grp.scale))
         return tuple(ys.unbind(0))
     ys = []
     if residual is not None:
         residual = _c(residual)
-    for lin, w in zip(lins, wm):
+    for i, (lin, w) in enumerate(zip(lins, wm)):
         N = lin.out_features
         y = x.new_empty((M, N))
-        k.gemm(x, w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=1.0 if residual is not None else 0.0)
+        beta = 1.0 if residual is not None else 0.0
+        if h is None:
+            k.gemm(x, w, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=beta)
+        else:
+            k.gemm(x, w, y, M, N + r, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=beta,
+                   tail=(dc[i * r:(i + 1) * r], h[:, i * r:(i + 1) * r], r, Gr, 0, 0, grp.scale))
         ys.append(y)
     return tuple(ys)
 
@@ -1247,8 +1271,14 @@ class _LoRAMergedLinear(Function):
     @staticmethod
     def forward(ctx, x, residual, grp, lins, down_cat, *ups):
         x = _c(x)
-        ys = _merged_forward(x, lins, grp, residual)
-        ctx.save_for_backward(x)
+        # the up factors' gradients dU_i += g_i^T h_i need h = s x D^T: r extra columns of this launch (round 6) instead of a
+        # launch of its own in the backward pass
+        h = x.new_empty((x.shape[0], grp.size * grp.rank)) if _lora_tail and any(u.requires_grad for u in ups) else None
+        ys = _merged_forward(x, lins, grp, residual, h)
+        if h is None:
+            ctx.save_for_backward(x)
+        else:
+            ctx.save_for_backward(x, h)
         ctx.grp, ctx.lins = grp, lins
         ctx.epoch = getattr(grp.store, "epoch", 0)  # the merged weights this forward multiplied by
         ctx.has_res = residual is not None
@@ -1258,14 +1288,17 @@ class _LoRAMergedLinear(Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        (x,) = ctx.saved_tensors
+        x, *rest = ctx.saved_tensors
+        h = rest[0] if rest else None
         grp, lins = ctx.grp, ctx.lins
         M, Kd = x.shape
         G, r = grp.size, grp.rank
         Gr = G * r
         k = kernels()
         gs = [_c(g) if g is not None else x.new_zeros((M, lin.out_features)) for g, lin in zip(gs, lins)]
-        dx = None
+        want_down, want_ups = ctx.needs_input_grad[4], ctx.needs_input_grad[5:]
+        dx = u = None
+        u_done = False
         if ctx.needs_input_grad[0]:
             _, wmt = grp.store.merged_weights(grp, lins)
             # (merged_weights refreshes lazily: an optimizer step of this store between a forward and its backward would hand
@@ -1275,22 +1308,29 @@ class _LoRAMergedLinear(Function):
             dx = x.new_empty((M, Kd))
             if G == 1:
                 N = lins[0].out_features
-                k.gemm(gs[0], wmt[0], dx, M, Kd, N, N, N, Kd)
+                if want_down and _lora_tail:  # u = s g U rides along: U^T [r, N] is the tail of W_eff^T [K, N]
+                    u = x.new_empty((M, r))
+                    k.gemm(gs[0], wmt[0], dx, M, Kd + r, N, N, N, Kd, tail=(grp.compute_copies()[3][0], u, r, r, 0, 0, grp.scale))
+                    u_done = True
+                else:
+                    k.gemm(gs[0], wmt[0], dx, M, Kd, N, N, N, Kd)
             else:
                 k.gemm_segments([(gs[i], wmt[i], lin.out_features, lin.out_features, lin.out_features)
                                  for i, lin in enumerate(lins)], dx, M, Kd, Kd)
-        want_down, want_ups = ctx.needs_input_grad[4], ctx.needs_input_grad[5:]
         if want_down or any(want_ups):
             dc, _, _, uts = grp.compute_copies()
-            h = x.new_empty((M, Gr)) if any(want_ups) else None
-            u = x.new_empty((M, Gr)) if want_down else None
+            h_done = h is not None
+            if h is None and any(want_ups):
+                h = x.new_empty((M, Gr))
+            if u is None and want_down:
+                u = x.new_empty((M, Gr))
             N0 = lins[0].out_features
             sg, su = _uniform_stride(gs), _uniform_stride(uts)
 
-            def low_rank():  # h = s x [D_1; ..]^T,  u_i = s g_i U_i (through U_i^T [r, N]: both operands k-contiguous)
-                if h is not None:
+            def low_rank():  # whatever did not ride in a neighbour's launch: h = s x [D_1; ..]^T, u_i = s g_i U_i (through U_i^T [r, N])
+                if h is not None and not h_done:
                     k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
-                if u is None:
+                if u is None or u_done:
                     return
                 if G > 1 and sg is not None and su is not None:
                     k.gemm(gs[0], uts[0], u, M, r, N0, N0, N0, Gr, alpha=grp.scale, batch=(G, 1), sA=(sg, 0), sB=(su, 0),
@@ -1300,6 +1340,7 @@ class _LoRAMergedLinear(Function):
                         N = lin.out_features
                         k.gemm(gs[i], uts[i], u[:, i * r:(i + 1) * r], M, r, N, N, N, Gr, alpha=grp.scale)
 
+            pre = low_rank if (not h_done and any(want_ups)) or (want_down and not u_done) else None
             probs = []
             for i, lin in enumerate(lins):
                 if want_ups[i]:
@@ -1308,11 +1349,12 @@ class _LoRAMergedLinear(Function):
             if want_down:
                 probs.append((u, x, grp.down_cat.grad, Gr, Kd, M, Gr, Kd, Kd))
             if _tt_grouping and all(k.tt_group_ok(*pr) for pr in probs):
-                _tt_enqueue(x.device, probs, (gs, h, u, x), pre=low_rank)
+                _tt_enqueue(x.device, probs, (gs, h, u, x), pre=pre)
             else:  # fp32 parity mode, odd shapes: one launch per gradient, still off the issuing stream
 
                 def weight_grads():
-                    low_rank()
+                    if pre is not None:
+                        pre()
                     for A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc in probs:
                         k.gemm(A, B, Cacc, Mp, Np, Kp, lda, ldb, ldc, transA=True, transB=True, R=Cacc, ldr=ldc, beta=1.0)
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 6
+#define COMAT_ABI_VERSION 7
 
 enum { COMAT_F32 = 0, COMAT_BF16 = 1,
        COMAT_FP8_E4M3 = 2 /* OCP e4m3fn bytes; operand dtype of comat_gemm / comat_conv2d only (comat_fp8_quantize) */ };
@@ -92,12 +92,25 @@ typedef struct {
      *   [M, 2 N] receives their gradient in the same layout: d value = dF * gelu(gate), d gate = dF * value * gelu'(gate), dF
      *   rounded to bf16 first (the bits of the two-launch form).  bf16, N % 16 == 0, ldc, ldc2 >= 2 N, 16-byte aligned rows,
      *   no bias / residual / activation / batch.
-     * Replaces the separate GEGLU kernel behind `ff.net.0.proj` of every BasicTransformerBlock (3P diffusers GEGLU, reached
+     * (epi2 = 1 .. 3) replace the separate GEGLU kernel behind `ff.net.0.proj` of every BasicTransformerBlock (3P diffusers GEGLU, reached
      * from TrainableSDPipeline.py:144-150): one launch and one [M, 2 D] read less per block, and no [M, 2 D] write at all in
-     * the no-grad denoise steps. */
+     * the no-grad denoise steps.
+     *   epi2 = 4 (ABI 7): TAIL COLUMNS.  The product has N = N1 + n2 columns; its last n2 rows of B come from a second matrix B2
+     *   (row-major [n2, K], leading dimension ldb like B, batch stride sB2_tail) and its last n2 COLUMNS go to a second output
+     *   C2 [M, n2] (leading dimension ldc2, batch stride sC2_tail, out_dtype) as alpha2 * A B2^T - no bias, activation or residual;
+     *   the first N1 = N - n2 columns get the whole first epilogue (bias [N1], bias2 [.., N1], R, act) into C.  transA = transB = 0,
+     *   batch2 = 1; n2 and N1 multiples of 8 and 16-byte aligned rows for the one-launch form, else (and outside the pipelined
+     *   kernel) two launches with the same results.
+     *   One launch replaces a frozen-plus-merged projection and the rank-r product that shares its A operand: the forward
+     *   `y = x W_eff^T` with `h = s x D^T` (the LoRA down projection, training_utils/pipeline.py:94-115, needed again by the factor
+     *   gradient dU += g^T h), and the data-gradient `dx = g W_eff` with `u = s g U` (needed by dD += u^T x). */
     void* C2;
     int64_t ldc2;
     int32_t epi2;
+    /* epi2 = 4 only (ABI 7) */
+    const void* B2;
+    int64_t n2, sB2_tail, sC2_tail;
+    float alpha2;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 

@@ -41,8 +41,16 @@ class SimKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
              sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
-             beta=0.0, act=ACT_NONE, scales=None, geglu=None):
+             beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None):
         b1, b2 = batch
+        if tail is not None:  # comat_gemm_params::epi2 = 4: the last n2 columns are alpha2 * A B2^T into C2, the rest as usual
+            B2, C2t, n2, ldc2, sB2t, sC2t, alpha2 = tail
+            assert geglu is None and not transA and not transB and b2 == 1 and 0 < n2 < N
+            self.gemm(A, B, Cout, M, N - n2, K, lda, ldb, ldc, batch=batch, sA=sA, sB=sB, sC=sC, bias=bias, bias2=bias2,
+                      rows_per_bias2=rows_per_bias2, R=R, ldr=ldr, sR=sR, alpha=alpha, beta=beta, act=act, scales=scales)
+            self.gemm(A, B2, C2t, M, n2, K, lda, ldb, ldc2, batch=batch, sA=sA, sB=(sB2t, 0), sC=(sC2t, 0), alpha=alpha2,
+                      scales=scales)
+            return
         assert (scales is not None) == (A.dtype == torch.uint8)
         if scales is not None:
             assert not transA and not transB and K % 64 == 0 and lda % 16 == 0 and ldb % 16 == 0 and b2 == 1

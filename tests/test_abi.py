@@ -26,13 +26,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/comat_hip.h but not exported"
     bound = set(_hip.SIGNATURES) | {"comat_abi_version", "comat_last_error", "comat_build_id"}
     assert bound == set(names), (bound ^ set(names))
-    assert lib.comat_abi_version() == 6
+    assert lib.comat_abi_version() == 7
 
 
 def test_struct_layouts_match_header():
     from comat_amd import _hip
     # 6 pointers + 18 int64 + 2 float + 6 int32 + pointer + int64 + 2 scale pointers (ABI 3)
-    assert C.sizeof(_hip.GemmParams) == 6 * 8 + 18 * 8 + 2 * 4 + 6 * 4 + 8 + 8 + 2 * 8 + 8 + 8 + 8  # ABI 5: + C2, ldc2, epi2 (+ 4 bytes of padding)
+    # ABI 5: + C2, ldc2, epi2 (+ 4 bytes of padding); ABI 7: + B2, n2, sB2_tail, sC2_tail, alpha2 (+ 4 bytes of padding)
+    assert C.sizeof(_hip.GemmParams) == 6 * 8 + 18 * 8 + 2 * 4 + 6 * 4 + 8 + 8 + 2 * 8 + 8 + 8 + 8 + 4 * 8 + 8
     assert C.sizeof(_hip.TTProblem) == 3 * 8 + 6 * 8  # comat_tt_problem (ABI 4)
     assert C.sizeof(_hip.ConvParams) == 6 * 8 + 13 * 4 + 2 * 4 + 4 * 4 + 4 + 8 + 8 + 2 * 8  # incl. 4 bytes of padding
 

@@ -851,6 +851,36 @@ def test_gemm2_matches_reference(hip, cfg, splits, default_opts):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("g2", [1, 0])
+def test_gemm_tail_columns(hip, dtype, g2, default_opts):
+    """comat_gemm_params::epi2 = 4: the last n2 columns of the product come from a second B matrix and go to a second output
+    (h = s x D^T riding in the projection's launch, u = s g U in its data-gradient's): single and batched problems, bias +
+    residual on the main part only, ragged M, a strided C2 (columns i r .. of a [M, G r] buffer), against fp32 references
+    and against the two-launch form (pipelined kernel off / fp32 mode: the library's fallback)."""
+    k = ops.kernels()
+    _set_opts(gemm2=g2, g2_cfg=0, g2_splits=0)
+    for (M, N1, K_, n2, G) in ((8192, 320, 320, 128, 1), (2048, 640, 640, 128, 3), (300, 200, 1280, 128, 1), (154, 640, 768, 128, 2),
+                               (512, 1280, 1280, 128, 1), (130, 96, 64, 8, 2)):
+        A = rnd(M, K_, dtype=dtype, seed=1, scale=0.5)
+        B = rnd(G, N1, K_, dtype=dtype, seed=2, scale=0.5)
+        B2 = rnd(G * n2, K_, dtype=dtype, seed=3, scale=0.5)
+        bias, R = (rnd(N1, seed=4), rnd(M, N1, dtype=dtype, seed=5)) if G == 1 else (None, None)
+        Ad, Bd, B2d = dv(A, hip, dtype), dv(B, hip, dtype), dv(B2, hip, dtype)
+        out = torch.full((G, M, N1), float("nan"), dtype=dtype, device=hip)
+        h = torch.full((M, G * n2), float("nan"), dtype=dtype, device=hip)
+        k.gemm(Ad, Bd, out, M, N1 + n2, K_, K_, K_, N1, batch=(G, 1), sA=(0, 0), sB=(N1 * K_, 0), sC=(M * N1, 0),
+               bias=dv(bias, hip) if bias is not None else None, R=dv(R, hip, dtype) if R is not None else None, ldr=N1,
+               beta=0.5 if R is not None else 0.0, tail=(B2d, h, n2, G * n2, n2 * K_, n2, 0.75))
+        ref = torch.einsum("mk,gnk->gmn", A, B)
+        if G == 1:
+            ref = ref + bias + 0.5 * R
+        what = f"tail columns gemm2={g2} {dtype} M={M} N1={N1} K={K_} n2={n2} G={G}"
+        check(out, ref, dtype, what)
+        check(h, 0.75 * (A @ B2.t()), dtype, what + " (tail)")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])  # 8..11: 128-byte k-tiles
 @pytest.mark.parametrize("splits", [0, 2])
 def test_gemm2_segments_and_conv(hip, cfg, splits, default_opts):

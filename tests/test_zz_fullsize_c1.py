@@ -210,3 +210,51 @@ def test_c3_full_size_attribute_concentration_leg_matches_oracle_golden(hip):
     # measured on an MI355X: 1.0e-5 (profiles/r05_f_fullsize_c2.txt)
     assert rel <= 1e-4, f"flat LoRA gradient: estimated rel. error {rel:.3e}"
 
+
+
+def test_c4_full_size_sdxl_leg_matches_oracle_golden(hip):
+    """The SDXL leg at FULL size: AttrConcenTrainableSDXLPipeline.forward with the real SDXL UNet layout (head
+    dim 64, Linear proj_in / proj_out, 1 / 2 / 10-deep transformers, text_time conditioning), 512 x 512, N = 2 / K = 1 (the last step
+    trained), concept matching + token-level and pixel-level concentration losses on the maps of mid_16 / up_16 / up_32, fp32, against
+    tests/golden/c4_full.npz = the CPU oracle on the same seeded world (tests/golden/make_c4_golden.py): loss terms and the LoRA
+    gradient (185.8 M values: per-tensor norms + 8 Rademacher projections each)."""
+    from make_c1_golden import rademacher
+    from make_c4_golden import c4_inputs
+
+    from comat_amd.blip import Blip
+    from comat_amd.pipeline import TrainableSDXLPipeline
+    from comat_amd.step import CoMatTrainer
+    from comat_amd.unet import LoRABank, UNet, VAEDecoder
+    path = os.path.join(HERE, "golden", "c4_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/c4_full.npz not generated")
+    gold = np.load(path)
+    (ucfg, vcfg, bcfg), sd, batch, scfg, ts, crop, acs = c4_inputs()
+    dtype = torch.float32
+    bank = LoRABank(ucfg, sd["lora"], dtype, hip)
+    pipe = TrainableSDXLPipeline(UNet(ucfg, sd["unet"], dtype, hip, bank), VAEDecoder(vcfg, sd["vae"], dtype, hip))
+    trainer = CoMatTrainer(pipe, bank, Blip(bcfg, sd["blip"], dtype, hip), None, scfg, seed=0)
+    bank.set_requires_grad(True)
+    bank.zero_grad()
+    out = trainer.compute_losses(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    for key, gk in (("loss", "loss"), ("Blip", "blip_reward"), ("token_loss", "token_loss"), ("pixel_loss", "pixel_loss")):
+        assert abs(float(out[key].detach()) - float(gold[gk])) < 2e-4 * max(abs(float(gold[gk])), 1e-3), (key, float(out[key].detach()), float(gold[gk]))
+    names = [str(n) for n in gold["names"]]
+    total_ref = float(np.sqrt((gold["grad_norm"] ** 2).sum()))
+    err_sq = 0.0
+    for i, n in enumerate(names):
+        gr = bank.params[n].grad.detach().double().cpu().reshape(-1)
+        nref = float(gold["grad_norm"][i])
+        assert abs(float(gr.norm()) - nref) <= 1e-3 * nref + 1e-6 * total_ref, f"{n}: gradient norm"
+        p = (rademacher(n, gr.numel()).double() @ gr).numpy()
+        est = float(np.sqrt(np.mean((p - gold["grad_proj"][i]) ** 2)))
+        assert est <= 3e-3 * nref + 3e-6 * total_ref, f"{n}: estimated gradient error {est:.3e} vs norm {nref:.3e}"
+        err_sq += est ** 2
+    rel = float(np.sqrt(err_sq)) / total_ref
+    path = os.environ.get("COMAT_TEST_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"c4_full float32 cuda grad_rel_err={rel:.3e}\n")
+    assert rel <= 1e-4, f"flat LoRA gradient: estimated rel. error {rel:.3e}"

@@ -1,12 +1,20 @@
 """tools/tune_gemm2.py output (JSON lines) -> comat_amd/csrc/gemm2_plans.inc (the static plan table of gemm2.hip).
-    python tools/make_gemm2_plans.py gpurun_out/g2_tune.jsonl [more.jsonl ...]
+    python tools/make_gemm2_plans.py [--base old_plans.inc] gpurun_out/g2_tune.jsonl [more.jsonl ...]
 Per problem the fastest measured (tile, splits); among variants within 3 % of the fastest the one with the fewest slices
 (less slab traffic, least sensitivity to what else runs on the chip)."""
 import json
+import re
 import sys
 
 rows = {}
-for path in sys.argv[1:]:
+args = sys.argv[1:]
+if args and args[0] == "--base":  # keep the entries of an existing table (problems the given measurements do not cover)
+    for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\},\s*// ([\d.]+) us \(general ([\d.]+)\), (\d+) calls",
+                         open(args[1]).read(), re.M):
+        v = m.groups()
+        rows[tuple(int(x) for x in v[:5])] = (int(v[5]), int(v[6]), float(v[7]), int(v[9]), float(v[8]), args[1])
+    args = args[2:]
+for path in args:
     for line in open(path):
         if not line.startswith("{"):
             continue
