@@ -28,6 +28,13 @@
 // both operands, so the k-permutation inside the MFMA cancels.
 #include "gemm_shared.h"
 
+// Diagnostic builds only (make diag -> lib/libcomat_hip_d<N>.so, tools/calls/r6_k.sh): the k-loop of gemm2_body with one of its
+// parts deleted - 1: no MFMAs (fragments are still read), 2: no fragment reads (MFMAs on stale registers), 3: no LDS-DMA,
+// 4: no barrier.  Results are garbage; the times say which part bounds a k-tile.  The product build has G2_DIAG 0.
+#ifndef G2_DIAG
+#define G2_DIAG 0
+#endif
+
 namespace {
 
 constexpr int BK = 32;       // bf16 k elements per k-tile
@@ -99,7 +106,7 @@ template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false>
 __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
                                           int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
     // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
-    if (g.splits > 1) {
+    if constexpr (TM * TN <= 4) if (g.splits > 1) {  // (wave tiles of more than 4 MFMA tiles are never split: the host keeps splits = 1)
         constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
         const SlabIO io(g.ws + WS_COUNTERS);
         const int64_t mine = (((int64_t)sp * g.ntiles + tile) * QPT * NTH + tid) * 16;  // byte offset of vector 0
@@ -332,6 +339,7 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
 
     // issue the DMA of the next k-tile of this block's range into ring stage `st`
     auto issue = [&](int st) {
+        if (G2_DIAG == 3) return;
         char* sbase = smem + st * SS + wave * 1024;
         if (CONV) {
             const int lim_y = g.Hin * g.ups, lim_x = g.Win * g.ups;
@@ -402,12 +410,20 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     // in flight across the barrier (counted vmcnt); then tile t+NST-1 is issued into the stage of tile t-1, whose reads
     // were all consumed by MFMAs before any wave reached this barrier. ----
     auto frags = [&](const char* st, int fo, short8_t (&xf)[TM], short8_t (&wf)[TN]) {
+        if (G2_DIAG == 2) return;
 #pragma unroll
         for (int a = 0; a < TM; ++a) xf[a] = *(const short8_t*)(st + a_base + a * 32 * RBK + fo);
 #pragma unroll
         for (int b = 0; b < TN; ++b) wf[b] = *(const short8_t*)(st + b_base + b * 32 * RBK + fo);
     };
     auto mmas = [&](const short8_t (&xf)[TM], const short8_t (&wf)[TN]) {
+#if G2_DIAG == 1
+#pragma unroll
+        for (int a = 0; a < TM; ++a) asm volatile("" ::"v"(xf[a]));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) asm volatile("" ::"v"(wf[b]));
+        return;
+#endif
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -423,6 +439,10 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     for (int u = 0; u < NST - 1; ++u)
         if (u < nt) issue(u);
     short8_t xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+#if G2_DIAG == 2
+    for (int a = 0; a < TM; ++a) xf0[a] = xf1[a] = short8_t{(short)lane, 1, 2, 3, 4, 5, 6, 7};
+    for (int b = 0; b < TN; ++b) wf0[b] = wf1[b] = short8_t{(short)lane, 7, 6, 5, 4, 3, 2, 1};
+#endif
     if (nt > 0) {
         wait_tiles<L, NST - 2>(nt - 1);  // tile 0 landed (this wave's part)
         __builtin_amdgcn_s_barrier();   // ... and every other wave's
@@ -466,7 +486,7 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
             mmas(xf0, wf0);
             const int nstage = stage + 1 == NST ? 0 : stage + 1;
             wait_tiles<L, NST - 3>(nt - 2 - t);
-            __builtin_amdgcn_s_barrier();
+            if (G2_DIAG != 4) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);  // the slot of tile t-1
             frags(smem + nstage * SS, fo0, xf0, wf0);
@@ -917,7 +937,10 @@ template <int NST> __global__ __launch_bounds__(256, 2) void gemm2_tt_group_kern
 enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x128 = 4, CFG_128x128_D6 = 5, CFG_64x64 = 6,
        CFG_128x128_W8 = 7,
        // 128-byte k-tiles (KS = 4): half as many barrier / wait / issue rounds along k, for latency-bound problems
-       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11, CFG_LAST = 11 };
+       CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11,
+       // 8 waves as 2 x 4 of 128 x 64 (4 x 2 MFMA tiles per wave: 6 fragment reads per 8 MFMAs, half the LDS-DMA bytes per FLOP of
+       // 128 x 128), ring of 4 x 32 KB = 128 KB, one block per CU, never split: VAE-sized problems (>= ~256 such tiles)
+       CFG_256x256 = 12, CFG_LAST = 12 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -929,6 +952,7 @@ static Cfg2 cfg_dims(int c) {
         case CFG_64x128: return {64, 128, 256};
         case CFG_64x64: return {64, 64, 256};
         case CFG_128x128_W8: return {128, 128, 512};
+        case CFG_256x256: return {256, 256, 512};
         case CFG_64x64_K4: return {64, 64, 256};
         case CFG_128x64_K4: return {128, 64, 256};
         case CFG_64x128_K4: return {64, 128, 256};
@@ -957,6 +981,7 @@ template <bool CONV, int EB> static void launch_cfg(int c, const Args2& a, unsig
         case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
         case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
             hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_256x256: hipLaunchKernelGGL((gemm2_kernel<256, 256, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
@@ -1023,7 +1048,7 @@ static void plan2(bool conv, bool fp8, int64_t M, int64_t N, int nkt, int64_t ba
     const Cfg2 d = cfg_dims(c);
     const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
-    if (slab_bytes <= 0 || ntiles > WS_COUNTERS) s = 1;
+    if (slab_bytes <= 0 || ntiles > WS_COUNTERS || c == CFG_256x256) s = 1;
     else {
         if (s == 0) {  // about 1.5 blocks per CU, every slice at least 24 k-tiles long
             s = 1;
