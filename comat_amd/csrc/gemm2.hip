@@ -27,12 +27,20 @@
 // Fragment rule (as gemm.hip): lane (r = lane & 31, h = lane >> 5) of k-step s holds k = 16 s + 8 h .. + 8 of row r for
 // both operands, so the k-permutation inside the MFMA cancels.
 #include "gemm_shared.h"
+#include <type_traits>
 
 // Diagnostic builds only (make diag -> lib/libcomat_hip_d<N>.so, tools/calls/r6_k.sh): the k-loop of gemm2_body with one of its
 // parts deleted - 1: no MFMAs (fragments are still read), 2: no fragment reads (MFMAs on stale registers), 3: no LDS-DMA,
 // 4: no barrier.  Results are garbage; the times say which part bounds a k-tile.  The product build has G2_DIAG 0.
 #ifndef G2_DIAG
 #define G2_DIAG 0
+#endif
+// Issue order of a k-step's fragment reads against the MFMAs of the step before (round 6).  The source asks for "reads of step
+// s + 1, then MFMAs of step s"; hipcc's scheduler sinks the reads into the second half of the MFMA batch and then waits for
+// lgkmcnt(0) in front of the next batch, so most of the LDS latency is exposed (ISA: `[k0] M5 r4 M1 r2 M1 [k0] ...`; no-DMA build:
+// 48 % MFMA busy at 256 x 256).  1: a scheduling barrier behind the reads (all reads first); 2: reads in pairs between the first MFMAs.
+#ifndef G2_PIN
+#define G2_PIN 0
 #endif
 
 namespace {
@@ -74,6 +82,14 @@ struct Args2 {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// N hand-issued 16-byte LDS reads x[i] <- LDS[addr + i * STRIDE] (immediate offsets); the compiler does not count them: the
+// caller waits with its own s_waitcnt lgkmcnt before any use (gemm2_body: frags_landed)
+template <int I, int N, int STRIDE> __device__ __forceinline__ void ds_read_frags(short8_t* x, unsigned addr) {
+    if constexpr (I < N) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[I]) : "v"(addr), "n"(I * STRIDE));
+        ds_read_frags<I + 1, N, STRIDE>(x, addr);
+    }
+}
 // wait until at most `tiles` k-tiles (L DMA instructions each) of this wave are still in flight; tiles in [0, MAXT]
 template <int L, int MAXT> __device__ __forceinline__ void wait_tiles(int tiles) {
     if (tiles >= MAXT) wait_vmcnt<L * MAXT>();
@@ -411,11 +427,33 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     // were all consumed by MFMAs before any wave reached this barrier. ----
     auto frags = [&](const char* st, int fo, short8_t (&xf)[TM], short8_t (&wf)[TN]) {
         if (G2_DIAG == 2) return;
+        if constexpr (G2_PIN == 3 && EB == 2) {
+            // hand-issued reads (the compiler neither counts nor moves them): the batch's TM + TN ds_read_b128 go out HERE, and
+            // frags_landed<NR>() in front of the MFMAs that use an EARLIER batch waits for lgkmcnt(NR) - everything but this batch
+            const unsigned la = (unsigned)(uintptr_t)(st + a_base + fo), lb = (unsigned)(uintptr_t)(st + b_base + fo);
+            ds_read_frags<0, TM, 32 * RBK>(xf, la);
+            ds_read_frags<0, TN, 32 * RBK>(wf, lb);
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a) xf[a] = *(const short8_t*)(st + a_base + a * 32 * RBK + fo);
 #pragma unroll
         for (int b = 0; b < TN; ++b) wf[b] = *(const short8_t*)(st + b_base + b * 32 * RBK + fo);
+        if (G2_PIN == 1) __builtin_amdgcn_sched_barrier(0);
     };
+    // hand-issued reads only: at most `younger` fragment reads (the batches issued after the one about to be used) may still be
+    // in flight; the empty asms tie the batch's registers to the wait, so that no MFMA reading them can be scheduled above it
+    auto frags_landed = [&](auto younger, short8_t (&xf)[TM], short8_t (&wf)[TN]) {
+        if constexpr (G2_PIN == 3 && EB == 2 && G2_DIAG != 2) {
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(younger)::value) : "memory");
+#pragma unroll
+            for (int a = 0; a < TM; ++a) asm volatile("" : "+v"(xf[a]));
+#pragma unroll
+            for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(wf[b]));
+        }
+    };
+    constexpr std::integral_constant<int, TM + TN> one_batch{};
+    constexpr std::integral_constant<int, 0> no_batch{};
     auto mmas = [&](const short8_t (&xf)[TM], const short8_t (&wf)[TN]) {
 #if G2_DIAG == 1
 #pragma unroll
@@ -428,6 +466,15 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wf[b], xf[a]);
+#if G2_PIN == 2
+        // the batch's MFMAs and the TM + TN fragment reads issued with it: MFMA, two reads, MFMA, two reads, .., the rest of the MFMAs
+#pragma unroll
+        for (int i = 0; i < (TM + TN + 1) / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN + 1) / 2, 0);
+#endif
     };
     auto mmas8 = [&](const short8_t (&x0)[TM], const short8_t (&w0)[TN], const short8_t (&x1)[TM], const short8_t (&w1)[TN]) {
 #pragma unroll
@@ -443,59 +490,72 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     for (int a = 0; a < TM; ++a) xf0[a] = xf1[a] = short8_t{(short)lane, 1, 2, 3, 4, 5, 6, 7};
     for (int b = 0; b < TN; ++b) wf0[b] = wf1[b] = short8_t{(short)lane, 7, 6, 5, 4, 3, 2, 1};
 #endif
-    if (nt > 0) {
+    int stage = 0;  // ring slot of tile t
+    if (nt > 0) {   // (ONE region from the first fragment read to the last MFMA: tools/isa_frag_check.py follows every path of it)
         wait_tiles<L, NST - 2>(nt - 1);  // tile 0 landed (this wave's part)
         __builtin_amdgcn_s_barrier();   // ... and every other wave's
         asm volatile("" ::: "memory");
         frags(smem, fo0, xf0, wf0);
-    }
-    int stage = 0;  // ring slot of tile t
     if constexpr (EB == 2 && KS == 4) {
         // four k-steps per tile: fragments of step s + 1 are requested before the MFMAs of step s issue; the barrier (and
         // the DMA issue behind it) sits before the MFMAs of the LAST step, with the next tile's step 0 already requested
         for (int t = 0; t + 1 < nt; ++t) {
             const char* cur = smem + stage * SS;
             frags(cur, fo1, xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
             frags(cur, fofs(2), xf0, wf0);
+            frags_landed(one_batch, xf1, wf1);
             mmas(xf1, wf1);
             frags(cur, fofs(3), xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
             const int nstage = stage + 1 == NST ? 0 : stage + 1;
             wait_tiles<L, NST - 3>(nt - 2 - t);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (G2_PIN == 3) frags(smem + nstage * SS, fo0, xf0, wf0);  // reads first: the DMA's address arithmetic covers their latency
             if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);
-            frags(smem + nstage * SS, fo0, xf0, wf0);
+            if (G2_PIN != 3) frags(smem + nstage * SS, fo0, xf0, wf0);
+            frags_landed(one_batch, xf1, wf1);
             mmas(xf1, wf1);
             stage = nstage;
         }
-        if (nt > 0) {
+        {
             const char* cur = smem + stage * SS;
             frags(cur, fo1, xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
             frags(cur, fofs(2), xf0, wf0);
+            frags_landed(one_batch, xf1, wf1);
             mmas(xf1, wf1);
             frags(cur, fofs(3), xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
+            frags_landed(no_batch, xf1, wf1);
             mmas(xf1, wf1);
         }
     } else if constexpr (EB == 2) {
         for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
             frags(smem + stage * SS, fo1, xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
             const int nstage = stage + 1 == NST ? 0 : stage + 1;
             wait_tiles<L, NST - 3>(nt - 2 - t);
             if (G2_DIAG != 4) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (G2_PIN == 3) frags(smem + nstage * SS, fo0, xf0, wf0);  // reads first: the DMA's address arithmetic covers their latency
             if (t + NST - 1 < nt) issue(stage == 0 ? NST - 1 : stage - 1);  // the slot of tile t-1
-            frags(smem + nstage * SS, fo0, xf0, wf0);
+            if (G2_PIN != 3) frags(smem + nstage * SS, fo0, xf0, wf0);
+            frags_landed(one_batch, xf1, wf1);
             mmas(xf1, wf1);
             stage = nstage;
         }
-        if (nt > 0) {  // last tile
+        {  // last tile
             frags(smem + stage * SS, fo1, xf1, wf1);
+            frags_landed(one_batch, xf0, wf0);
             mmas(xf0, wf0);
+            frags_landed(no_batch, xf1, wf1);
             mmas(xf1, wf1);
         }
     } else {
@@ -517,10 +577,11 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
             for (int b = 0; b < TN; ++b) wf0[b] = wn[b];
             stage = nstage;
         }
-        if (nt > 0) {
+        {
             frags(smem + stage * SS, fo1, xf1, wf1);
             mmas8(xf0, wf0, xf1, wf1);
         }
+    }
     }
 
     g2_finish<TM, TN, WTM, WTN, NTH, false>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
