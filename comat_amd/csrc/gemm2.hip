@@ -31,7 +31,7 @@
 
 // Diagnostic builds only (make diag -> lib/libcomat_hip_d<N>.so, tools/calls/r6_k.sh): the k-loop of gemm2_body with one of its
 // parts deleted - 1: no MFMAs (fragments are still read), 2: no fragment reads (MFMAs on stale registers), 3: no LDS-DMA,
-// 4: no barrier.  Results are garbage; the times say which part bounds a k-tile.  The product build has G2_DIAG 0.
+// 4: no barrier, 5: no epilogue.  Results are garbage; the times say which part bounds a k-tile.  The product build has G2_DIAG 0.
 #ifndef G2_DIAG
 #define G2_DIAG 0
 #endif
@@ -41,6 +41,20 @@
 // 48 % MFMA busy at 256 x 256).  1: a scheduling barrier behind the reads (all reads first); 2: reads in pairs between the first MFMAs.
 #ifndef G2_PIN
 #define G2_PIN 0
+#endif
+// The interleaved k-loop (round 6, bf16): every MFMA of a batch is followed by its share of the NEXT batch's fragment reads and - in the
+// batch behind the barrier - of the next k-tile's LDS-DMA pieces, the order pinned by scheduling barriers.  Why: a DMA piece costs
+// the issuing wave ~90 cycles of issue; all pieces in a burst behind the barrier (every wave at once) leave the matrix pipe idle for
+// ~350 cycles per k-tile (tools/probes/loop_probe.hip, 256 x 256 shape, L2-resident source: 98.8 % MFMA busy without DMA, 73.8 % with
+// the burst, 92.4 % with one piece behind every second MFMA).  0 = the round-5 loop.
+#ifndef G2_ILV
+#define G2_ILV 1
+#endif
+#ifndef G2_STAGE
+#define G2_STAGE 1  // 0: the round-5 epilogue (lane = row) for A/B builds
+#endif
+#ifndef G2_NST256
+#define G2_NST256 4  // ring depth of the 256 x 256 shape (5 = all 160 KiB of LDS)
 #endif
 
 namespace {
@@ -82,6 +96,12 @@ struct Args2 {
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 // N hand-issued 16-byte LDS reads x[i] <- LDS[addr + i * STRIDE] (immediate offsets); the compiler does not count them: the
 // caller waits with its own s_waitcnt lgkmcnt before any use (gemm2_body: frags_landed)
 template <int I, int N, int STRIDE> __device__ __forceinline__ void ds_read_frags(short8_t* x, unsigned addr) {
@@ -118,7 +138,14 @@ __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, con
 
 // split-K combine (inside the launch) + fused epilogue of one block tile; shared by the k-contiguous and the k-major kernel
 // -> true for the block that ran the tile's epilogue (every block when the problem is not split)
-template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false>
+// STG (round 6): the epilogue runs on a ROW-CONTIGUOUS layout.  The MFMA's transposed accumulators give every lane one output row
+// and 8 + 8 of its columns: a store instruction then writes 16 bytes into each of 32 different rows - 64 separate requests, a quarter
+// of a cache line each (measured: a 4096 x 4096 bf16 output costs 36 us, 0.95 TB/s, against 5 us for the whole launch without its
+// stores: profiles/r06_r_kscan_epilogue.txt).  With STG every wave stages 32 rows x WTN columns of fp32 accumulators in its own
+// slice of the (now idle) LDS ring and reads them back with lane = (row, 8-column chunk): 8 lanes cover 128 contiguous bytes of a
+// row, a store instruction writes 8 (WTN = 64) whole lines, and the residual loads are as contiguous.  The arithmetic per element
+// is the same code in the same order (epilogue_run / _tail / _geglu / _geglu_bwd): identical bits.
+template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false, bool STG = false>
 __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
                                           int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
     // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
@@ -181,6 +208,19 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     // ---- epilogue.  acc[a][b][i]: output row m = lane & 31 of the (a)-th 32-row tile, column (i & 3) + 8 (i >> 2) + 4 h
     // of the (b)-th 32-column tile.  Half-swapping quad 0 <-> 1 and 2 <-> 3 gives lane h = 0 columns 0..7 and 16..23,
     // lane h = 1 columns 8..15 and 24..31 ----
+#if G2_DIAG == 5  // no epilogue: the accumulators stay alive through a store that never happens
+    {
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sacc += acc[a][b][i];
+        if (sacc == 12345.678f) ((float*)g.ep.C)[0] = sacc;
+        return true;
+    }
+#endif
     Epi ep = g.ep;
     if (g.scale_a) ep.alpha *= *g.scale_a;
     if (g.scale_b) ep.alpha *= *g.scale_b;
@@ -190,6 +230,69 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     if (ep.epi2 == 4) ep.C2 = (char*)ep.C2 + z * g.sC2t * (ep.out_dt == COMAT_F32 ? 4 : 2);
     const int64_t nmain = g.N - (ep.epi2 == 4 ? ep.n2 : 0);  // tail columns: [nmain, N) go to C2 (8-column pieces never straddle)
     const bool vec = g.vec != 0;
+    if constexpr (STG && G2_STAGE) {
+        constexpr int RS = WTN + 4;   // floats per staged row: 16 bytes of padding put the 8 rows of a write phase on different banks
+        constexpr int CH = WTN / 8;   // 8-column chunks per row
+        constexpr int RPP = 64 / CH;  // rows per pass of the wave
+        static_assert(WTN % 8 == 0 && 64 % CH == 0 && 32 % RPP == 0, "staged epilogue: lanes tile 32 rows");
+        const int lane = tid & 63;
+        float* stg = (float*)smem + (size_t)(tid >> 6) * (32 * RS);
+        __syncthreads();  // every wave is done with the ring (fragment reads, the ticket flag)
+        // ONE copy of the epilogue arithmetic in the instruction stream: the loops over row blocks and passes are NOT unrolled (the
+        // unrolled form was 19 000 instructions, ~150 KB of code that every wave walks through once per tile: more than the
+        // instruction cache holds); only the staging writes are per row block (the accumulator array needs a constant index).
+#pragma nounroll
+        for (int a = 0; a < TM; ++a) {
+            static_for<0, TM>([&](auto at) {
+                constexpr int A = decltype(at)::value;
+                if (a == A) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *(float4*)(stg + r * RS + b * 32 + 8 * q + 4 * h) =
+                                make_float4(acc[A][b][4 * q], acc[A][b][4 * q + 1], acc[A][b][4 * q + 2], acc[A][b][4 * q + 3]);
+                }
+            });
+            const int64_t mrow = m0 + wr * WTM + a * 32, ncol = n0 + wc * WTN;
+            if (ep.epi2 == 1 || ep.epi2 == 2) {  // GEGLU: lane = (row, 32-column tile, half j): value chunk j and its gate chunk
+                constexpr int LPR = 2 * TN, RPG = 64 / LPR;
+#pragma nounroll
+                for (int p = 0; p < 32 / RPG; ++p) {
+                    const int row = p * RPG + lane / LPR, t = (lane % LPR) >> 1, j = lane & 1;
+                    float v[16];
+                    const float* src = stg + row * RS + t * 32 + 8 * j;
+                    *(float4*)v = *(const float4*)src;
+                    *(float4*)(v + 4) = *(const float4*)(src + 4);
+                    *(float4*)(v + 8) = *(const float4*)(src + 16);
+                    *(float4*)(v + 12) = *(const float4*)(src + 20);
+                    const int64_t m = mrow + row, nt = ncol + t * 32;
+                    if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nt + 8 * j, nt, j);
+                }
+            } else {
+#pragma nounroll
+                for (int p = 0; p < 32 / RPP; ++p) {
+                    const int row = p * RPP + lane / CH, c = lane % CH;
+                    float v[8];
+                    const float* src = stg + row * RS + c * 8;
+                    *(float4*)v = *(const float4*)src;
+                    *(float4*)(v + 4) = *(const float4*)(src + 4);
+                    const int64_t m = mrow + row, n = ncol + c * 8;
+                    if (m < g.M) {
+                        if (ep.epi2 == 3) {
+                            if (n < g.N) epilogue_geglu_bwd(ep, v, m, n);
+                        } else if (ep.epi2 == 4) {
+                            if (n < nmain) epilogue_run<WT>(ep, v, m, n, nmain, vec);
+                            else if (n < g.N) epilogue_tail(ep, v, m, n - nmain);
+                        } else if (n < g.N) {
+                            epilogue_run<WT>(ep, v, m, n, g.N, vec);
+                        }
+                    }
+                }
+            }
+        }
+        return true;
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int64_t m = m0 + wr * WTM + a * 32 + r;
@@ -263,7 +366,17 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     lin /= (unsigned)g.splits;
     int tm, tn;
     int64_t z;
-    if (g.order) {  // row blocks fastest: an XCD's chunk holds ALL row blocks of a few column blocks (weights stay put)
+    if (g.order == 2) {  // grouped (option g2_order = 3): row blocks fastest inside bands of 4 row blocks - the 32 tiles an XCD
+                         // runs at a time form a 4 x 8 patch (12 operand panels per k-tile instead of 18 for two whole rows)
+        const unsigned per_z = (unsigned)g.tiles_m * (unsigned)g.tiles_n;
+        z = __builtin_amdgcn_readfirstlane((int)(lin / per_z));
+        lin -= (unsigned)z * per_z;
+        const unsigned band = lin / (4u * (unsigned)g.tiles_n), first = band * 4u;
+        const unsigned rows = (unsigned)g.tiles_m - first < 4u ? (unsigned)g.tiles_m - first : 4u;
+        const unsigned in_band = lin - band * 4u * (unsigned)g.tiles_n;
+        tm = __builtin_amdgcn_readfirstlane((int)(first + in_band % rows));
+        tn = __builtin_amdgcn_readfirstlane((int)(in_band / rows));
+    } else if (g.order) {  // row blocks fastest: an XCD's chunk holds ALL row blocks of a few column blocks (weights stay put)
         tm = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_m));
         lin /= (unsigned)g.tiles_m;
         tn = __builtin_amdgcn_readfirstlane((int)(lin % (unsigned)g.tiles_n));
@@ -353,34 +466,12 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         }
     }
 
-    // issue the DMA of the next k-tile of this block's range into ring stage `st`
-    auto issue = [&](int st) {
+    // the DMA of the next k-tile of this block's range into ring stage `st`, as L = IA + IB pieces (1 KiB wave-instructions) that
+    // the interleaved k-loop places one by one between its MFMAs: issue_pre (GEMM: segment switch), issue_piece(j, st) for
+    // j = 0 .. L - 1 in any order (A pieces first: j < IA), issue_post (conv: tap cursor).  issue(st) = all of it at once (prologue)
+    auto issue_pre = [&]() {
         if (G2_DIAG == 3) return;
-        char* sbase = smem + st * SS + wave * 1024;
-        if (CONV) {
-            const int lim_y = g.Hin * g.ups, lim_x = g.Win * g.ups;
-#pragma unroll
-            for (int i = 0; i < IA; ++i) {
-                int sy = by[i] + ky, sx = bx[i] + kx;
-                bool ok = rv[i] && (unsigned)sy < (unsigned)lim_y && (unsigned)sx < (unsigned)lim_x;
-                if (g.zins) ok = ok && !((sy | sx) & 1);
-                if (g.ups == 2) {
-                    sy >>= 1;
-                    sx >>= 1;
-                }
-                const int off = (((bb[i] + sy) * g.Win + sx) * g.Cin + ci0) * EB + csrc * 16;  // bytes (host: < 2^31)
-                const void* src = ok ? (const void*)(g.seg[0].A + off) : (const void*)(g_zero_page + (lane & 15) * 16);
-                dma16(src, sbase + i * NW * 1024);
-            }
-            ci0 += KE;
-            if (ci0 >= g.Cin) {
-                ci0 = 0;
-                if (++kx == g.KW) {
-                    kx = 0;
-                    ++ky;
-                }
-            }
-        } else {
+        if (!CONV) {
             if (seg_left == 0) {  // next segment (uniform branch)
                 ++seg;
                 const Seg2 sg = g.seg[seg];
@@ -391,17 +482,53 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
                 for (int i = 0; i < IB; ++i) pb[i] = sg.B + z * sg.sB + brow_[i] * sg.ldb + csrc * 16;
             }
             --seg_left;
-#pragma unroll
-            for (int i = 0; i < IA; ++i) {
+        }
+    };
+    auto issue_piece = [&](const int j, int st) {  // j: compile-time after unrolling
+        if (G2_DIAG == 3) return;
+        char* sbase = smem + st * SS + wave * 1024;
+        if (j < IA) {
+            const int i = j;
+            if (CONV) {
+                const int lim_y = g.Hin * g.ups, lim_x = g.Win * g.ups;
+                int sy = by[i] + ky, sx = bx[i] + kx;
+                bool ok = rv[i] && (unsigned)sy < (unsigned)lim_y && (unsigned)sx < (unsigned)lim_x;
+                if (g.zins) ok = ok && !((sy | sx) & 1);
+                if (g.ups == 2) {
+                    sy >>= 1;
+                    sx >>= 1;
+                }
+                const int off = (((bb[i] + sy) * g.Win + sx) * g.Cin + ci0) * EB + csrc * 16;  // bytes (host: < 2^31)
+                const void* src = ok ? (const void*)(g.seg[0].A + off) : (const void*)(g_zero_page + (lane & 15) * 16);
+                dma16(src, sbase + i * NW * 1024);
+            } else {
                 dma16(pa[i], sbase + i * NW * 1024);
                 pa[i] += RBK;
             }
-        }
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
+        } else {
+            const int i = j - IA;
             dma16(pb[i], sbase + BM * RBK + i * NW * 1024);
             pb[i] += RBK;
         }
+    };
+    auto issue_post = [&]() {
+        if (G2_DIAG == 3) return;
+        if (CONV) {
+            ci0 += KE;
+            if (ci0 >= g.Cin) {
+                ci0 = 0;
+                if (++kx == g.KW) {
+                    kx = 0;
+                    ++ky;
+                }
+            }
+        }
+    };
+    auto issue = [&](int st) {
+        issue_pre();
+#pragma unroll
+        for (int j = 0; j < L; ++j) issue_piece(j, st);
+        issue_post();
     };
 
     f32x16_t acc[TM][TN];
@@ -482,6 +609,44 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
 #pragma unroll
             for (int b = 0; b < TN; ++b) mma_t_fp8(acc[a][b], w0[b], w1[b], x0[a], x1[a]);
     };
+    // interleaved batch: the TM x TN MFMAs on (xc, wc); behind MFMA m: reads [m RP, (m + 1) RP) of the next batch's TM + TN fragment
+    // reads into (xn, wn) from `stn + fon` (has_next), and - with_dma - pieces of the next k-tile's DMA into ring slot `slot`
+    // (do_issue: a tile is left to issue; wave-uniform)
+    auto batch = [&](auto with_dma, short8_t (&xc)[TM], short8_t (&wc)[TN], short8_t (&xn)[TM], short8_t (&wn)[TN], const char* stn,
+                     int fon, bool has_next, bool do_issue, int slot) {
+        constexpr int NM = TM * TN, NR = TM + TN;
+        constexpr int RP = (NR + NM - 1) / NM;                // reads behind each MFMA
+        constexpr int DP = L >= NM ? (L + NM - 1) / NM : 1;   // DMA pieces behind an MFMA that carries any
+        constexpr int DS = L >= NM ? 1 : NM / L;              // ... which is every DS-th MFMA
+        constexpr bool DMA = decltype(with_dma)::value;
+        if (DMA && do_issue) issue_pre();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+#if G2_DIAG == 1
+            asm volatile("" ::"v"(xc[m / TN]), "v"(wc[m % TN]));
+#else
+            mma_t(acc[m / TN][m % TN], wc[m % TN], xc[m / TN]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (G2_DIAG != 2 && has_next) {
+#pragma unroll
+                for (int q = m * RP; q < (m + 1) * RP && q < NR; ++q) {
+                    if (q < TM) xn[q] = *(const short8_t*)(stn + a_base + q * 32 * RBK + fon);
+                    else wn[q - TM] = *(const short8_t*)(stn + b_base + (q - TM) * 32 * RBK + fon);
+                }
+            }
+            if (DMA && (m % DS) == DS - 1 && do_issue) {
+#pragma unroll
+                for (int j = (m / DS) * DP; j < (m / DS + 1) * DP && j < L; ++j) issue_piece(j, slot);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DMA && do_issue) issue_post();
+        static_assert((NM / DS) * DP >= L, "every DMA piece has a place");
+    };
+    constexpr std::true_type dma_here{};
+    constexpr std::false_type no_dma{};
 #pragma unroll
     for (int u = 0; u < NST - 1; ++u)
         if (u < nt) issue(u);
@@ -496,7 +661,27 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         __builtin_amdgcn_s_barrier();   // ... and every other wave's
         asm volatile("" ::: "memory");
         frags(smem, fo0, xf0, wf0);
-    if constexpr (EB == 2 && KS == 4) {
+    if constexpr (EB == 2 && KS == 4 && G2_ILV == 1) {
+        for (int t = 0; t + 1 < nt; ++t) {
+            const char* cur = smem + stage * SS;
+            batch(no_dma, xf0, wf0, xf1, wf1, cur, fo1, true, false, 0);
+            batch(no_dma, xf1, wf1, xf0, wf0, cur, fofs(2), true, false, 0);
+            batch(no_dma, xf0, wf0, xf1, wf1, cur, fofs(3), true, false, 0);
+            const int nstage = stage + 1 == NST ? 0 : stage + 1;
+            wait_tiles<L, NST - 3>(nt - 2 - t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            batch(dma_here, xf1, wf1, xf0, wf0, smem + nstage * SS, fo0, true, t + NST - 1 < nt, stage == 0 ? NST - 1 : stage - 1);
+            stage = nstage;
+        }
+        {
+            const char* cur = smem + stage * SS;
+            batch(no_dma, xf0, wf0, xf1, wf1, cur, fo1, true, false, 0);
+            batch(no_dma, xf1, wf1, xf0, wf0, cur, fofs(2), true, false, 0);
+            batch(no_dma, xf0, wf0, xf1, wf1, cur, fofs(3), true, false, 0);
+            batch(no_dma, xf1, wf1, xf0, wf0, smem, fo0, false, false, 0);
+        }
+    } else if constexpr (EB == 2 && KS == 4) {
         // four k-steps per tile: fragments of step s + 1 are requested before the MFMAs of step s issue; the barrier (and
         // the DMA issue behind it) sits before the MFMAs of the LAST step, with the next tile's step 0 already requested
         for (int t = 0; t + 1 < nt; ++t) {
@@ -534,6 +719,21 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
             mmas(xf0, wf0);
             frags_landed(no_batch, xf1, wf1);
             mmas(xf1, wf1);
+        }
+    } else if constexpr (EB == 2 && G2_ILV == 1) {
+        for (int t = 0; t + 1 < nt; ++t) {
+            const char* cur = smem + stage * SS;
+            batch(no_dma, xf0, wf0, xf1, wf1, cur, fo1, true, false, 0);
+            const int nstage = stage + 1 == NST ? 0 : stage + 1;
+            wait_tiles<L, NST - 3>(nt - 2 - t);
+            if (G2_DIAG != 4) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            batch(dma_here, xf1, wf1, xf0, wf0, smem + nstage * SS, fo0, true, t + NST - 1 < nt, stage == 0 ? NST - 1 : stage - 1);
+            stage = nstage;
+        }
+        {  // last tile
+            batch(no_dma, xf0, wf0, xf1, wf1, smem + stage * SS, fo1, true, false, 0);
+            batch(no_dma, xf1, wf1, xf0, wf0, smem, fo0, false, false, 0);
         }
     } else if constexpr (EB == 2) {
         for (int t = 0; t + 1 < nt; ++t) {  // steady state: a next tile exists (no data-dependent branch around the LDS reads)
@@ -584,7 +784,8 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     }
     }
 
-    g2_finish<TM, TN, WTM, WTN, NTH, false>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
+    static_assert(NW * 32 * (WTN + 4) * 4 <= NST * SS, "the staged epilogue fits the ring");
+    g2_finish<TM, TN, WTM, WTN, NTH, false, true>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
 }
 
 template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2, int KS = 2>
@@ -1042,7 +1243,7 @@ template <bool CONV, int EB> static void launch_cfg(int c, const Args2& a, unsig
         case CFG_64x64: hipLaunchKernelGGL((gemm2_kernel<64, 64, 2, 2, 8, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
         case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
             hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
-        case CFG_256x256: hipLaunchKernelGGL((gemm2_kernel<256, 256, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_256x256: hipLaunchKernelGGL((gemm2_kernel<256, 256, 2, 4, G2_NST256, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
@@ -1156,6 +1357,7 @@ static int epi_vec_ok(const Epi& ep, int64_t N, int64_t sC, int64_t sR, int64_t 
 // 2 = whichever the model prefers by more than 10 %.
 static int tile_order(const Args2& a, bool conv, bool fp8, int bm, int bn) {
     const int opt = comat_option(COMAT_OPT_G2_ORDER);
+    if (opt == 3) return 2;
     if (opt != 2) return opt == 1;
     const int64_t tm = a.tiles_m, tn = a.tiles_n, items = tm * tn;
     const double eb = fp8 ? 1.0 : 2.0;

@@ -16,6 +16,8 @@ from tools.mb_big import timeit  # noqa: E402
 CONVS = [(1, 256, 256, 512, 256, 1), (1, 256, 256, 256, 256, 1), (1, 128, 128, 512, 512, 1), (2, 64, 64, 320, 320, 1)]
 GEMMS = [(8192, 5120, 640), (8192, 1280, 1280), (4096, 4096, 4096)]
 CFGS = [int(c) for c in os.environ.get("MB_CFGS", "1,12").split(",")]
+if os.environ.get("MB_ONLY") == "kscan":  # time against K at fixed M, N: slope = a k-tile, intercept = prologue + epilogue
+    CONVS, GEMMS = [], [(4096, 4096, k) for k in (64, 512, 1024, 2048, 4096, 8192)]
 if os.environ.get("MB_ONLY") == "big":  # counter passes: one conv, one GEMM
     CONVS, GEMMS = CONVS[:1], GEMMS[2:]
 
@@ -25,7 +27,9 @@ def main():
     k = _hip.HipKernels()
     ops.set_kernel_backend(k)
     T = torch.bfloat16
-    tag = os.path.basename(os.environ.get("COMAT_LIB_PATH", "libcomat_hip.so"))
+    if os.environ.get("MB_ORDER"):
+        _hip.set_option("g2_order", int(os.environ["MB_ORDER"]))
+    tag = os.environ.get("MB_ORDER", "") + " " + os.path.basename(os.environ.get("COMAT_LIB_PATH", "libcomat_hip.so"))
     r = lambda *s: (torch.rand(*s, device=dev) * 2 - 1).to(T)
     for (B, H, W, Cin, Cout, ups) in CONVS:
         x, w = r(B * H * W, Cin), r(Cout, 3, 3, Cin) * (9 * Cin) ** -0.5
