@@ -293,38 +293,43 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
         }
         return true;
     }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
+    // lane = row form (kernels without the staging area): one copy of the arithmetic too - the loop over the wave's MFMA tiles is
+    // not unrolled, the accumulator tile is picked by a uniform branch chain
+#pragma nounroll
+    for (int ab = 0; ab < TM * TN; ++ab) {
+        const int a = ab / TN, b = ab % TN;
         const int64_t m = m0 + wr * WTM + a * 32 + r;
+        float v[16];
+        static_for<0, TM * TN>([&](auto t) {
+            constexpr int T = decltype(t)::value;
+            if (ab == T) {
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = acc[a][b][i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half_swap(v[j], v[4 + j]);
-                half_swap(v[8 + j], v[12 + j]);
+                for (int i = 0; i < 16; ++i) v[i] = acc[T / TN][T % TN][i];
             }
-            const int64_t nt = n0 + wc * WTN + b * 32, nb = nt + 8 * h;
-            if (ep.epi2 == 3) {  // GEGLU backward: the lane's two 8-column pieces of dF -> d value / d gate (N % 16 == 0)
-                if (m < g.M) {
-                    if (nb < g.N) epilogue_geglu_bwd(ep, v, m, nb);
-                    if (nb + 16 < g.N) epilogue_geglu_bwd(ep, v + 8, m, nb + 16);
-                }
-            } else if (ep.epi2 == 4) {  // tail columns: the first epilogue for columns < nmain, alpha2 * product into C2 behind
-                if (m < g.M) {
-                    if (nb < nmain) epilogue_run<WT>(ep, v, m, nb, nmain, vec);
-                    else if (nb < g.N) epilogue_tail(ep, v, m, nb - nmain);
-                    if (nb + 16 < nmain) epilogue_run<WT>(ep, v + 8, m, nb + 16, nmain, vec);
-                    else if (nb + 16 < g.N) epilogue_tail(ep, v + 8, m, nb + 16 - nmain);
-                }
-            } else if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
-                if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
-            } else if (m < g.M) {
-                if (nb < g.N) epilogue_run<WT>(ep, v, m, nb, g.N, vec);
-                if (nb + 16 < g.N) epilogue_run<WT>(ep, v + 8, m, nb + 16, g.N, vec);
+        });
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            half_swap(v[j], v[4 + j]);
+            half_swap(v[8 + j], v[12 + j]);
+        }
+        const int64_t nt = n0 + wc * WTN + b * 32, nb = nt + 8 * h;
+        if (ep.epi2 == 3) {  // GEGLU backward: the lane's two 8-column pieces of dF -> d value / d gate (N % 16 == 0)
+            if (m < g.M) {
+                if (nb < g.N) epilogue_geglu_bwd(ep, v, m, nb);
+                if (nb + 16 < g.N) epilogue_geglu_bwd(ep, v + 8, m, nb + 16);
             }
+        } else if (ep.epi2 == 4) {  // tail columns: the first epilogue for columns < nmain, alpha2 * product into C2 behind
+            if (m < g.M) {
+                if (nb < nmain) epilogue_run<WT>(ep, v, m, nb, nmain, vec);
+                else if (nb < g.N) epilogue_tail(ep, v, m, nb - nmain);
+                if (nb + 16 < nmain) epilogue_run<WT>(ep, v + 8, m, nb + 16, nmain, vec);
+                else if (nb + 16 < g.N) epilogue_tail(ep, v + 8, m, nb + 16 - nmain);
+            }
+        } else if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
+            if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
+        } else if (m < g.M) {
+            if (nb < g.N) epilogue_run<WT>(ep, v, m, nb, g.N, vec);
+            if (nb + 16 < g.N) epilogue_run<WT>(ep, v + 8, m, nb + 16, g.N, vec);
         }
     }
     return true;
