@@ -18,6 +18,9 @@ GEMMS = [(8192, 5120, 640), (8192, 1280, 1280), (4096, 4096, 4096)]
 CFGS = [int(c) for c in os.environ.get("MB_CFGS", "1,12").split(",")]
 if os.environ.get("MB_ONLY") == "kscan":  # time against K at fixed M, N: slope = a k-tile, intercept = prologue + epilogue
     CONVS, GEMMS = [], [(4096, 4096, k) for k in (64, 512, 1024, 2048, 4096, 8192)]
+if os.environ.get("MB_ONLY") == "unet":  # the UNet's row counts: intercept (launch + prologue + epilogue) and slope per block shape
+    CONVS = []
+    GEMMS = [(m, n, k) for (m, n) in ((8192, 320), (2048, 640), (512, 1280), (8192, 2560)) for k in (64, 320, 1280)]
 if os.environ.get("MB_ONLY") == "big":  # counter passes: one conv, one GEMM
     CONVS, GEMMS = CONVS[:1], GEMMS[2:]
 
