@@ -280,6 +280,9 @@ def build_world(device, dtype, rank, cfg_name, bs=1):
     usd = weights.make_unet_weights(ucfg, seed=1234)
     lsd = weights.make_lora_weights(ucfg, seed=4321)
     bank = LoRABank(ucfg, lsd, dtype, device)
+    if cfg_name == "c5":  # activation scales of the fp8 forward: "delayed" (round 6, default) or "jit" (rounds 2-5) for A/B runs
+        from comat_amd import ops as _ops
+        _ops.set_fp8_scaling(os.environ.get("COMAT_FP8_SCALING", "delayed"))
     unet = UNet(ucfg, usd, dtype, device, bank, fp8_forward=cfg_name == "c5")
     keep_for_cpu = usd if (rank == 0) else None
     vae = VAEDecoder(vcfg, weights.make_vae_weights(vcfg, seed=2345), dtype, device)
@@ -328,6 +331,8 @@ def build_world(device, dtype, rank, cfg_name, bs=1):
     # and asynchronous, instead of fourteen pageable host-to-device copies that each wait for the stream to drain
     batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     fixed = dict(crop=(0, 0, 64, 64) if tiny else (1, 1, res - 2, res - 2))
+    if cfg_name == "c5":  # delayed fp8 scaling: the first step's scales from one eager no-grad sampler pass (untimed set-up)
+        trainer.fp8_calibrate(batch)
     if cfg_name == "c2":
         fixed["training_steps"] = [0, 1, 2, 3, 4]
     return trainer, batch, fixed, scfg, keep_for_cpu, time.time() - t0

@@ -112,11 +112,17 @@ SIGNATURES = {
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
     "comat_set_option": [C.c_char_p, _i32],
     "comat_last_gemm_kernel": [],
-    "comat_fp8_scale": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "comat_fp8_scale": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "comat_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "comat_fp8_quantize_scaled": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
+    "comat_fp8_scales_update": [_vp, _vp, _i32, _vp],
+    "comat_layernorm_fwd_q_ok": [_i32, _i32],
+    "comat_layernorm_fwd_q": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f, _i32, _vp, _vp, _vp, _vp],
+    "comat_groupnorm_fwd_q_ok": [_i32, _i64, _i32, _i32, _i32],
+    "comat_groupnorm_fwd_q": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f, _i32, _i32, _vp, _vp, _vp, _vp],
 }
 RESTYPES = {"comat_gemm_workspace_bytes": C.c_int64}
-ABI_VERSION = 7
+ABI_VERSION = 8
 WS_COUNTER_BYTES = 256 * 1024  # COMAT_WS_COUNTER_BYTES: ticket counters at the head of a split-K workspace
 
 _lib = None
@@ -404,9 +410,10 @@ class HipKernels:
         _check(_lib.comat_conv2d(C.byref(p), _stream()), "comat_conv2d")
 
     # ---- fp8 operands ---------------------------------------------------------------------------------------
-    def fp8_quantize(self, x, out=None, scale=None):
+    def fp8_quantize(self, x, out=None, scale=None, amax=None):
         """per-tensor e4m3 quantisation of a contiguous fp32 / bf16 tensor: -> (bytes [same shape] uint8, scale [1] fp32);
-        value = scale * fp8.  Two launches (abs-max -> scale, then the bytes)."""
+        value = scale * fp8.  Two launches (abs-max -> scale, then the bytes).  amax: [1] int32 = a delayed-scaling site's running
+        maximum (float bits), which receives this tensor's abs-max too (calibration pass)."""
         assert x.is_contiguous()
         n = x.numel()
         ws = self._fp8_workspace(x.device)
@@ -414,9 +421,38 @@ class HipKernels:
             scale = torch.empty(1, dtype=torch.float32, device=x.device)
         if out is None:
             out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        _check(_lib.comat_fp8_scale(_ptr(x), n, dt(x), _ptr(scale), _ptr(ws), _stream()), "comat_fp8_scale")
+        _check(_lib.comat_fp8_scale(_ptr(x), n, dt(x), _ptr(scale), _ptr(ws), _ptr(amax), _stream()), "comat_fp8_scale")
         _check(_lib.comat_fp8_quantize(_ptr(x), n, dt(x), _ptr(scale), _ptr(out), _stream()), "comat_fp8_quantize")
         return out, scale
+
+    def fp8_quantize_scaled(self, x, scale, amax, out=None):
+        """delayed scaling: the bytes of x under the scale already in `scale` [1]; max |x| folded into `amax` [1] int32 (float bits).
+        One launch."""
+        assert x.is_contiguous()
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _check(_lib.comat_fp8_quantize_scaled(_ptr(x), x.numel(), dt(x), _ptr(scale), _ptr(out), _ptr(amax), _stream()),
+               "comat_fp8_quantize_scaled")
+        return out
+
+    def fp8_scales_update(self, amax, scale, n):
+        """once per optimizer step: scale[i] = max(amax[i], 2^-100) / 448 and amax[i] = 0 for every site i < n that saw a tensor"""
+        _check(_lib.comat_fp8_scales_update(_ptr(amax), _ptr(scale), int(n), _stream()), "comat_fp8_scales_update")
+
+    def layernorm_fwd_q_ok(self, x):
+        return bool(_lib.comat_layernorm_fwd_q_ok(int(x.shape[1]), dt(x))) and x.data_ptr() % 16 == 0
+
+    def layernorm_fwd_q(self, x, gamma, beta, y, stats, M, Cc, eps, q8, scale, amax):
+        _check(_lib.comat_layernorm_fwd_q(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), M, Cc, eps, dt(x), _ptr(q8),
+                                          _ptr(scale), _ptr(amax), _stream()), "comat_layernorm_fwd_q")
+
+    def groupnorm_fwd_q_ok(self, x, B, HW, Cc, G):
+        return bool(_lib.comat_groupnorm_fwd_q_ok(B, HW, Cc, G, dt(x))) and x.data_ptr() % 16 == 0
+
+    def groupnorm_fwd_q(self, x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu, q8, scale, amax):
+        ws = self._gn_workspace(x.device, B, G)
+        _check(_lib.comat_groupnorm_fwd_q(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(stats), _ptr(ws), B, HW, Cc, G, eps,
+                                          int(silu), dt(x), _ptr(q8), _ptr(scale), _ptr(amax), _stream()), "comat_groupnorm_fwd_q")
 
     def _fp8_workspace(self, dev):
         key = ("fp8", dev, _stream())

@@ -71,6 +71,30 @@ __device__ __forceinline__ float block_max_256(float v, float* sbuf) {
     return fmaxf(fmaxf(sbuf[0], sbuf[1]), fmaxf(sbuf[2], sbuf[3]));
 }
 
+// fp8 delayed scaling: fold a block's (wave's) abs-max into a site's running maximum.  |x| >= 0, so the uint order of the float
+// bits is the float order; the atomic runs at the memory side (agent scope, coherent across the 8 XCDs' L2s) and is skipped when
+// the slot already holds a value at least as large - after the first few arrivals almost every block leaves with one load.
+__device__ __forceinline__ void fp8_amax_track(unsigned* slot, float m) {
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 8 (4) fp32 values * inv -> e4m3fn bytes (hardware RNE conversion, saturating): the arithmetic of comat_fp8_quantize
+__device__ __forceinline__ uint2 fp8_pack8(const float* v, float inv) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    return make_uint2((unsigned)lo, (unsigned)hi);
+}
+__device__ __forceinline__ unsigned fp8_pack4(const float* v, float inv) {
+    int lo = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    return (unsigned)lo;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------
 void comat_set_error(const char* fmt, ...);
 int comat_check_launch(const char* what);

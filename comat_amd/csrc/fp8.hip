@@ -29,7 +29,8 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
 
 // ws[0]: ticket counter (uint, zero between launches), ws[1]: running maximum as uint bits (zero between launches).
 // |x| >= 0, so the uint order of the float bits is the float order and atomicMax is exact and order-independent.
-template <typename T> __global__ __launch_bounds__(256) void fp8_scale_kernel(const T* x, int64_t n, float* scale, unsigned* ws) {
+template <typename T> __global__ __launch_bounds__(256) void fp8_scale_kernel(const T* x, int64_t n, float* scale, unsigned* ws,
+                                                                              unsigned* amax_bits) {
     __shared__ float sbuf[4];
     float m = 0.0f;
     const int64_t nv = n / 8;
@@ -52,6 +53,7 @@ template <typename T> __global__ __launch_bounds__(256) void fp8_scale_kernel(co
             const unsigned bits = __hip_atomic_exchange(ws + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *scale = fmaxf(__uint_as_float(bits), 0x1p-100f) / FP8_MAX;
+            if (amax_bits) __hip_atomic_fetch_max(amax_bits, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // delayed scaling: tracked too
         }
     }
 }
@@ -63,12 +65,7 @@ template <typename T> __global__ __launch_bounds__(256) void fp8_quantize_kernel
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         float v[8];
         load8<T>(x + i * 8, v);
-        int lo = 0, hi = 0;
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
-        *(uint2*)(y + i * 8) = make_uint2((unsigned)lo, (unsigned)hi);
+        *(uint2*)(y + i * 8) = fp8_pack8(v, inv);
     }
     if (blockIdx.x == 0 && threadIdx.x < n - nv * 8) {
         const int64_t i = nv * 8 + threadIdx.x;
@@ -77,19 +74,77 @@ template <typename T> __global__ __launch_bounds__(256) void fp8_quantize_kernel
     }
 }
 
+// Delayed scaling (round 6): the bytes under a scale that is ALREADY in memory (the site's abs-max of the previous optimizer step),
+// and this tensor's abs-max folded into the site's running maximum for the next one - ONE launch, no ticket, nobody waits.
+template <typename T> __global__ __launch_bounds__(256) void fp8_quantize_scaled_kernel(const T* x, int64_t n, const float* scale,
+                                                                                        unsigned char* y, unsigned* amax_bits) {
+    __shared__ float sbuf[4];
+    const float inv = 1.0f / *scale;
+    const int64_t nv = n / 8;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+        *(uint2*)(y + i * 8) = fp8_pack8(v, inv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - nv * 8) {
+        const int64_t i = nv * 8 + threadIdx.x;
+        const float xe = ldf<T>(x + i);
+        m = fmaxf(m, fabsf(xe));
+        const int q = __builtin_amdgcn_cvt_pk_fp8_f32(xe * inv, 0.0f, 0, false);
+        y[i] = (unsigned char)(q & 0xff);
+    }
+    m = block_max_256(m, sbuf);
+    if (threadIdx.x == 0) fp8_amax_track(amax_bits, m);
+}
+
+// once per optimizer step: every site that saw a tensor gets scale = max(amax, 2^-100) / 448 and a fresh running maximum
+__global__ __launch_bounds__(256) void fp8_scales_update_kernel(unsigned* amax_bits, float* scale, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned b = __hip_atomic_load(amax_bits + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b != 0u) {
+        scale[i] = fmaxf(__uint_as_float(b), 0x1p-100f) / FP8_MAX;
+        __hip_atomic_store(amax_bits + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
-extern "C" int comat_fp8_scale(const void* x, int64_t n, int32_t dtype, float* scale, void* ws, void* stream) {
+extern "C" int comat_fp8_quantize_scaled(const void* x, int64_t n, int32_t dtype, const float* scale, void* y, uint32_t* amax_bits,
+                                         void* stream) {
+    COMAT_REQUIRE(x && scale && y && amax_bits && n > 0, "comat_fp8_quantize_scaled: null argument or empty tensor");
+    COMAT_REQUIRE(dtype_ok(dtype), "comat_fp8_quantize_scaled: bad dtype");
+    COMAT_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, "comat_fp8_quantize_scaled: x / y must be 16 / 8-byte aligned");
+    const int grid = grid_1d(n / 8, 256 * 4, 2048);
+    if (dtype == COMAT_F32)
+        hipLaunchKernelGGL(fp8_quantize_scaled_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, n,
+                           scale, (unsigned char*)y, amax_bits);
+    else
+        hipLaunchKernelGGL(fp8_quantize_scaled_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n,
+                           scale, (unsigned char*)y, amax_bits);
+    return comat_check_launch("comat_fp8_quantize_scaled");
+}
+
+extern "C" int comat_fp8_scales_update(uint32_t* amax_bits, float* scale, int32_t n, void* stream) {
+    COMAT_REQUIRE(amax_bits && scale && n > 0, "comat_fp8_scales_update: null argument or no sites");
+    hipLaunchKernelGGL(fp8_scales_update_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, amax_bits, scale, n);
+    return comat_check_launch("comat_fp8_scales_update");
+}
+
+extern "C" int comat_fp8_scale(const void* x, int64_t n, int32_t dtype, float* scale, void* ws, uint32_t* amax_bits, void* stream) {
     COMAT_REQUIRE(x && scale && ws && n > 0, "comat_fp8_scale: null argument or empty tensor");
     COMAT_REQUIRE(dtype_ok(dtype), "comat_fp8_scale: bad dtype");
     COMAT_REQUIRE((((uintptr_t)x) & 15) == 0, "comat_fp8_scale: x must be 16-byte aligned");
     const int grid = grid_1d(n / 8, 256 * 4, 1024);
     if (dtype == COMAT_F32)
         hipLaunchKernelGGL(fp8_scale_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, scale,
-                           (unsigned*)ws);
+                           (unsigned*)ws, amax_bits);
     else
         hipLaunchKernelGGL(fp8_scale_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, n, scale,
-                           (unsigned*)ws);
+                           (unsigned*)ws, amax_bits);
     return comat_check_launch("comat_fp8_scale");
 }
 

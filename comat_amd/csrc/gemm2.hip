@@ -1207,7 +1207,9 @@ enum { CFG_AUTO = 0, CFG_128x128 = 1, CFG_128x64 = 2, CFG_256x128 = 3, CFG_64x12
        CFG_64x64_K4 = 8, CFG_128x64_K4 = 9, CFG_64x128_K4 = 10, CFG_128x128_K4 = 11,
        // 8 waves as 2 x 4 of 128 x 64 (4 x 2 MFMA tiles per wave: 6 fragment reads per 8 MFMAs, half the LDS-DMA bytes per FLOP of
        // 128 x 128), ring of 4 x 32 KB = 128 KB, one block per CU, never split: VAE-sized problems (>= ~256 such tiles)
-       CFG_256x256 = 12, CFG_LAST = 12 };
+       CFG_256x256 = 12,
+       // half of it: 4 waves of 128 x 64 (one per SIMD), ring of 4 x 24 KB, never split: problems whose N gives 256 x 256 too few tiles
+       CFG_256x128_W4 = 13, CFG_LAST = 13 };
 
 struct Cfg2 {
     int bm, bn, nth;
@@ -1220,6 +1222,7 @@ static Cfg2 cfg_dims(int c) {
         case CFG_64x64: return {64, 64, 256};
         case CFG_128x128_W8: return {128, 128, 512};
         case CFG_256x256: return {256, 256, 512};
+        case CFG_256x128_W4: return {256, 128, 256};
         case CFG_64x64_K4: return {64, 64, 256};
         case CFG_128x64_K4: return {128, 64, 256};
         case CFG_64x128_K4: return {64, 128, 256};
@@ -1249,6 +1252,7 @@ template <bool CONV, int EB> static void launch_cfg(int c, const Args2& a, unsig
         case CFG_128x128_W8:  // 8 waves (2 x 4, 64x32 each): two waves per SIMD even when a CU holds a single block
             hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 4, 4, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
         case CFG_256x256: hipLaunchKernelGGL((gemm2_kernel<256, 256, 2, 4, G2_NST256, CONV, EB>), dim3(blocks), dim3(512), 0, st, a); break;
+        case CFG_256x128_W4: hipLaunchKernelGGL((gemm2_kernel<256, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
         default: hipLaunchKernelGGL((gemm2_kernel<128, 128, 2, 2, 4, CONV, EB>), dim3(blocks), dim3(256), 0, st, a); break;
     }
 }
@@ -1315,7 +1319,7 @@ static void plan2(bool conv, bool fp8, int64_t M, int64_t N, int nkt, int64_t ba
     const Cfg2 d = cfg_dims(c);
     const int64_t ntiles = cdiv64(M, d.bm) * cdiv64(N, d.bn) * batch;
     const int64_t slab_bytes = ws_bytes - COMAT_WS_COUNTER_BYTES;
-    if (slab_bytes <= 0 || ntiles > WS_COUNTERS || c == CFG_256x256) s = 1;
+    if (slab_bytes <= 0 || ntiles > WS_COUNTERS || c == CFG_256x256 || c == CFG_256x128_W4) s = 1;
     else {
         if (s == 0) {  // about 1.5 blocks per CU, every slice at least 24 k-tiles long
             s = 1;

@@ -416,14 +416,22 @@ struct GnFin {
     float eps;
 };
 
-template <typename T, int MODE, bool FIN = false>
+struct GnQ {  // MODE 0 with Q: the e4m3 bytes of the rounded output + its abs-max (see NormQ below)
+    unsigned char* q8;
+    const float* scale;
+    unsigned* amax_bits;
+};
+template <typename T, int MODE, bool FIN = false, bool Q = false>
 __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ stats, const double* __restrict__ ws,
                                                         T* __restrict__ out, int HW, int C, int G, int silu,
-                                                        int rows_per_block, const T* __restrict__ add, GnFin fin) {
+                                                        int rows_per_block, const T* __restrict__ add, GnFin fin, GnQ gq) {
     constexpr int EPV = 16 / sizeof(T);
     const int b = blockIdx.y;
+    __shared__ float sm_q[Q ? 4 : 1];
+    float qinv = 0.f, qmax = 0.f;
+    if (Q) qinv = 1.0f / *gq.scale;
     __shared__ float sm_a[FIN ? 64 : 1], sm_b[FIN ? 64 : 1];
     if (FIN) {
         constexpr int SUB = 8;
@@ -517,7 +525,21 @@ __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x,
                 }
             }
             *(uint4*)(out + off) = ov.u;
+            if (Q) {
+                float r[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    r[e] = gv_get<T>(ov, e);
+                    qmax = fmaxf(qmax, fabsf(r[e]));
+                }
+                if (EPV == 8) *(uint2*)(gq.q8 + off) = fp8_pack8(r, qinv);
+                else *(unsigned*)(gq.q8 + off) = fp8_pack4(r, qinv);
+            }
         }
+    }
+    if (Q) {
+        qmax = block_max_256(qmax, sm_q);
+        if (threadIdx.x == 0) fp8_amax_track(gq.amax_bits, qmax);
     }
 }
 
@@ -549,9 +571,9 @@ static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_F
 
 template <typename T>
 static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
-                       int64_t HW, int C, int G, float eps, int silu, hipStream_t st) {
+                       int64_t HW, int C, int G, float eps, int silu, hipStream_t st, const GnQ* q = nullptr) {
     constexpr int EPV = 16 / sizeof(T);
-    const bool fin = gn_fin_in_apply(G);
+    const bool fin = !q && gn_fin_in_apply(G);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
     if (fin && rpb < cdiv64(HW, 64)) rpb = (int)cdiv64(HW, 64);  // at most 64 partial slabs per sample
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
@@ -567,14 +589,19 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     const int arpb = gn_apply_rows_per_block(B, HW, C, EPV);
     const dim3 ag((unsigned)cdiv64(HW, arpb), (unsigned)B);
     const GnFin f = {ws, stats, (int)sg.x, (double)HW * (C / G), eps};
-    if (fin)
+    const GnQ noq = {nullptr, nullptr, nullptr};
+    if (q)  // (the finalize-in-apply experiment has no e4m3 form: the host keeps fin off for these calls)
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, false, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
+                           (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
+                           f, *q);
+    else if (fin)
         hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                            (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
-                           f);
+                           f, noq);
     else
         hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, false>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                            (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
-                           f);
+                           f, noq);
 }
 
 template <typename T>
@@ -596,10 +623,10 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
     const GnFin f = {ws, nullptr, (int)sg.x, 0.0, 0.0f};
     if (fin)
         hipLaunchKernelGGL((gn_vapply2_kernel<T, 1, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
-                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f);
+                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f, GnQ{nullptr, nullptr, nullptr});
     else
         hipLaunchKernelGGL((gn_vapply2_kernel<T, 1, false>), ag, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats,
-                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f);
+                           (const double*)ws, (T*)dx, (int)HW, C, G, silu, arpb, (const T*)add, f, GnQ{nullptr, nullptr, nullptr});
 }
 
 static inline bool gn_vec_ok(const void* a, const void* b, int C, int dtype, int64_t HW) {
@@ -667,10 +694,18 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const T* __restrict__ dy, co
 
 // ---- vectorised LayerNorm: one wave per row, the row lives in registers (ONE 16-byte read per element group) --------
 // VPL = 16-byte vectors per lane (C <= 64 * VPL * EPV).  Same two-pass formulas as the scalar kernels above.
-template <typename T, int VPL>
+// Q (fp8 forward, delayed scaling): the e4m3 bytes of the ROUNDED output under the consumer's scale leave with it (q8 [M, C]) and
+// its abs-max is folded into the site's running maximum - the bits of comat_fp8_quantize_scaled over y, without its launch and
+// without reading y back.
+struct NormQ {
+    unsigned char* q8;
+    const float* scale;
+    unsigned* amax_bits;
+};
+template <typename T, int VPL, bool Q = false>
 __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, T* __restrict__ y,
-                                                        float* __restrict__ stats, int64_t M, int C, float eps) {
+                                                        float* __restrict__ stats, int64_t M, int C, float eps, NormQ nq) {
     constexpr int EPV = 16 / sizeof(T);
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -702,6 +737,8 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const T* __restrict__ x,
             }
         }
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    float qinv = 0.f, qmax = 0.f;
+    if (Q) qinv = 1.0f / *nq.scale;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int vi = lane + i * 64;
@@ -719,7 +756,22 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const T* __restrict__ x,
 #pragma unroll
             for (int e = 0; e < EPV; ++e) gv_set<T>(o, e, (v[i][e] - mean) * rstd * gg[e] + bb[e]);
             *(uint4*)(y + row * C + (int64_t)vi * EPV) = o.u;
+            if (Q) {
+                float r[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    r[e] = gv_get<T>(o, e);
+                    qmax = fmaxf(qmax, fabsf(r[e]));
+                }
+                unsigned char* qp = nq.q8 + row * C + (int64_t)vi * EPV;
+                if (EPV == 8) *(uint2*)qp = fp8_pack8(r, qinv);
+                else *(unsigned*)qp = fp8_pack4(r, qinv);
+            }
         }
+    }
+    if (Q) {
+        qmax = wave_max(qmax);
+        if (lane == 0) fp8_amax_track(nq.amax_bits, qmax);
     }
     if (lane == 0) {
         stats[2 * row] = mean;
@@ -815,6 +867,32 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
     return comat_check_launch("comat_groupnorm_fwd");
 }
 
+// 1 when comat_groupnorm_fwd_q takes the shape: the vectorised three-launch form, i.e. not the shapes the one-launch form serves
+extern "C" int comat_groupnorm_fwd_q_ok(int32_t B, int64_t HW, int32_t C, int32_t G, int32_t dtype) {
+    if (!dtype_ok(dtype) || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || G > MAX_G || B > 65535) return 0;
+    if (comat_option(COMAT_OPT_NORM_FUSED) == 3 && HW <= 256 && C / G <= GN_ONE_MAXCPG) return 0;  // gn_try_one<0> "pays"
+    return gn_vec_ok(nullptr, nullptr, C, dtype, HW) ? 1 : 0;
+}
+
+extern "C" int comat_groupnorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws,
+                                     int32_t B, int64_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* q8,
+                                     const float* scale, uint32_t* amax_bits, void* stream) {
+    COMAT_REQUIRE(x && gamma && beta && y && stats && ws && q8 && scale && amax_bits, "comat_groupnorm_fwd_q: null pointer");
+    if (!comat_groupnorm_fwd_q_ok(B, HW, C, G, dtype) || !gn_vec_ok(x, y, C, dtype, HW) || (((uintptr_t)q8) & 7) != 0) {
+        comat_set_error("comat_groupnorm_fwd_q: only the vectorised three-launch form emits e4m3 bytes (B = %d, HW = %lld, C = %d, "
+                        "G = %d): run comat_groupnorm_fwd and comat_fp8_quantize_scaled", B, (long long)HW, C, G);
+        return COMAT_EUNSUPPORTED;
+    }
+    const GnQ q = {(unsigned char*)q8, scale, amax_bits};
+    if (dtype == COMAT_BF16) gn_fwd_vec<bf16_t>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, (hipStream_t)stream, &q);
+    else gn_fwd_vec<float>(x, gamma, beta, y, stats, ws, B, HW, C, G, eps, silu, (hipStream_t)stream, &q);
+    return comat_check_launch("comat_groupnorm_fwd_q");
+}
+
+extern "C" int comat_layernorm_fwd_q_ok(int32_t C, int32_t dtype) {
+    return dtype_ok(dtype) && ln_vpl(C, dtype, nullptr, nullptr, nullptr, nullptr) ? 1 : 0;
+}
+
 extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
                                    const float* stats, void* dx, double* ws, int32_t B, int64_t HW, int32_t C,
                                    int32_t G, int32_t silu, const void* add, int32_t dtype, void* stream) {
@@ -837,6 +915,31 @@ extern "C" int comat_groupnorm_bwd(const void* dy, const void* x, const float* g
     return comat_check_launch("comat_groupnorm_bwd");
 }
 
+extern "C" int comat_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t M,
+                                     int32_t C, float eps, int32_t dtype, void* q8, const float* scale, uint32_t* amax_bits,
+                                     void* stream) {
+    COMAT_REQUIRE(x && gamma && beta && y && stats && q8 && scale && amax_bits, "comat_layernorm_fwd_q: null pointer");
+    COMAT_REQUIRE(M > 0 && C > 0 && dtype_ok(dtype), "comat_layernorm_fwd_q: bad shape or dtype");
+    const int vpl = (((uintptr_t)q8) & 7) == 0 ? ln_vpl(C, dtype, x, y, gamma, beta) : 0;
+    if (!vpl) {
+        comat_set_error("comat_layernorm_fwd_q: only the vectorised form emits e4m3 bytes (C = %d a multiple of %d up to %d, 16-byte "
+                        "aligned tensors): run comat_layernorm_fwd and comat_fp8_quantize_scaled", C, dtype == COMAT_BF16 ? 8 : 4,
+                        dtype == COMAT_BF16 ? 2048 : 1024);
+        return COMAT_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)cdiv64(M, NT / 64));
+    const NormQ nq = {(unsigned char*)q8, scale, amax_bits};
+#define LN_FWDQ(T, V) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, V, true>), grid, dim3(NT), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, C, eps, nq)
+    if (dtype == COMAT_BF16) {
+        if (vpl == 1) LN_FWDQ(bf16_t, 1); else if (vpl == 2) LN_FWDQ(bf16_t, 2); else if (vpl == 3) LN_FWDQ(bf16_t, 3); else LN_FWDQ(bf16_t, 4);
+    } else {
+        if (vpl == 1) LN_FWDQ(float, 1); else if (vpl == 2) LN_FWDQ(float, 2); else if (vpl == 3) LN_FWDQ(float, 3); else LN_FWDQ(float, 4);
+    }
+#undef LN_FWDQ
+    return comat_check_launch("comat_layernorm_fwd_q");
+}
+
 extern "C" int comat_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                    int64_t M, int32_t C, float eps, int32_t dtype, void* stream) {
     COMAT_REQUIRE(x && gamma && beta && y && stats, "comat_layernorm_fwd: null pointer");
@@ -845,7 +948,8 @@ extern "C" int comat_layernorm_fwd(const void* x, const float* gamma, const floa
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)cdiv64(M, NT / 64));
     const int vpl = ln_vpl(C, dtype, x, y, gamma, beta);
-#define LN_FWD(T, V) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, V>), grid, dim3(NT), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, C, eps)
+    const NormQ noq = {nullptr, nullptr, nullptr};
+#define LN_FWD(T, V) hipLaunchKernelGGL((ln_fwd_vec_kernel<T, V>), grid, dim3(NT), 0, st, (const T*)x, gamma, beta, (T*)y, stats, M, C, eps, noq)
     if (vpl && dtype == COMAT_BF16) {
         if (vpl == 1) LN_FWD(bf16_t, 1); else if (vpl == 2) LN_FWD(bf16_t, 2); else if (vpl == 3) LN_FWD(bf16_t, 3); else LN_FWD(bf16_t, 4);
         return comat_check_launch("comat_layernorm_fwd");

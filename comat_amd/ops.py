@@ -349,6 +349,111 @@ def fp8_weight(holder):
     return w8
 
 
+# ---- activation scales ------------------------------------------------------------------------------------------------
+# "jit" (rounds 2-5): every activation that enters an fp8 product is quantised under its OWN abs-max - two launches per tensor
+# (a reduction with a ticket, then the bytes), ~1 300 of them per SDXL forward.
+# "delayed" (round 6; COMAT_FP8_SCALING=delayed, bench.py --config c5): a quantisation SITE (the input of one frozen layer) keeps
+# a scale and a running abs-max in two device words (include/comat_hip.h, ABI 8).  Every tensor that passes the site during an
+# optimizer step is quantised under the scale that is already there - the abs-max over ALL of the previous step's calls of that
+# site (every denoise step, trained or not) - and folds its own abs-max into the running maximum; fp8_end_of_step() (after the
+# optimizer) turns the maxima into the next step's scales.  One launch per tensor, and none where the producer emits the bytes
+# itself: LayerNorm / GroupNorm(+SiLU) store the e4m3 bytes next to their output when told whom they feed (`fp8_for=`) - the
+# same bits as quantising the stored output.  Values beyond the previous step's abs-max saturate at +-448 * scale, as in every
+# delayed-scaling recipe.  Before the first step the scales come from fp8_calibration(): one no-grad pass in which every site
+# quantises just in time AND records its abs-max.
+_FP8_MAX_SITES = 4096
+_fp8_scaling = os.environ.get("COMAT_FP8_SCALING", "jit")
+_fp8_calibrating = False
+_fp8_states = {}
+
+
+def set_fp8_scaling(mode: str):
+    global _fp8_scaling
+    assert mode in ("jit", "delayed"), mode
+    _fp8_scaling = mode
+
+
+def fp8_scaling():
+    return _fp8_scaling
+
+
+class _Fp8State:
+    """the scale / running-maximum words of every quantisation site on one device (fixed addresses: captured graphs read them)"""
+
+    def __init__(self, device):
+        self.scale = torch.zeros(_FP8_MAX_SITES, dtype=torch.float32, device=device)
+        self.amax = torch.zeros(_FP8_MAX_SITES, dtype=torch.int32, device=device)  # float bits of a non-negative value
+        self.n = 0
+
+
+def fp8_state(device):
+    """allocate the site table of `device` (call once OUTSIDE any graph capture: UNet.__init__ does)"""
+    key = str(torch.device(device))
+    st = _fp8_states.get(key)
+    if st is None:
+        st = _fp8_states[key] = _Fp8State(device)
+    return st
+
+
+def _fp8_site(holder, device):
+    """(scale [1], amax [1]) views of the site in front of `holder` (index assigned at first use; no device allocation)"""
+    site = getattr(holder, "_fp8_site", None)
+    if site is None:
+        st = fp8_state(device)
+        assert st.n < _FP8_MAX_SITES, "fp8: site table full"
+        i = st.n
+        st.n += 1
+        site = holder._fp8_site = (st.scale[i:i + 1], st.amax[i:i + 1])
+    return site
+
+
+class fp8_calibration:
+    """`with fp8_calibration():` every site quantises just in time (its own abs-max) and records the abs-max: run the sampler once
+    under it, then fp8_end_of_step() (TrainableSDPipeline.fp8_calibrate does both)"""
+
+    def __enter__(self):
+        global _fp8_calibrating
+        self.prev, _fp8_calibrating = _fp8_calibrating, True
+        for st in _fp8_states.values():
+            st.amax.zero_()
+        return self
+
+    def __exit__(self, *exc):
+        global _fp8_calibrating
+        _fp8_calibrating = self.prev
+        return False
+
+
+def fp8_end_of_step():
+    """delayed scaling: the running maxima of this step become the next step's scales (one launch per device; a no-op otherwise)"""
+    if _fp8_scaling != "delayed":
+        return
+    for st in _fp8_states.values():
+        if st.n:
+            kernels().fp8_scales_update(st.amax, st.scale, st.n)
+
+
+def fp8_act(x, holder):
+    """(e4m3 bytes, scale [1]) of the activation x entering the fp8 product of `holder`"""
+    k = kernels()
+    if _fp8_scaling != "delayed":
+        return k.fp8_quantize(x)
+    sc, am = _fp8_site(holder, x.device)
+    if _fp8_calibrating:
+        return k.fp8_quantize(x, scale=sc, amax=am)[0], sc
+    pre = getattr(x, "_fp8", None)
+    if pre is not None and pre[1] is sc:  # the producer of x stored the bytes for this very site
+        return pre[0], sc
+    return k.fp8_quantize_scaled(x, sc, am), sc
+
+
+def _fp8_producer_site(holder, k_inner, device):
+    """a norm that feeds `holder`: the site it should quantise for, or None (no fp8, not eligible, jit scales, calibration pass)"""
+    if holder is None or _fp8_scaling != "delayed" or _fp8_calibrating or not _use_fp8(holder, k_inner):
+        return None
+    return _fp8_site(holder, device)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # parameter holders
 # ----------------------------------------------------------------------------------------------------------------
@@ -810,7 +915,7 @@ def _geglu_linear_fwd(x, lin, need_pre):
     k = kernels()
     y = x.new_empty((M, D))
     if _use_fp8(lin, Kd):
-        a, (w, sw) = k.fp8_quantize(x), fp8_weight(lin)
+        a, (w, sw) = fp8_act(x, lin), fp8_weight(lin)
         a, scales = a[0], (a[1], sw)
     else:
         a, w, scales = x, lin.w, None
@@ -869,7 +974,7 @@ class _GegluFeedForward(Function):
         residual = _c(residual) if residual is not None else None
         beta = 1.0 if residual is not None else 0.0
         if _use_fp8(ff2, D):
-            f8, sf = k.fp8_quantize(f)
+            f8, sf = fp8_act(f, ff2)
             w8, sw = fp8_weight(ff2)
             k.gemm(f8, w8, y, M, N, D, D, D, N, bias=ff2.bias, R=residual, ldr=N, beta=beta, scales=(sf, sw))
         else:
@@ -1017,7 +1122,7 @@ class _Linear(Function):
             residual = _c(residual)
         if _use_fp8(lin, Kd):
             k = kernels()
-            x8, sx = k.fp8_quantize(x)
+            x8, sx = fp8_act(x, lin)
             w8, sw = fp8_weight(lin)
             k.gemm(x8, w8, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N,
                    beta=1.0 if residual is not None else 0.0, act=act, scales=(sx, sw))
@@ -1088,7 +1193,7 @@ class _LoRAGroupLinear(Function):
         k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
         if any(use8):
             # frozen part on the fp8 MFMA (x quantised once for the whole group), low-rank part added in the storage dtype
-            x8, sx = k.fp8_quantize(x)
+            x8, sx = fp8_act(x, lins[use8.index(True)])
             ys = []
             for i, lin in enumerate(lins):
                 N = lin.out_features
@@ -1413,7 +1518,7 @@ class _Conv(Function):
             residual = _c(residual)
         if _use_fp8(conv, conv.cin):
             k = kernels()
-            x8, sx = k.fp8_quantize(x)
+            x8, sx = fp8_act(x, conv)
             w8, sw = fp8_weight(conv)
             k.conv2d(x8, w8, y, B, H, W, conv.cin, Ho, Wo, conv.cout, conv.kh, conv.kw, conv.stride, conv.pad, mode=0,
                      ups=ups, bias=conv.bias, bias2=bias2, R=residual, beta=1.0 if residual is not None else 0.0,
@@ -1473,13 +1578,21 @@ class _GroupNorm(Function):
     comat_groupnorm_bwd) instead of autograd's separate accumulation add."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, B, HW, G, eps, silu_, fork):
+    def forward(ctx, x, gamma, beta, B, HW, G, eps, silu_, fork, fp8_for=None):
         x = _c(x)
         Cc = x.shape[1]
         assert x.shape[0] == B * HW
         y = torch.empty_like(x)
         stats = torch.empty((B, G, 2), dtype=torch.float32, device=x.device)
-        kernels().groupnorm_fwd(x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu_)
+        k = kernels()
+        site = _fp8_producer_site(fp8_for, Cc, x.device)
+        if site is not None and k.groupnorm_fwd_q_ok(x, B, HW, Cc, G):
+            # fp8 forward, delayed scaling: the e4m3 bytes of y for the layer it feeds leave the same launch (fp8_act finds them)
+            q8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            k.groupnorm_fwd_q(x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu_, q8, site[0], site[1])
+            y._fp8 = (q8, site[0])
+        else:
+            k.groupnorm_fwd(x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu_)
         ctx.save_for_backward(x, gamma, beta, stats)
         ctx.cfg = (B, HW, Cc, G, silu_)
         ctx.set_materialize_grads(False)
@@ -1490,32 +1603,41 @@ class _GroupNorm(Function):
         x, gamma, beta, stats = ctx.saved_tensors
         B, HW, Cc, G, silu_ = ctx.cfg
         if g is None:  # the normalised branch is unused: only the bypass gradient flows
-            return (g_bypass,) + (None,) * 8
+            return (g_bypass,) + (None,) * 9
         dx = torch.empty_like(x)
         add = None if g_bypass is None else _c(g_bypass)
         kernels().groupnorm_bwd(_c(g), x, gamma, beta, stats, dx, B, HW, Cc, G, silu_, add=add)
-        return (dx,) + (None,) * 8
+        return (dx,) + (None,) * 9
 
 
-def group_norm(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False):
-    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), False)
+def group_norm(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False, fp8_for=None):
+    """fp8_for: the frozen layer (holder) this output feeds - under the fp8 forward with delayed scaling the kernel also stores
+    the e4m3 bytes that layer will multiply (ops.fp8_act picks them up); ignored otherwise"""
+    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), False, fp8_for)
 
 
-def group_norm_fork(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False):
+def group_norm_fork(x, gamma, beta, B, HW, G=32, eps=1e-5, silu=False, fp8_for=None):
     """(GroupNorm(x), x'): use x' for the branch that bypasses the norm (see _GroupNorm)."""
-    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), True)
+    return _GroupNorm.apply(x, gamma, beta, B, HW, G, float(eps), bool(silu), True, fp8_for)
 
 
 class _LayerNorm(Function):
     """y = LayerNorm(x); `fork` as in _GroupNorm (the residual connection around a pre-norm sub-layer)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fork):
+    def forward(ctx, x, gamma, beta, eps, fork, fp8_for=None):
         x = _c(x)
         M, Cc = x.shape
         y = torch.empty_like(x)
         stats = torch.empty((M, 2), dtype=torch.float32, device=x.device)
-        kernels().layernorm_fwd(x, gamma, beta, y, stats, M, Cc, eps)
+        k = kernels()
+        site = _fp8_producer_site(fp8_for, Cc, x.device)
+        if site is not None and k.layernorm_fwd_q_ok(x):
+            q8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+            k.layernorm_fwd_q(x, gamma, beta, y, stats, M, Cc, eps, q8, site[0], site[1])
+            y._fp8 = (q8, site[0])
+        else:
+            k.layernorm_fwd(x, gamma, beta, y, stats, M, Cc, eps)
         ctx.save_for_backward(x, gamma, stats)
         ctx.set_materialize_grads(False)
         return (y, x.view_as(x)) if fork else y
@@ -1524,20 +1646,20 @@ class _LayerNorm(Function):
     def backward(ctx, g, g_bypass=None):
         x, gamma, stats = ctx.saved_tensors
         if g is None:
-            return g_bypass, None, None, None, None
+            return g_bypass, None, None, None, None, None
         dx = torch.empty_like(x)
         add = None if g_bypass is None else _c(g_bypass)
         kernels().layernorm_bwd(_c(g), x, gamma, stats, dx, x.shape[0], x.shape[1], add=add)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return _LayerNorm.apply(x, gamma, beta, float(eps), False)
+def layer_norm(x, gamma, beta, eps=1e-5, fp8_for=None):
+    return _LayerNorm.apply(x, gamma, beta, float(eps), False, fp8_for)
 
 
-def layer_norm_fork(x, gamma, beta, eps=1e-5):
-    """(LayerNorm(x), x'): use x' for the residual that bypasses the norm (see _GroupNorm)."""
-    return _LayerNorm.apply(x, gamma, beta, float(eps), True)
+def layer_norm_fork(x, gamma, beta, eps=1e-5, fp8_for=None):
+    """(LayerNorm(x), x'): use x' for the residual that bypasses the norm (see _GroupNorm); fp8_for as in group_norm."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps), True, fp8_for)
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -105,6 +105,27 @@ class TrainableSDPipeline:
         torch.cuda.synchronize()
         return len(self.graphed.graphs)
 
+    def fp8_calibrate(self, prompt_embeds, negative_prompt_embeds, height, width, num_inference_steps, guidance_scale=7.5,
+                      latents=None, noises=None, **sdxl_kw):
+        """fp8 forward with delayed scaling (ops.set_fp8_scaling('delayed')): the scales of the FIRST optimisation step.  One
+        eager no-grad sampler pass over all `num_inference_steps` denoise steps of this prompt in which every quantisation site
+        quantises under its own abs-max and records it; the maxima over the pass become the scales (ops.fp8_end_of_step), as
+        they will after every later step.  Captured graphs are not touched (they hold the delayed-scaling launches, which read
+        the scale words at replay time).  -> True when a calibration ran."""
+        if not getattr(self.unet, "fp8", False) or ops.fp8_scaling() != "delayed":
+            return False
+        graphed, runner = self.graphed, self.trained_runner
+        self.graphed = self.trained_runner = None
+        try:
+            with torch.no_grad(), ops.fp8_calibration():
+                self.forward(prompt_embeds, negative_prompt_embeds, height=height, width=width, training_timesteps=(),
+                             num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, latents=latents,
+                             noises=noises, output_type="latent", **sdxl_kw)
+        finally:
+            self.graphed, self.trained_runner = graphed, runner
+        ops.fp8_end_of_step()
+        return True
+
     def prepare_latents(self, batch_size, height, width, generator=None, latents=None):
         """(bs,4,h/8,w/8) NCHW fp32 -> channels-last tokens [bs*h*w, 4] fp32 on the device."""
         h, w = height // 8, width // 8

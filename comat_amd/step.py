@@ -371,6 +371,18 @@ class CoMatTrainer:
         if self.cfg.gan_loss:
             self.opt_D.step(scale)
             self.D.bank.mark_updated()
+        ops.fp8_end_of_step()  # fp8 forward with delayed scaling: this step's abs-maxima become the next step's scales
+
+    def fp8_calibrate(self, batch):
+        """scales of the first step under delayed fp8 scaling (TrainableSDPipeline.fp8_calibrate) from this batch's prompt"""
+        cfg = self.cfg
+        kw = {}
+        if "pooled_prompt_embeds" in batch:
+            kw = dict(pooled_prompt_embeds=batch["pooled_prompt_embeds"],
+                      negative_pooled_prompt_embeds=batch["negative_pooled_prompt_embeds"], add_time_ids=batch.get("add_time_ids"))
+        return self.pipe.fp8_calibrate(batch["prompt_embeds"], batch["negative_prompt_embeds"], cfg.resolution, cfg.resolution,
+                                       cfg.total_step, guidance_scale=cfg.cfg_scale, latents=batch.get("latents"),
+                                       noises=batch.get("noises"), **kw)
 
     def train_step(self, batch, **fixed):
         """Full step: G forward/backward, D forward/backward, gradient exchange, G and D updates.  Returns a dict of

@@ -126,7 +126,7 @@ class ResBlock:
     def __call__(self, x, B, H, W, temb_act):
         HW = H * W
         # x feeds the norm AND the shortcut: the fork hands both gradients to one GroupNorm-backward launch
-        h, x = ops.group_norm_fork(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True)
+        h, x = ops.group_norm_fork(x, *self.n1, B, HW, G=self.groups, eps=self.eps, silu=True, fp8_for=self.c1)
         b2 = None
         if self.temb is not None:
             b2 = temb_act.get(id(self))
@@ -134,7 +134,7 @@ class ResBlock:
                 with torch.no_grad():  # depends on t and frozen weights only: computed once per timestep value
                     b2 = temb_act[id(self)] = ops.linear(temb_act["silu_temb"], self.temb, out_dtype=torch.float32)
         h = ops.conv2d(h, self.c1, B, H, W, bias2=b2)
-        h = ops.group_norm(h, *self.n2, B, HW, G=self.groups, eps=self.eps, silu=True)
+        h = ops.group_norm(h, *self.n2, B, HW, G=self.groups, eps=self.eps, silu=True, fp8_for=self.c2)
         sc = x if self.short is None else ops.linear(x, self.short)
         return ops.conv2d(h, self.c2, B, H, W, residual=sc)
 
@@ -183,18 +183,19 @@ class CrossAttnBlock:
     def __call__(self, x, B, H, W, ctx, L, want_probs, kv_cache=None):
         """returns (tokens, [cross-attention probabilities of every transformer layer] or None)"""
         N = H * W
-        h, x = ops.group_norm_fork(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False)
+        h, x = ops.group_norm_fork(x, *self.norm, B, N, G=self.cfg.norm_groups, eps=1e-6, silu=False, fp8_for=self.proj_in)
         h = ops.linear(h, self.proj_in)
         probs_all = [] if want_probs else None
         for Lr in self.layers:
             att, ln = Lr["att"], Lr["ln"]
-            y, h = ops.layer_norm_fork(h, *ln[0])  # (norm, residual alias): one LayerNorm-backward launch per fork
+            # (norm, residual alias): one LayerNorm-backward launch per fork; fp8_for: the layer the norm feeds (ops.group_norm)
+            y, h = ops.layer_norm_fork(h, *ln[0], fp8_for=att[("attn1", "qkv")][0][0])
             o = self._self_attn(att, y, B, N)
             h = ops.lora_group_linear(o, *att[("attn1", "out")], residual=h)[0]
-            y, h = ops.layer_norm_fork(h, *ln[1])
+            y, h = ops.layer_norm_fork(h, *ln[1], fp8_for=att[("attn2", "q")][0][0])
             o, probs = self._cross_attn(att, y, ctx, B, N, L, want_probs, kv_cache)
             h = ops.lora_group_linear(o, *att[("attn2", "out")], residual=h)[0]
-            y, h = ops.layer_norm_fork(h, *ln[2])
+            y, h = ops.layer_norm_fork(h, *ln[2], fp8_for=Lr["ff1"])
             h = ops.geglu_feed_forward(y, Lr["ff1"], Lr["ff2"], residual=h)  # fwd: 2 launches; bwd: GEGLU' in ff2's dgrad epilogue
             if want_probs:
                 probs_all.append(probs)
@@ -238,9 +239,11 @@ class UNet:
         self._temb_cache = {}
         self._te_cache = {}
         if self.fp8:  # quantise the frozen weights now (once), not inside the first step or a graph capture
+            ops.fp8_state(device)  # ... and give every activation site its scale / running-maximum words (delayed scaling)
             for o in m.made:
                 if ops.fp8_eligible(o, o.cin if isinstance(o, ops.FrozenConv) else o.in_features):
                     ops.fp8_weight(o)
+                    ops._fp8_site(o, device)
 
     def added_embedding(self, text_embeds, time_ids):
         """SDXL `text_time` conditioning (TrainableSDPipeline.py:772-784,807): add_embedding([pooled text |

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define COMAT_ABI_VERSION 7
+#define COMAT_ABI_VERSION 8
 
 enum { COMAT_F32 = 0, COMAT_BF16 = 1,
        COMAT_FP8_E4M3 = 2 /* OCP e4m3fn bytes; operand dtype of comat_gemm / comat_conv2d only (comat_fp8_quantize) */ };
@@ -395,13 +395,37 @@ int comat_adamw_tick(int32_t* counters, const float* gnorm_sq, void* stream);
  * Per-tensor fp8 (OCP e4m3fn) quantisation: the operand format of the fp8-forward configuration (BASELINE.json
  * configs[4]: "fp8 MFMA UNet forward with bf16 backward"; the reference itself trains in fp16 autocast,
  * training_script.py:449-456 - fp8 is this project's MI355X target, restated on the CPU by oracle/fp8.py).
- *   comat_fp8_scale:    *scale = max(max_i |x_i|, 2^-100) / 448      (one launch; ws: 8 bytes the caller zeroed once)
+ *   comat_fp8_scale:    *scale = max(max_i |x_i|, 2^-100) / 448      (one launch; ws: 8 bytes the caller zeroed once).  ABI 8:
+ *                       amax_bits (may be NULL) = the site's running maximum below, which receives the tensor's abs-max too
  *   comat_fp8_quantize: y_i = e4m3fn(x_i * (1 / *scale)), round to nearest even, saturating; y: n bytes
  * x: n elements of `dtype` (fp32 or bf16), 16-byte aligned.  Feed y and scale to comat_gemm / comat_conv2d with
  * in_dtype = COMAT_FP8_E4M3.
+ *
+ * DELAYED SCALING (ABI 8).  A quantisation SITE (the input of one frozen layer) owns two device words: `scale` (fp32) and
+ * `amax_bits` (the float bits of a running abs-max, zeroed once).  During an optimizer step every tensor that passes the site
+ * is quantised under the scale that is already there and folds its own abs-max into amax_bits; once per optimizer step
+ * comat_fp8_scales_update turns every running maximum that saw a tensor into next step's scale and re-arms it.  One launch per
+ * tensor, no reduction anybody waits for - and none at all where the producer of the tensor emits the bytes itself:
+ *   comat_fp8_quantize_scaled: y_i = e4m3fn(x_i * (1 / *scale)); *amax_bits = max(*amax_bits, bits(max_i |x_i|))
+ *   comat_fp8_scales_update:   for i < n with amax_bits[i] != 0: scale[i] = max(float(amax_bits[i]), 2^-100) / 448, amax_bits[i] = 0
+ *   comat_layernorm_fwd_q / comat_groupnorm_fwd_q: the normalisation of comat_layernorm_fwd / comat_groupnorm_fwd that ALSO
+ *       stores q8 = the e4m3 bytes of its (rounded) output y under *scale and folds max |y| into *amax_bits: the bits of
+ *       comat_fp8_quantize_scaled(y), one launch and one read of y less.  Only the vectorised forms (comat_*_fwd_q_ok -> 1);
+ *       other shapes return COMAT_EUNSUPPORTED and the caller runs the two calls.
+ * (The reference has no fp8 path: nothing to cite; arithmetic restated by oracle/fp8.py.)
  * ---------------------------------------------------------------------------------------------------------- */
-int comat_fp8_scale(const void* x, int64_t n, int32_t dtype, float* scale, void* ws, void* stream);
+int comat_fp8_scale(const void* x, int64_t n, int32_t dtype, float* scale, void* ws, uint32_t* amax_bits, void* stream);
 int comat_fp8_quantize(const void* x, int64_t n, int32_t dtype, const float* scale, void* y, void* stream);
+int comat_fp8_quantize_scaled(const void* x, int64_t n, int32_t dtype, const float* scale, void* y, uint32_t* amax_bits,
+                              void* stream);
+int comat_fp8_scales_update(uint32_t* amax_bits, float* scale, int32_t n, void* stream);
+int comat_layernorm_fwd_q_ok(int32_t C, int32_t dtype);
+int comat_layernorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t M, int32_t C,
+                          float eps, int32_t dtype, void* q8, const float* scale, uint32_t* amax_bits, void* stream);
+int comat_groupnorm_fwd_q_ok(int32_t B, int64_t HW, int32_t C, int32_t G, int32_t dtype);
+int comat_groupnorm_fwd_q(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws, int32_t B,
+                          int64_t HW, int32_t C, int32_t G, float eps, int32_t silu, int32_t dtype, void* q8, const float* scale,
+                          uint32_t* amax_bits, void* stream);
 
 #ifdef __cplusplus
 }

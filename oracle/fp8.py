@@ -12,6 +12,8 @@ element against torch's float8_e4m3fn cast over every representable value and th
   scale = max(amax|x|, 2^-100) / 448           (fp32)
   byte  = e4m3fn_rne(x * (1 / scale))          (fp32 reciprocal and product, saturating at +-448)
   value = scale * byte
+Delayed scaling (round 6): the same byte rule under a scale taken from the abs-max of the tensors that passed the site during
+the PREVIOUS optimizer step (`quantize_with_scale`); the scale rule itself is unchanged.
 """
 from __future__ import annotations
 
@@ -42,6 +44,15 @@ def quantize(x: torch.Tensor):
     s = scale_of(x)
     q = (x.detach().float() * (1.0 / s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
     return q.view(torch.uint8), s
+
+
+def quantize_with_scale(x: torch.Tensor, s) -> torch.Tensor:
+    """delayed scaling (include/comat_hip.h, ABI 8: comat_fp8_quantize_scaled and the *_fwd_q producers): the e4m3fn bytes of x
+    under a scale that was fixed BEFORE x was seen (the site's abs-max of the previous optimizer step); values beyond
+    448 * s saturate"""
+    s = torch.as_tensor(s, dtype=torch.float32)
+    q = (x.detach().float() * (1.0 / s)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8)
 
 
 def dequantize(q: torch.Tensor, s: torch.Tensor) -> torch.Tensor:

@@ -163,9 +163,49 @@ class SimKernels:
         _v(Y, (B * Hout * Wout, Cout), (Cout, 1)).copy_(acc.to(Y.dtype))
 
     # ---- fp8 operands ---------------------------------------------------------------------------------------
-    def fp8_quantize(self, x, out=None, scale=None):
+    @staticmethod
+    def _track(amax, m):
+        """amax [1] int32 holds float bits; non-negative floats order like their bits"""
+        cur = amax.view(torch.float32)
+        cur.copy_(torch.maximum(cur, m.reshape(1).float()))
+
+    def fp8_quantize_scaled(self, x, scale, amax, out=None):
+        return self._quantize_scaled(x, scale, amax, out)
+
+    def _quantize_scaled(self, x, scale, amax, out=None):
+        xf = x.float()
+        q = (xf * (1.0 / scale.float())).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+        self._track(amax, xf.abs().max())
+        if out is None:
+            out = torch.empty(x.shape, dtype=torch.uint8)
+        out.copy_(q)
+        return out
+
+    def fp8_scales_update(self, amax, scale, n):
+        a = amax[:n].view(torch.float32)
+        seen = amax[:n] != 0
+        scale[:n].copy_(torch.where(seen, torch.clamp(a, min=2.0 ** -100) / 448.0, scale[:n]))
+        amax[:n].zero_()
+
+    def layernorm_fwd_q_ok(self, x):
+        return x.shape[1] % 8 == 0
+
+    def layernorm_fwd_q(self, x, gamma, beta, y, stats, M, Cc, eps, q8, scale, amax):
+        self.layernorm_fwd(x, gamma, beta, y, stats, M, Cc, eps)
+        self._quantize_scaled(y, scale, amax, out=q8)
+
+    def groupnorm_fwd_q_ok(self, x, B, HW, Cc, G):
+        return Cc % 8 == 0 and HW > 256
+
+    def groupnorm_fwd_q(self, x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu, q8, scale, amax):
+        self.groupnorm_fwd(x, gamma, beta, y, stats, B, HW, Cc, G, eps, silu)
+        self._quantize_scaled(y, scale, amax, out=q8)
+
+    def fp8_quantize(self, x, out=None, scale=None, amax=None):
         """include/comat_hip.h: scale = max(amax, 2^-100) / 448, bytes = e4m3fn(x * (1 / scale)) (RNE, saturating)"""
         xf = x.float()
+        if amax is not None:
+            self._track(amax, xf.abs().max())
         sc = torch.clamp(xf.abs().max(), min=2.0 ** -100) / 448.0
         q = (xf * (1.0 / sc)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
         if scale is None:

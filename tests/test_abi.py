@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/comat_hip.h but not exported"
     bound = set(_hip.SIGNATURES) | {"comat_abi_version", "comat_last_error", "comat_build_id"}
     assert bound == set(names), (bound ^ set(names))
-    assert lib.comat_abi_version() == 7
+    assert lib.comat_abi_version() == 8
 
 
 def test_struct_layouts_match_header():

@@ -802,7 +802,7 @@ G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kerne
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])  # 8..11: 128-byte k-tiles; 12: 256 x 256, never split
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])  # 8..11: 128-byte k-tiles; 12 (256 x 256), 13 (256 x 128, 4 waves): never split
 @pytest.mark.parametrize("splits", [0, 1, 3])
 def test_gemm2_matches_reference(hip, cfg, splits, default_opts):
     """gemm2.hip (LDS-DMA pipelined kernel) under every block tile (g2_cfg) and split count against an fp32 reference
@@ -881,7 +881,7 @@ def test_gemm_tail_columns(hip, dtype, g2, default_opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])  # 8..11: 128-byte k-tiles; 12: 256 x 256, never split
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])  # 8..11: 128-byte k-tiles; 12 (256 x 256), 13 (256 x 128, 4 waves): never split
 @pytest.mark.parametrize("splits", [0, 2])
 def test_gemm2_segments_and_conv(hip, cfg, splits, default_opts):
     """K-segmented products (frozen + low-rank, batched q/k/v launch) and implicit-GEMM convs (stride 1 / 2, fused 2x

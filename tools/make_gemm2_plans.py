@@ -31,7 +31,7 @@ for path in args:
 out = ["// gemm2_plans.inc - measured plans of the pipelined GEMM / conv kernel for the problems of the SD1.5 (C2) and SDXL (C4) steps:",
        "// tools/tune_gemm2.py on an MI355X -> tools/make_gemm2_plans.py.  {conv, M, N, k-tiles, batch, tile code, slices}",
        "// tile codes: 1 128x128, 2 128x64, 3 256x128, 4 64x128, 6 64x64, 7 128x128 with 8 waves; 8..11 = 64x64, 128x64, 64x128, 128x128 with",
-       "// 128-byte k-tiles.  Trailing comment: us per launch with this plan,",
+       "// 128-byte k-tiles; 12 256x256, 13 256x128 (wave tiles of 128x64, never split).  Trailing comment: us per launch with this plan,",
        "// with the general 64x64 kernel, calls per step.",
        "static const Plan2Entry g2_plans[] = {"]
 for key in sorted(rows, key=lambda k: (-rows[k][3] * rows[k][2])):

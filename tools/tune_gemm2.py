@@ -22,7 +22,8 @@ import bench  # noqa: E402
 from comat_amd import _hip, ops  # noqa: E402
 
 CFGS = {1: (128, 128), 2: (128, 64), 3: (256, 128), 4: (64, 128), 6: (64, 64), 7: (128, 128),
-        8: (64, 64), 9: (128, 64), 10: (64, 128), 11: (128, 128)}  # 8..11: 128-byte k-tiles
+        8: (64, 64), 9: (128, 64), 10: (64, 128), 11: (128, 128),  # 8..11: 128-byte k-tiles
+        12: (256, 256), 13: (256, 128)}  # wave tiles of 128 x 64, never split
 
 
 class Recorder:
@@ -153,7 +154,7 @@ def main():
             blocks = -(-M // bm) * -(-N // bn) * batch
             best = None
             for s in (1, 2, 3, 4, 6, 8, 12, 16):
-                if s > 1 and (nkt // s < 8 or blocks * s > 1536 or blocks >= 512):
+                if s > 1 and (nkt // s < 8 or blocks * s > 1536 or blocks >= 512 or c >= 12):
                     continue
                 _hip.set_option("g2_cfg", c)
                 _hip.set_option("g2_splits", s)
@@ -166,13 +167,18 @@ def main():
             if c == 3 and -(-M // 256) * -(-N // 128) * batch < 64:  # 256 x 128: only with enough tiles (round 4: it wins at
                 continue                                            # 512 x 10240 x 1280, 24.8 vs 32.1 us)
             k2[c] = sweep(c)
+        for c in (12, 13):  # the 128 x 64 wave tiles: only where they get at least half a chip of blocks
+            bm, bn = CFGS[c]
+            if -(-M // bm) * -(-N // bn) * batch >= 120:
+                k2[c] = sweep(c)
         floor = min(k2.values())
         for c4, twin in ((8, 6), (9, 2), (10, 4), (11, 1)):  # 128-byte k-tiles: only where the twin is in the running
             if twin in k2 and k2[twin] <= 1.3 * floor and floor < 60.0:
                 sweep(c4)
-        _hip.set_option("gemm2", 0)
-        res["general"] = round(timeit(call), 2)
-        _hip.set_option("gemm2", 1)
+        if os.environ.get("TUNE_GENERAL", "0") != "0":  # the register-staged 64 x 64 kernel, for the table's comment column
+            _hip.set_option("gemm2", 0)
+            res["general"] = round(timeit(call), 2)
+            _hip.set_option("gemm2", 1)
         _hip.set_option("g2_cfg", 0)
         _hip.set_option("g2_splits", 0)
         res["auto"] = round(timeit(call), 2)
