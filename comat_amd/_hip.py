@@ -35,6 +35,9 @@ class GemmParams(C.Structure):
         ("scale_a", C.c_void_p), ("scale_b", C.c_void_p),
         ("C2", C.c_void_p), ("ldc2", C.c_int64), ("epi2", C.c_int32),
         ("B2", C.c_void_p), ("n2", C.c_int64), ("sB2_tail", C.c_int64), ("sC2_tail", C.c_int64), ("alpha2", C.c_float),  # epi2 = 4 (ABI 7)
+        ("s_scale_b", C.c_int64),  # ABI 8
+        ("A2k", C.c_void_p), ("B2k", C.c_void_p), ("K2", C.c_int64), ("lda2k", C.c_int64), ("ldb2k", C.c_int64),
+        ("sA2k", C.c_int64), ("sB2k", C.c_int64),  # bf16 k-tail of an fp8 product (ABI 8)
     ]
 
 
@@ -271,8 +274,10 @@ class HipKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
              sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
-             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None):
-        """scales = (scale_a, scale_b): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h);
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None):
+        """ktail = (A2 [M, K2], B2 [N, K2], K2, lda2, ldb2, sA2, sB2): bf16 k-tail added to the scaled fp8 product in the same launch;
+        scales = (scale_a, scale_b[, s_scale_b]): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h; batch z of a
+        batched product uses scale_b[z * s_scale_b]);
         geglu = (C2 [M, N / 2], keep_pre): the GEGLU epilogue over interleaved value / gate columns (comat_gemm_params::epi2):
         C2 receives value * gelu(gate); Cout receives the pre-activations only when keep_pre (it may be None otherwise);
         geglu = (pre [M, 2 N], "bwd"): the GEGLU backward epilogue (epi2 = 3): Cout [M, 2 N] = gradient of the pre-activations;
@@ -309,8 +314,13 @@ class HipKernels:
         assert A.dtype == B.dtype
         p.in_dtype, p.out_dtype = dt(A), (dt(Cout) if Cout is not None else BF16)
         assert (scales is not None) == (p.in_dtype == FP8), "fp8 operands come with their scales"
-        if scales is not None:
+        if scales is not None:  # (scale_a, scale_b[, batch stride of scale_b])
             p.scale_a, p.scale_b = _ptr(scales[0]), _ptr(scales[1])
+            p.s_scale_b = scales[2] if len(scales) > 2 else 0
+        if ktail is not None:
+            assert p.in_dtype == FP8 and ktail[0].dtype == torch.bfloat16 and ktail[1].dtype == torch.bfloat16
+            p.A2k, p.B2k = _ptr(ktail[0]), _ptr(ktail[1])
+            p.K2, p.lda2k, p.ldb2k, p.sA2k, p.sB2k = ktail[2:]
         p.r_dtype = dt(R) if R is not None else 0
         ws = self._workspace(A.device)
         p.ws, p.ws_bytes = ws.data_ptr(), self.WS_BYTES

@@ -79,19 +79,22 @@ __device__ __forceinline__ void fp8_amax_track(unsigned* slot, float m) {
     if (b > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         __hip_atomic_fetch_max(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// 8 (4) fp32 values * inv -> e4m3fn bytes (hardware RNE conversion, saturating): the arithmetic of comat_fp8_quantize
+// 8 (4) fp32 values * inv -> e4m3fn bytes: the arithmetic of comat_fp8_quantize.  The hardware conversion rounds to nearest even
+// but does NOT saturate (beyond +-480 it produces the NaN byte): under a just-in-time scale nothing exceeds 448; under a delayed
+// scale a tensor may, so the product is clamped first (v_med3_f32, one instruction; exact for everything in range)
+__device__ __forceinline__ float fp8_sat(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
 __device__ __forceinline__ uint2 fp8_pack8(const float* v, float inv) {
     int lo = 0, hi = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
-    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[0] * inv), fp8_sat(v[1] * inv), lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[2] * inv), fp8_sat(v[3] * inv), lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[4] * inv), fp8_sat(v[5] * inv), hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[6] * inv), fp8_sat(v[7] * inv), hi, true);
     return make_uint2((unsigned)lo, (unsigned)hi);
 }
 __device__ __forceinline__ unsigned fp8_pack4(const float* v, float inv) {
     int lo = 0;
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
-    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[0] * inv), fp8_sat(v[1] * inv), lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(v[2] * inv), fp8_sat(v[3] * inv), lo, true);
     return (unsigned)lo;
 }
 

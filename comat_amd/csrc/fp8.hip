@@ -93,7 +93,7 @@ template <typename T> __global__ __launch_bounds__(256) void fp8_quantize_scaled
         const int64_t i = nv * 8 + threadIdx.x;
         const float xe = ldf<T>(x + i);
         m = fmaxf(m, fabsf(xe));
-        const int q = __builtin_amdgcn_cvt_pk_fp8_f32(xe * inv, 0.0f, 0, false);
+        const int q = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_sat(xe * inv), 0.0f, 0, false);
         y[i] = (unsigned char)(q & 0xff);
     }
     m = block_max_256(m, sbuf);

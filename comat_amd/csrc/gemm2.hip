@@ -90,6 +90,12 @@ struct Args2 {
     int vec;  // 16-byte epilogue accesses are legal (alignment / divisibility checked by the host)
     const float* scale_a;  // fp8 operands: device pointers to the per-tensor dequantisation scales (NULL = 1)
     const float* scale_b;
+    int64_t s_scale_b;     // batch z uses scale_b[z * s_scale_b]
+    // fp8 operands only: bf16 k-tail  + A2k B2k^T  added to the SCALED fp8 product (comat_gemm_params::A2k); strides in bytes
+    const char* A2k;
+    const char* B2k;
+    int64_t lda2k, ldb2k, sA2k, sB2k;
+    int K2;
     // epi2 == 4 (tail columns, single-segment GEMM only): rows >= N - ep.n2 of B come from B2 (leading dimension seg[0].ldb)
     const char* B2;
     int64_t sB2t, sC2t;  // batch strides of B2 (bytes) and C2 (elements)
@@ -147,7 +153,7 @@ __device__ __forceinline__ void mma_t_fp8(f32x16_t& acc, const short8_t& w0, con
 // is the same code in the same order (epilogue_run / _tail / _geglu / _geglu_bwd): identical bits.
 template <int TM, int TN, int WTM, int WTN, int NTH, bool WT = false, bool STG = false>
 __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& g, int sp, int64_t tile, int64_t z, int64_t m0,
-                                          int64_t n0, int wr, int wc, int r, int h, int tid, char* smem) {
+                                          int64_t n0, int wr, int wc, int r, int h, int tid, char* smem, bool prescaled = false) {
     // ---- split-K: combine inside the launch (write-through slab stores, sc1 loads by the last arriver: gemm_shared.h) ----
     if constexpr (TM * TN <= 4) if (g.splits > 1) {  // (wave tiles of more than 4 MFMA tiles are never split: the host keeps splits = 1)
         constexpr int QPT = TM * TN * 4;  // 16-byte vectors per thread
@@ -222,8 +228,10 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     }
 #endif
     Epi ep = g.ep;
-    if (g.scale_a) ep.alpha *= *g.scale_a;
-    if (g.scale_b) ep.alpha *= *g.scale_b;
+    if (!prescaled) {  // (the fp8 kernel with a bf16 k-tail has applied the operand scales to its accumulators already)
+        if (g.scale_a) ep.alpha *= *g.scale_a;
+        if (g.scale_b) ep.alpha *= g.scale_b[z * g.s_scale_b];
+    }
     ep.C = (char*)ep.C + z * g.sC * (ep.out_dt == COMAT_F32 ? 4 : 2);
     if (ep.R) ep.R = (const char*)ep.R + z * g.sR * (ep.r_dt == COMAT_F32 ? 4 : 2);
     if (ep.bias) ep.bias += z * g.sBias;
@@ -789,8 +797,55 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
     }
     }
 
+    // fp8 operands + bf16 k-tail (the LoRA up projection of a frozen projection, K2 = rank): the e4m3 product is scaled in its
+    // registers, then K2 / 16 more MFMA steps run on fragments read STRAIGHT from global memory (the tail is 128 .. 256 bytes per
+    // row: no ring, one exposed round trip) - by the first k-slice only when the problem is split
+    bool prescaled = false;
+    if constexpr (EB == 1) {
+        if (g.A2k) {
+            prescaled = true;
+            float sc = 1.0f;
+            if (g.scale_a) sc *= *g.scale_a;
+            if (g.scale_b) sc *= g.scale_b[z * g.s_scale_b];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] *= sc;
+            if (sp == 0) {
+                const char* pa2[TM];
+                const char* pb2[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    int64_t row = m0 + wr * WTM + a * 32 + r;
+                    if (row >= g.M) row = g.M - 1;  // rows beyond M are never stored
+                    pa2[a] = g.A2k + z * g.sA2k + row * g.lda2k + h * 16;
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    int64_t row = n0 + wc * WTN + b * 32 + r;
+                    if (row >= g.N) row = g.N - 1;
+                    pb2[b] = g.B2k + z * g.sB2k + row * g.ldb2k + h * 16;
+                }
+                const int steps = g.K2 >> 4;
+#pragma unroll 2
+                for (int s2 = 0; s2 < steps; ++s2) {
+                    short8_t xt[TM], wt[TN];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) xt[a] = *(const short8_t*)(pa2[a] + s2 * 32);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) wt[b] = *(const short8_t*)(pb2[b] + s2 * 32);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b) mma_t(acc[a][b], wt[b], xt[a]);
+                }
+            }
+        }
+    }
     static_assert(NW * 32 * (WTN + 4) * 4 <= NST * SS, "the staged epilogue fits the ring");
-    g2_finish<TM, TN, WTM, WTN, NTH, false, true>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem);
+    g2_finish<TM, TN, WTM, WTN, NTH, false, true>(acc, g, sp, tile, z, m0, n0, wr, wc, r, h, tid, smem, prescaled);
 }
 
 template <int BM, int BN, int WM, int WN, int NST, bool CONV, int EB = 2, int KS = 2>
@@ -1296,10 +1351,11 @@ static void plan2(bool conv, bool fp8, int64_t M, int64_t N, int nkt, int64_t ba
     g2_overrides(&fc, &fs);
     int c = fc;
     int64_t s = fs;
-    if (c == CFG_AUTO && !fp8) {  // the table was measured with bf16 operands
+    if (c == CFG_AUTO) {  // (kind 0 / 1: bf16 GEMM / conv, 2 / 3: the same with fp8 operands - measured separately, round 6)
+        const int kind = (conv ? 1 : 0) + (fp8 ? 2 : 0);
         for (size_t i = 0; i < sizeof(g2_plans) / sizeof(g2_plans[0]); ++i) {
             const Plan2Entry& e = g2_plans[i];
-            if (e.conv == (conv ? 1 : 0) && e.M == M && e.N == N && e.nkt == nkt && e.batch == batch) {
+            if (e.conv == kind && e.M == M && e.N == N && e.nkt == nkt && e.batch == batch) {
                 c = e.cfg;
                 if (s == 0) s = e.splits;
                 break;
@@ -1504,6 +1560,17 @@ int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
     a.sC = p->sC1; a.sR = p->sR1; a.sBias = 0;
     a.scale_a = fp8 ? p->scale_a : nullptr;
     a.scale_b = fp8 ? p->scale_b : nullptr;
+    a.s_scale_b = fp8 && p->batch1 > 1 ? p->s_scale_b : 0;
+    if (p->A2k || p->B2k) {  // bf16 k-tail of an fp8 product: the caller's contract, checked here (no second kernel behind it)
+        if (!fp8 || !p->A2k || !p->B2k || p->K2 <= 0 || p->K2 % 16 || p->K2 > 4096 || p->lda2k % 8 || p->ldb2k % 8 || p->lda2k < p->K2 ||
+            p->ldb2k < p->K2 || !al16(p->A2k) || !al16(p->B2k) || p->epi2 || (p->batch1 > 1 && (p->sA2k % 8 || p->sB2k % 8))) {
+            comat_set_error("comat_gemm: the bf16 k-tail (A2k, B2k) needs fp8 operands, K2 %% 16 == 0, 16-byte aligned rows and no second epilogue");
+            return -1;
+        }
+        a.A2k = (const char*)p->A2k; a.B2k = (const char*)p->B2k;
+        a.lda2k = p->lda2k * 2; a.ldb2k = p->ldb2k * 2; a.sA2k = p->sA2k * 2; a.sB2k = p->sB2k * 2;
+        a.K2 = (int)p->K2;
+    }
     fill_epi(a, p);
     if (p->epi2 == 4) {  // tail columns: 8-column pieces on both sides of the seam, 16-byte rows of C2 and B2; else two launches
         const int es = p->out_dtype == COMAT_F32 ? 4 : 8;

@@ -349,6 +349,23 @@ def fp8_weight(holder):
     return w8
 
 
+def fp8_weight_group(lins):
+    """(bytes [G, N, K], scales [G]) of projections whose frozen weights are co-allocated at a constant spacing (frozen_linear_group):
+    each weight under ITS OWN scale, as fp8_weight would quantise it, but in one buffer - the group's fp8 products are then one
+    batched launch (comat_gemm_params::s_scale_b).  None when the weights are not co-allocated."""
+    g8 = getattr(lins[0], "_w8_group", None)
+    if g8 is None:
+        if len(lins) < 2 or _uniform_stride([lin.w for lin in lins]) is None:
+            return None
+        G, (N, Kd) = len(lins), lins[0].w.shape
+        w8 = torch.empty((G, N, Kd), dtype=torch.uint8, device=lins[0].w.device)
+        sc = torch.empty(G, dtype=torch.float32, device=w8.device)
+        for i, lin in enumerate(lins):
+            lin._w8 = kernels().fp8_quantize(lin.w.contiguous(), out=w8[i], scale=sc[i:i + 1])
+        g8 = lins[0]._w8_group = (w8, sc)
+    return g8
+
+
 # ---- activation scales ------------------------------------------------------------------------------------------------
 # "jit" (rounds 2-5): every activation that enters an fp8 product is quantised under its OWN abs-max - two launches per tensor
 # (a reduction with a ticket, then the bytes), ~1 300 of them per SDXL forward.
@@ -361,6 +378,9 @@ def fp8_weight(holder):
 # same bits as quantising the stored output.  Values beyond the previous step's abs-max saturate at +-448 * scale, as in every
 # delayed-scaling recipe.  Before the first step the scales come from fp8_calibration(): one no-grad pass in which every site
 # quantises just in time AND records its abs-max.
+# COMAT_FP8_KTAIL (default 1): the LoRA up projection of a frozen projection rides in the fp8 product's launch as a bf16 k-tail
+# (comat_gemm_params::A2k); 0 = its own launch behind it (rounds 2-5), for A/B runs
+_fp8_ktail = os.environ.get("COMAT_FP8_KTAIL", "1") != "0"
 _FP8_MAX_SITES = 4096
 _fp8_scaling = os.environ.get("COMAT_FP8_SCALING", "jit")
 _fp8_calibrating = False
@@ -1191,7 +1211,23 @@ class _LoRAGroupLinear(Function):
         sw, su = _uniform_stride([lin.w for lin in lins]), _uniform_stride(ucs)
         use8 = [_use_fp8(lin, Kd) for lin in lins]
         k.gemm(x, dc, h, M, Gr, Kd, Kd, Kd, Gr, alpha=grp.scale)
-        if any(use8):
+        g8 = fp8_weight_group(lins) if (all(use8) and G > 1 and su is not None and all(lin.bias is None for lin in lins)
+                                        and r % 16 == 0 and Gr % 8 == 0) else None
+        if g8 is not None:
+            # q / k / v (k / v) of one attention: ONE batched fp8 product (shared input bytes, a scale per frozen weight) and ONE
+            # batched low-rank product on top of it - 3 launches for the group instead of 1 + 2 G
+            x8, sx = fp8_act(x, lins[0])
+            N = lins[0].out_features
+            ys = x.new_empty((G, M, N))
+            if _fp8_ktail:
+                k.gemm(x8, g8[0], ys, M, N, Kd, Kd, Kd, N, batch=(G, 1), sB=(N * Kd, 0), sC=(M * N, 0), scales=(sx, g8[1], 1),
+                       ktail=(h, ucs[0], r, Gr, r, r, su))
+            else:
+                k.gemm(x8, g8[0], ys, M, N, Kd, Kd, Kd, N, batch=(G, 1), sB=(N * Kd, 0), sC=(M * N, 0), scales=(sx, g8[1], 1))
+                k.gemm(h, ucs[0], ys, M, N, r, Gr, r, N, batch=(G, 1), sA=(r, 0), sB=(su, 0), sC=(M * N, 0), R=ys, ldr=N,
+                       sR=(M * N, 0), beta=1.0)
+            ys = list(ys.unbind(0))
+        elif any(use8):
             # frozen part on the fp8 MFMA (x quantised once for the whole group), low-rank part added in the storage dtype
             x8, sx = fp8_act(x, lins[use8.index(True)])
             ys = []
@@ -1199,7 +1235,12 @@ class _LoRAGroupLinear(Function):
                 N = lin.out_features
                 y = x.new_empty((M, N))
                 beta = 1.0 if residual is not None else 0.0
-                if use8[i]:
+                if use8[i] and _fp8_ktail and r % 16 == 0 and Gr % 8 == 0:
+                    # frozen product (e4m3 MFMA) + low-rank product (bf16 MFMA, k-tail) + bias + residual: one launch
+                    w8, sw8 = fp8_weight(lin)
+                    k.gemm(x8, w8, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=beta, scales=(sx, sw8),
+                           ktail=(h[:, i * r:(i + 1) * r], ucs[i], r, Gr, r, 0, 0))
+                elif use8[i]:
                     w8, sw8 = fp8_weight(lin)
                     k.gemm(x8, w8, y, M, N, Kd, Kd, Kd, N, bias=lin.bias, R=residual, ldr=N, beta=beta, scales=(sx, sw8))
                     k.gemm(h[:, i * r:(i + 1) * r], ucs[i], y, M, N, r, Gr, r, N, R=y, ldr=N, beta=1.0)

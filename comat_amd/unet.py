@@ -75,7 +75,7 @@ class _Mods:
         """fp8: False, True (every eligible block layer) or a tuple of name fragments (only layers whose state-dict name
         contains one of them: per-category parity tests)"""
         self.sd, self.dtype, self.device = sd, dtype, device
-        self.fp8, self.made = fp8, []
+        self.fp8, self.made, self.groups = fp8, [], []
 
     def _tag(self, obj, name):
         obj.allow_fp8 = (bool(self.fp8) and not any(s in name for s in self.NO_FP8)
@@ -97,7 +97,9 @@ class _Mods:
         ws = [self.sd[n + ".weight"] for n in names]
         if len(names) > 1 and all(tuple(w.shape) == tuple(ws[0].shape) for w in ws):
             grp = ops.frozen_linear_group(ws, [self.sd.get(n + ".bias") for n in names], self.dtype, self.device)
-            return [self._tag(g, n) for g, n in zip(grp, names)]
+            grp = [self._tag(g, n) for g, n in zip(grp, names)]
+            self.groups.append(grp)
+            return grp
         return [self.lin(n) for n in names]
 
     def conv(self, name, stride=1, pad=1):
@@ -240,6 +242,9 @@ class UNet:
         self._te_cache = {}
         if self.fp8:  # quantise the frozen weights now (once), not inside the first step or a graph capture
             ops.fp8_state(device)  # ... and give every activation site its scale / running-maximum words (delayed scaling)
+            for grp in m.groups:  # q / k / v (k / v) of one attention: their bytes in one buffer (one batched fp8 product)
+                if all(ops.fp8_eligible(o, o.in_features) for o in grp):
+                    ops.fp8_weight_group(grp)
             for o in m.made:
                 if ops.fp8_eligible(o, o.cin if isinstance(o, ops.FrozenConv) else o.in_features):
                     ops.fp8_weight(o)

@@ -111,6 +111,18 @@ typedef struct {
     const void* B2;
     int64_t n2, sB2_tail, sC2_tail;
     float alpha2;
+    /* ABI 8, fp8 operands with batch1 > 1: batch z is scaled by scale_b[z * s_scale_b] (0: one scale for every batch) - the
+     * q / k / v projections of one attention share their input (one scale_a) but carry a scale per frozen weight */
+    int64_t s_scale_b;
+    /* ABI 8, fp8 operands only: a MIXED-PRECISION K TAIL in the same launch,
+     *     C = act(alpha * (scale_a * scale_b * A B^T + A2k B2k^T) + bias + bias2) + beta * R
+     * with A2k [M, K2] and B2k [N, K2] in bf16 (row strides lda2k / ldb2k, batch1 strides sA2k / sB2k, in elements; K2 a multiple
+     * of 16, 16-byte aligned rows; NULL: none).  This is the LoRA branch of a frozen projection under the fp8 forward:
+     * y = x8 W8^T (e4m3 MFMA) + h U^T (bf16 MFMA, h = s x D^T) - `training_utils/pipeline.py:94-115` - without a second launch and
+     * without the read-modify-write of y. */
+    const void* A2k;
+    const void* B2k;
+    int64_t K2, lda2k, ldb2k, sA2k, sB2k;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 

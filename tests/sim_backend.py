@@ -41,7 +41,7 @@ class SimKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
              sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
-             beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None):
+             beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None):
         b1, b2 = batch
         if tail is not None:  # comat_gemm_params::epi2 = 4: the last n2 columns are alpha2 * A B2^T into C2, the rest as usual
             B2, C2t, n2, ldc2, sB2t, sC2t, alpha2 = tail
@@ -54,10 +54,17 @@ class SimKernels:
         assert (scales is not None) == (A.dtype == torch.uint8)
         if scales is not None:
             assert not transA and not transB and K % 64 == 0 and lda % 16 == 0 and ldb % 16 == 0 and b2 == 1
-        sa, sb = scales if scales is not None else (None, None)
+        sa, sb = scales[:2] if scales is not None else (None, None)
+        if scales is not None and len(scales) > 2 and scales[2] and b1 > 1:  # per-batch scale of B (comat_gemm_params::s_scale_b)
+            sb = torch.as_strided(sb, (b1, 1, 1, 1), (scales[2], 0, 0, 0), sb.storage_offset())
         Av = _v(A, (b1, b2, M, K), (sA[0], sA[1], 1, lda) if transA else (sA[0], sA[1], lda, 1))
         Bv = _v(B, (b1, b2, N, K), (sB[0], sB[1], 1, ldb) if transB else (sB[0], sB[1], ldb, 1))
-        acc = alpha * (_f(Av, sa) @ _f(Bv, sb).transpose(-1, -2))
+        prod = _f(Av, sa) @ _f(Bv, sb).transpose(-1, -2)
+        if ktail is not None:  # comat_gemm_params::A2k: bf16 k-tail on top of the scaled fp8 product
+            A2, B2, K2, lda2, ldb2, sA2, sB2 = ktail
+            assert scales is not None and K2 % 16 == 0 and geglu is None and b2 == 1
+            prod = prod + _v(A2, (b1, b2, M, K2), (sA2, 0, lda2, 1)).float() @ _v(B2, (b1, b2, N, K2), (sB2, 0, ldb2, 1)).float().transpose(-1, -2)
+        acc = alpha * prod
         if bias is not None:
             acc = acc + bias.float()
         if bias2 is not None:

@@ -470,7 +470,9 @@ def test_layernorm_emits_the_bytes_of_its_own_output(dev, dtype, shape):
     g, b = (1 + 0.1 * rnd(Cc, seed=1)).to(dev), (0.1 * rnd(Cc, seed=2)).to(dev)
     y0, st0 = torch.empty_like(x), torch.empty((M, 2), device=dev)
     k.layernorm_fwd(x, g, b, y0, st0, M, Cc, 1e-5)
-    assert k.layernorm_fwd_q_ok(x)
+    if not k.layernorm_fwd_q_ok(x):  # rows of more than 256 16-byte vectors (fp32: C > 1024) take the scalar kernel: two calls there
+        assert dtype == torch.float32 and Cc > 1024
+        return
     y, st, q8 = torch.empty_like(x), torch.empty((M, 2), device=dev), torch.empty((M, Cc), dtype=torch.uint8, device=dev)
     scale = (OF.scale_of(y0.cpu()) * 0.8).reshape(1).to(dev)
     amax = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -515,14 +517,14 @@ def test_delayed_scaling_site_protocol(dev, delayed):
             y1 = ops.linear(x1.to(dev), lin)
         ops.fp8_end_of_step()
         s1 = OF.scale_of(x1)
-        assert rel_l2(y1, ref(x1, s1)) < 1e-5
+        assert rel_l2(y1, ref(x1, s1)) < 1e-4
         y2 = ops.linear(x2.to(dev), lin)       # 2.5x larger values under the scale of x1: the tail saturates, as the oracle's does
-        assert rel_l2(y2, ref(x2, s1)) < 1e-5
+        assert rel_l2(y2, ref(x2, s1)) < 1e-4
         y3 = ops.linear(x3.to(dev), lin)
-        assert rel_l2(y3, ref(x3, s1)) < 1e-5
+        assert rel_l2(y3, ref(x3, s1)) < 1e-4
         ops.fp8_end_of_step()                  # max(|x2|, |x3|) = |x2|
         y3b = ops.linear(x3.to(dev), lin)
-        assert rel_l2(y3b, ref(x3, OF.scale_of(x2))) < 1e-5
+        assert rel_l2(y3b, ref(x3, OF.scale_of(x2))) < 1e-4
 
 
 def test_delayed_scaling_unet_matches_the_jit_form_after_calibration(dev, delayed):
@@ -567,3 +569,58 @@ def test_delayed_scaling_unet_matches_the_jit_form_after_calibration(dev, delaye
           f"{n_sites} sites: {counts['scaled']} quantize launches, {counts['ln']} LayerNorm + {counts['gn']} GroupNorm producers")
     assert rel_l2(e_cal, e_jit) < 1e-6   # the calibration pass IS the jit form
     assert rel_l2(e_del, e_jit) < 2e-2   # same scales; only bytes on a rounding boundary may differ (see the jit UNet test)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64, 16), (200, 96, 128, 128), (333, 320, 640, 128), (2048, 1280, 1280, 128), (8192, 640, 640, 32)])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_fp8_gemm_with_a_bf16_k_tail_matches_oracle(dev, shape, splits):
+    """comat_gemm_params::A2k (ABI 8): scale_a * scale_b * (A8 B8^T) + A2 B2^T in ONE launch - the LoRA up projection riding in the
+    frozen projection's fp8 product - against the oracle's dequantised product plus the bf16 product; also with the e4m3 product
+    cut along k (the tail must be added once, by the first slice)"""
+    M, N, K, K2 = shape
+    x, w = rnd(M, K, seed=1) * 2.0, rnd(N, K, seed=2) * 0.05
+    h, u = (rnd(M, 3 * K2, seed=5) * 0.5).bfloat16(), (rnd(N, K2, seed=6) * 0.2).bfloat16()
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4).bfloat16()
+    (xq, sx), (wq, sw) = OF.quantize(x), OF.quantize(w)
+    hs = h[:, K2:2 * K2]  # a column slice of the rank-r buffer of a q / k / v group (lda2k = 3 K2)
+    ref = (OF.dequantize(xq, sx).double() @ OF.dequantize(wq, sw).double().t() + hs.double() @ u.double().t() + bias.double()
+           + res.double())
+    k = ops.kernels()
+    x8, sxd = k.fp8_quantize(x.to(dev))
+    w8, swd = k.fp8_quantize(w.to(dev))
+    hd, ud = h.to(dev), u.to(dev)
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    if dev.type == "cuda":
+        from comat_amd import _hip
+        _hip.set_option("g2_splits", splits)
+    try:
+        k.gemm(x8, w8, y, M, N, K, K, K, N, bias=bias.to(dev), R=res.to(dev), ldr=N, beta=1.0, scales=(sxd, swd),
+               ktail=(hd[:, K2:2 * K2], ud, K2, 3 * K2, K2, 0, 0))
+    finally:
+        if dev.type == "cuda":
+            _hip.set_option("g2_splits", 0)
+    assert rel_l2(y, ref) < 6e-3, rel_l2(y, ref)
+    if dev.type == "cuda":
+        assert _hip.last_gemm_kernel() == 3
+
+
+def test_fp8_batched_gemm_with_per_batch_weight_scales_and_k_tail(dev):
+    """q / k / v of one attention in one launch: shared input bytes, a scale per frozen weight (s_scale_b), the three up projections
+    as the batched k-tail"""
+    G, M, N, K, r = 3, 300, 192, 256, 32
+    x = rnd(M, K, seed=1)
+    ws = [rnd(N, K, seed=10 + i) * (0.02 * (i + 1)) for i in range(G)]  # different magnitudes: different scales
+    h, us = (rnd(M, G * r, seed=5) * 0.5).bfloat16(), (rnd(G, N, r, seed=6) * 0.2).bfloat16()
+    xq, sx = OF.quantize(x)
+    ref = torch.stack([OF.dequantize(xq, sx).double() @ OF.dequantize(*OF.quantize(ws[i])).double().t()
+                       + h[:, i * r:(i + 1) * r].double() @ us[i].double().t() for i in range(G)])
+    k = ops.kernels()
+    x8, sxd = k.fp8_quantize(x.to(dev))
+    w8 = torch.empty((G, N, K), dtype=torch.uint8, device=dev)
+    sc = torch.empty(G, device=dev)
+    for i in range(G):
+        k.fp8_quantize(ws[i].to(dev), out=w8[i], scale=sc[i:i + 1])
+    ys = torch.empty((G, M, N), dtype=torch.bfloat16, device=dev)
+    k.gemm(x8, w8, ys, M, N, K, K, K, N, batch=(G, 1), sB=(N * K, 0), sC=(M * N, 0), scales=(sxd, sc, 1),
+           ktail=(h.to(dev), us.to(dev), r, G * r, r, r, N * r))
+    assert rel_l2(ys, ref) < 6e-3, rel_l2(ys, ref)

@@ -19,7 +19,7 @@ for path in args:
         if not line.startswith("{"):
             continue
         r = json.loads(line)
-        key = (1 if r["kind"] == "conv" else 0, r["M"], r["N"], r["nkt"], r["batch"])
+        key = ({"conv": 1, "gemm8": 2, "conv8": 3}.get(r["kind"], 0), r["M"], r["N"], r["nkt"], r["batch"])
         var = {k: v for k, v in r["us"].items() if ":" in k}
         best = min(var.values())
         ok = [(int(k.split(":")[1]), v, k) for k, v in var.items() if v <= best * 1.03]
@@ -29,7 +29,8 @@ for path in args:
         if old is None or r["calls"] >= old[3] or path != old[5]:  # later files (newer measurements) win
             rows[key] = (cfg, s, us, max(r["calls"], old[3] if old else 0), r["us"].get("general", 0.0), path)
 out = ["// gemm2_plans.inc - measured plans of the pipelined GEMM / conv kernel for the problems of the SD1.5 (C2) and SDXL (C4) steps:",
-       "// tools/tune_gemm2.py on an MI355X -> tools/make_gemm2_plans.py.  {conv, M, N, k-tiles, batch, tile code, slices}",
+       "// tools/tune_gemm2.py on an MI355X -> tools/make_gemm2_plans.py.  {kind, M, N, k-tiles, batch, tile code, slices}; kind 0 GEMM, 1 conv,",
+       "// 2 / 3 the same with fp8 operands (C5; k-tiles of 64 bytes either way)",
        "// tile codes: 1 128x128, 2 128x64, 3 256x128, 4 64x128, 6 64x64, 7 128x128 with 8 waves; 8..11 = 64x64, 128x64, 64x128, 128x128 with",
        "// 128-byte k-tiles; 12 256x256, 13 256x128 (wave tiles of 128x64, never split).  Trailing comment: us per launch with this plan,",
        "// with the general 64x64 kernel, calls per step.",

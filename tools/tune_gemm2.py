@@ -37,7 +37,17 @@ class Recorder:
 
         def wrapped(*a, **kw):
             sig = None
-            if name == "gemm" and a[0].dtype == torch.bfloat16 and not kw.get("transA") and not kw.get("transB"):
+            if name == "gemm" and a[0].dtype == torch.uint8:  # fp8 operands (C5): 64-byte k-tiles = 64 elements (a GEGLU epilogue is timed as a plain one)
+                b = kw.get("batch", (1, 1))
+                kt = kw.get("ktail")
+                sig = ("gemm8", a[3], a[4], a[5] // 64, b[0], (a[5], kt[2] if kt is not None else 0), kw.get("R") is not None,
+                       str(a[2].dtype))
+            elif name == "conv2d" and a[0].dtype == torch.uint8 and kw.get("mode", 0) == 0:
+                B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad = a[3:14]
+                sig = ("conv8", B * Hout * Wout, Cout, KH * KW * Cin // 64, 1,
+                       (B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, kw.get("ups", 1)), kw.get("R") is not None,
+                       str(a[2].dtype))
+            elif name == "gemm" and a[0].dtype == torch.bfloat16 and not kw.get("transA") and not kw.get("transB"):
                 b = kw.get("batch", (1, 1))
                 if b[1] == 1 and a[5] % 32 == 0 and a[3] >= 48:
                     # (a[2] is None for the GEGLU epilogue of a no-grad call: no pre-activations are stored)
@@ -94,6 +104,24 @@ def make_call(k, sig, dev):
     kind, M, N, nkt, batch, extra, has_r, out_dt = sig
     odt = torch.float32 if "float32" in out_dt else T
     r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(T)
+    r8 = lambda *s: torch.randint(0, 120, s, device=dev, dtype=torch.uint8)  # e4m3 bytes of small positive values
+    one = torch.ones(max(batch, 1), device=dev)
+    if kind == "gemm8":
+        K, K2 = extra
+        a, b = r8(M, K), r8(batch, N, K)
+        c = torch.empty((batch, M, N), dtype=odt, device=dev)
+        R = torch.zeros_like(c[0]) if has_r else None
+        kt = (r(M, batch * K2), r(batch, N, K2), K2, batch * K2, K2, K2, N * K2) if K2 else None
+        return lambda: k.gemm(a, b, c, M, N, K, K, K, N, R=R, ldr=N, beta=1.0 if has_r else 0.0, batch=(batch, 1), sB=(N * K, 0),
+                              sC=(M * N, 0), scales=(one, one, 1), ktail=kt)
+    if kind == "conv8":
+        B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, ups = extra
+        x, w = r8(B * Hin * Win, Cin), r8(Cout, KH, KW, Cin)
+        y = torch.empty((B * Hout * Wout, Cout), dtype=odt, device=dev)
+        R = torch.zeros_like(y) if has_r else None
+        bias = torch.zeros(Cout, device=dev)
+        return lambda: k.conv2d(x, w, y, B, Hin, Win, Cin, Hout, Wout, Cout, KH, KW, stride, pad, mode=0, ups=ups, bias=bias, R=R,
+                                beta=1.0 if has_r else 0.0, scales=(one, one))
     if kind == "gemm":
         K = extra
         a, b = r(batch, M, K), r(batch, N, K)
@@ -122,7 +150,8 @@ def main():
     seen = {}
     for cfg_name in sys.argv[1:] or ["c2"]:
         ops.set_kernel_backend(k)
-        trainer, batch, fixed, scfg, _, _ = bench.build_world(dev, torch.bfloat16, 0, cfg_name)
+        world, bs = (cfg_name[:-3], 4) if cfg_name.endswith("bs4") else (cfg_name, 1)  # "c2bs4": the batch-4 secondary line
+        trainer, batch, fixed, scfg, _, _ = bench.build_world(dev, torch.bfloat16, 0, world, bs=bs)
         trainer.train_step(batch, **fixed)
         rec = Recorder(k)
         ops.set_kernel_backend(rec)
@@ -139,7 +168,8 @@ def main():
         for m in re.finditer(r"^\s*\{(\d+), (\d+), (\d+), (\d+), (\d+), ", open(os.path.join(ROOT, "comat_amd", "csrc", "gemm2_plans.inc")).read(), re.M):
             have.add(tuple(int(v) for v in m.groups()))
         n0 = len(seen)
-        seen = {sig: n for sig, n in seen.items() if (1 if sig[0] == "conv" else 0, sig[1], sig[2], sig[3], sig[4]) not in have}
+        code = {"gemm": 0, "seg": 0, "conv": 1, "gemm8": 2, "conv8": 3}
+        seen = {sig: n for sig, n in seen.items() if (code[sig[0]], sig[1], sig[2], sig[3], sig[4]) not in have}
         print(f"# {n0} distinct problems, {len(seen)} of them not in gemm2_plans.inc", file=sys.stderr, flush=True)
     print(f"# {len(seen)} distinct problems", file=sys.stderr, flush=True)
     top = int(os.environ.get("TUNE_TOP", "0")) or len(seen)
@@ -173,7 +203,7 @@ def main():
                 k2[c] = sweep(c)
         floor = min(k2.values())
         for c4, twin in ((8, 6), (9, 2), (10, 4), (11, 1)):  # 128-byte k-tiles: only where the twin is in the running
-            if twin in k2 and k2[twin] <= 1.3 * floor and floor < 60.0:
+            if twin in k2 and k2[twin] <= 1.3 * floor and floor < 60.0 and not kind.endswith("8"):  # (bf16 only)
                 sweep(c4)
         if os.environ.get("TUNE_GENERAL", "0") != "0":  # the register-staged 64 x 64 kernel, for the table's comment column
             _hip.set_option("gemm2", 0)
