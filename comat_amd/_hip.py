@@ -38,6 +38,7 @@ class GemmParams(C.Structure):
         ("s_scale_b", C.c_int64),  # ABI 8
         ("A2k", C.c_void_p), ("B2k", C.c_void_p), ("K2", C.c_int64), ("lda2k", C.c_int64), ("ldb2k", C.c_int64),
         ("sA2k", C.c_int64), ("sB2k", C.c_int64),  # bf16 k-tail of an fp8 product (ABI 8)
+        ("q8", C.c_void_p), ("q_scale", C.c_void_p), ("q_amax", C.c_void_p), ("ldq8", C.c_int64),  # GEGLU epilogue -> e4m3 (ABI 8)
     ]
 
 
@@ -274,8 +275,10 @@ class HipKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1),
              sA=(0, 0), sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0,
-             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None):
-        """ktail = (A2 [M, K2], B2 [N, K2], K2, lda2, ldb2, sA2, sB2): bf16 k-tail added to the scaled fp8 product in the same launch;
+             sR=(0, 0), alpha=1.0, beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None, q8=None):
+        """q8 = (bytes [M, N / 2] uint8, scale [1], amax [1] int32): the GEGLU epilogue also emits the e4m3 bytes of its product under
+        `scale` and tracks its abs-max (delayed fp8 scaling); geglu[0] may then be None (no bf16 copy);
+        ktail = (A2 [M, K2], B2 [N, K2], K2, lda2, ldb2, sA2, sB2): bf16 k-tail added to the scaled fp8 product in the same launch;
         scales = (scale_a, scale_b[, s_scale_b]): fp32 device scalars of fp8 (uint8) operands A and B (include/comat_hip.h; batch z of a
         batched product uses scale_b[z * s_scale_b]);
         geglu = (C2 [M, N / 2], keep_pre): the GEGLU epilogue over interleaved value / gate columns (comat_gemm_params::epi2):
@@ -293,8 +296,15 @@ class HipKernels:
             p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 3
             assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous() and Cout.dtype == torch.bfloat16
         elif geglu is not None:
-            p.C2, p.ldc2, p.epi2 = _ptr(geglu[0]), geglu[0].shape[1], 1 if geglu[1] else 2
-            assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous()
+            p.epi2 = 1 if geglu[1] else 2
+            if geglu[0] is not None:
+                p.C2, p.ldc2 = _ptr(geglu[0]), geglu[0].shape[1]
+                assert geglu[0].dtype == torch.bfloat16 and geglu[0].is_contiguous()
+            else:
+                assert q8 is not None
+            if q8 is not None:
+                assert q8[0].dtype == torch.uint8 and q8[0].is_contiguous()
+                p.q8, p.q_scale, p.q_amax, p.ldq8 = _ptr(q8[0]), _ptr(q8[1]), _ptr(q8[2]), q8[0].shape[1]
         p.A, p.B, p.C = _ptr(A), _ptr(B), _ptr(Cout)
         p.bias, p.bias2, p.R = _ptr(bias), _ptr(bias2), _ptr(R)
         if bias is not None:

@@ -714,7 +714,8 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     COMAT_REQUIRE(p->lda >= (p->transA ? p->M : p->K) && p->ldb >= (p->transB ? p->N : p->K) &&
                       p->ldc >= p->N - (p->epi2 == 4 ? p->n2 : 0),  // (tail columns, epi2 = 4: C holds the first N - n2 columns)
                   "comat_gemm: leading dimension too small");
-    COMAT_REQUIRE(p->epi2 == 0 || (p->C2 != nullptr && p->epi2 >= 1 && p->epi2 <= 4), "comat_gemm: bad second epilogue");
+    COMAT_REQUIRE(p->epi2 == 0 || ((p->C2 != nullptr || (p->q8 != nullptr && p->epi2 <= 2)) && p->epi2 >= 1 && p->epi2 <= 4),
+                  "comat_gemm: bad second epilogue");
     if (p->epi2 == 4)
         COMAT_REQUIRE(p->B2 != nullptr && p->n2 > 0 && p->n2 < p->N && p->ldc2 >= p->n2 && !p->transA && !p->transB && p->batch2 == 1,
                       "comat_gemm: tail columns (epi2 = 4) need B2, 0 < n2 < N, ldc2 >= n2, k-contiguous operands, one batch level");
@@ -729,6 +730,7 @@ extern "C" int comat_gemm(const comat_gemm_params* p, void* stream) {
     const int rc2 = comat_gemm2_try_gemm(p, stream);
     comat_note_gemm_kernel(rc2 > 0 ? rc2 : 0);
     if (rc2) return rc2 < 0 ? rc2 : comat_check_launch("comat_gemm");
+    COMAT_REQUIRE(!p->q8, "comat_gemm: the e4m3 output of the GEGLU epilogue (q8) exists on the pipelined kernel only");
     if (p->epi2 == 4) {  // tail columns outside the pipelined kernel: the two products one after the other, same results
         comat_gemm_params q = *p;
         q.epi2 = 0; q.C2 = nullptr; q.B2 = nullptr; q.n2 = 0;

@@ -238,6 +238,8 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
     if (ep.epi2 == 4) ep.C2 = (char*)ep.C2 + z * g.sC2t * (ep.out_dt == COMAT_F32 ? 4 : 2);
     const int64_t nmain = g.N - (ep.epi2 == 4 ? ep.n2 : 0);  // tail columns: [nmain, N) go to C2 (8-column pieces never straddle)
     const bool vec = g.vec != 0;
+    float qinv = 0.f, qmax = 0.f;  // GEGLU epilogue that also emits e4m3 bytes (Epi::q8)
+    if (ep.q8) qinv = 1.0f / *ep.q_scale;
     if constexpr (STG && G2_STAGE) {
         constexpr int RS = WTN + 4;   // floats per staged row: 16 bytes of padding put the 8 rows of a write phase on different banks
         constexpr int CH = WTN / 8;   // 8-column chunks per row
@@ -275,7 +277,7 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                     *(float4*)(v + 8) = *(const float4*)(src + 16);
                     *(float4*)(v + 12) = *(const float4*)(src + 20);
                     const int64_t m = mrow + row, nt = ncol + t * 32;
-                    if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nt + 8 * j, nt, j);
+                    if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nt + 8 * j, nt, j, qinv, qmax);
                 }
             } else {
 #pragma nounroll
@@ -298,6 +300,10 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                     }
                 }
             }
+        }
+        if (ep.q8) {
+            qmax = wave_max(qmax);
+            if (lane == 0) fp8_amax_track(ep.q_amax, qmax);
         }
         return true;
     }
@@ -334,7 +340,7 @@ __device__ __forceinline__ bool g2_finish(f32x16_t (&acc)[TM][TN], const Args2& 
                 else if (nb + 16 < g.N) epilogue_tail(ep, v + 8, m, nb + 16 - nmain);
             }
         } else if (ep.epi2) {  // GEGLU over interleaved value / gate columns (N % 32 == 0: whole tiles only)
-            if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h);
+            if (m < g.M && nt < g.N) epilogue_geglu(ep, v, m, nb, nt, h, qinv, qmax);
         } else if (m < g.M) {
             if (nb < g.N) epilogue_run<WT>(ep, v, m, nb, g.N, vec);
             if (nb + 16 < g.N) epilogue_run<WT>(ep, v + 8, m, nb + 16, g.N, vec);
@@ -1403,6 +1409,9 @@ static void fill_epi(Args2& a, const comat_gemm_params* p) {
     a.ep.out_dt = p->out_dtype; a.ep.r_dt = p->r_dtype;
     a.ep.C2 = p->C2; a.ep.ldc2 = p->ldc2; a.ep.epi2 = p->epi2;
     a.ep.n2 = p->epi2 == 4 ? p->n2 : 0; a.ep.alpha2 = p->alpha2;
+    const bool q = p->q8 && (p->epi2 == 1 || p->epi2 == 2);
+    a.ep.q8 = q ? (unsigned char*)p->q8 : nullptr; a.ep.q_scale = q ? p->q_scale : nullptr;
+    a.ep.q_amax = q ? p->q_amax : nullptr; a.ep.ldq8 = q ? p->ldq8 : 0;
 }
 
 // 16-byte epilogue accesses: 8 columns per lane must stay inside a row and every row start must be 16-byte aligned
@@ -1584,12 +1593,20 @@ int comat_gemm2_try_gemm(const comat_gemm_params* p, void* stream) {
     } else if (p->epi2 == 3) {  // GEGLU backward epilogue: C, C2 [M, 2 N] bf16 with 16-byte rows, nothing else fused
         if (p->out_dtype != COMAT_BF16 || p->N % 16 || p->R || p->bias || p->bias2 || p->act != COMAT_ACT_NONE || p->batch1 > 1 || !p->C ||
             !p->C2 || !al16(p->C) || !al16(p->C2) || p->ldc % 8 || p->ldc2 % 8 || p->ldc < 2 * p->N || p->ldc2 < 2 * p->N)
-            return -1;
+            return 0;  // declined: comat_gemm runs the two-launch form, which states its own requirements
     } else if (p->epi2) {  // GEGLU epilogue: bf16 output, 16-byte rows, whole 32-column tiles, nothing else fused
         if ((p->epi2 != 1 && p->epi2 != 2) || p->out_dtype != COMAT_BF16 || p->N % 32 || p->R || p->bias2 || p->act != COMAT_ACT_NONE ||
-            p->batch1 > 1 || !p->C2 || !al16(p->C2) || p->ldc2 % 8 || p->ldc2 < p->N / 2 || (p->bias && !al16(p->bias)))
+            p->batch1 > 1 || (!p->C2 && !p->q8) || !al16(p->C2) || p->ldc2 % 8 || (p->C2 && p->ldc2 < p->N / 2) || (p->bias && !al16(p->bias)) ||
+            (p->epi2 == 1 && (!al16(p->C) || p->ldc % 8))) {
+            if (!fp8 && !p->q8) return 0;  // declined: the two-launch form of comat_gemm takes over
+            comat_set_error("comat_gemm: GEGLU epilogue with fp8 operands / e4m3 output: bf16 output, N %% 32 == 0, 16-byte aligned rows, "
+                            "no residual / bias2 / activation / batch (no second kernel behind this path)");
             return -1;
-        if (p->epi2 == 1 && (!al16(p->C) || p->ldc % 8)) return -1;
+        }
+        if (p->q8 && (!p->q_scale || !p->q_amax || (((uintptr_t)p->q8) & 7) || p->ldq8 % 8 || p->ldq8 < p->N / 2)) {
+            comat_set_error("comat_gemm: q8 needs q_scale, q_amax, 8-byte aligned rows and ldq8 >= N / 2");
+            return -1;
+        }
     }
     return finish_launch(a, false, fp8, p->batch1, p->ws, p->ws_bytes, stream);
 }

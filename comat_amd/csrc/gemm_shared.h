@@ -20,6 +20,12 @@ struct Epi {
     // epi2 == 4 (tail columns): the last n2 columns of the product go to C2 as alpha2 * product
     int64_t n2;
     float alpha2;
+    // GEGLU epilogues under the fp8 forward with delayed scaling (comat_gemm_params::q8): the e4m3 bytes of value * gelu(gate) for the
+    // layer that consumes it, its abs-max folded into that site's running maximum; C2 (the bf16 copy) may then be NULL
+    unsigned char* q8;
+    const float* q_scale;
+    unsigned* q_amax;
+    int64_t ldq8;
 };
 
 // XCD-aware workgroup -> work-item map.  Workgroup b is dispatched to XCD b % 8 (MI355X: 8 XCDs, a private 4 MiB L2
@@ -187,7 +193,8 @@ __device__ __forceinline__ void epilogue_tail(const Epi& ep, const float* v, int
 // 32-column tile.  out = value * gelu(gate) for 8 channels -> ONE 16-byte store into C2 [M, N / 2]; with epi2 == 1 the
 // pre-activations are stored too (C, same layout as without the fusion: the backward pass reads them).  Both halves are
 // rounded to the storage type BEFORE the product, exactly what the unfused pair of kernels computes.
-__device__ __forceinline__ void epilogue_geglu(const Epi& ep, const float* v, int64_t m, int64_t nb, int64_t nt, int h) {
+__device__ __forceinline__ void epilogue_geglu(const Epi& ep, const float* v, int64_t m, int64_t nb, int64_t nt, int h, float qinv,
+                                               float& qmax) {
     float a[8], g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -211,7 +218,16 @@ __device__ __forceinline__ void epilogue_geglu(const Epi& ep, const float* v, in
         *(uint4*)((bf16_t*)ep.C + m * ep.ldc + nb) = pa.u;
         *(uint4*)((bf16_t*)ep.C + m * ep.ldc + nb + 16) = pg.u;
     }
-    *(uint4*)((bf16_t*)ep.C2 + m * ep.ldc2 + (nt >> 1) + 8 * h) = po.u;
+    if (ep.C2) *(uint4*)((bf16_t*)ep.C2 + m * ep.ldc2 + (nt >> 1) + 8 * h) = po.u;
+    if (ep.q8) {  // the bytes comat_fp8_quantize_scaled would make of the stored (rounded) product
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            r[e] = bf16_to_f32(po.h[e]);
+            qmax = fmaxf(qmax, fabsf(r[e]));
+        }
+        *(uint2*)(ep.q8 + m * ep.ldq8 + (nt >> 1) + 8 * h) = fp8_pack8(r, qinv);
+    }
 }
 
 // GEGLU BACKWARD epilogue (epi2 == 3): `v` = 8 consecutive columns d .. d + 7 of row m of the product dF = g W2 (the gradient of the

@@ -381,6 +381,8 @@ def fp8_weight_group(lins):
 # COMAT_FP8_KTAIL (default 1): the LoRA up projection of a frozen projection rides in the fp8 product's launch as a bf16 k-tail
 # (comat_gemm_params::A2k); 0 = its own launch behind it (rounds 2-5), for A/B runs
 _fp8_ktail = os.environ.get("COMAT_FP8_KTAIL", "1") != "0"
+# COMAT_FP8_GEGLU_Q8 (default 1): `ff.net.0.proj` + GEGLU emits the e4m3 bytes for `ff.net.2` from its epilogue (comat_gemm_params::q8)
+_fp8_geglu_q8 = os.environ.get("COMAT_FP8_GEGLU_Q8", "1") != "0"
 _FP8_MAX_SITES = 4096
 _fp8_scaling = os.environ.get("COMAT_FP8_SCALING", "jit")
 _fp8_calibrating = False
@@ -926,27 +928,36 @@ def set_geglu_fused(flag: bool):
     _geglu_fused = bool(flag)
 
 
-def _geglu_linear_fwd(x, lin, need_pre):
-    """(GEGLU(x W^T + b), pre-activations or None): ONE launch (the product leaves the GEMM epilogue; the pre-activations are
+def _geglu_linear_fwd(x, lin, need_pre, fp8_for=None):
+    """(GEGLU(x W^T + b), pre-activations or None, None): ONE launch (the product leaves the GEMM epilogue; the pre-activations are
     stored only when a backward pass will read them) where the library's pipelined kernel takes the problem, else the GEMM and
-    the interleaved-layout GEGLU kernel."""
+    the interleaved-layout GEGLU kernel.
+    fp8_for: the frozen layer that consumes the result.  Under the fp8 forward with delayed scaling the epilogue writes the e4m3
+    bytes that layer multiplies INSTEAD of the bf16 product (comat_gemm_params::q8): -> (None, pre, (bytes, scale))."""
     M, Kd = x.shape
     D, N2 = lin.out_features, lin.pre_features
     k = kernels()
-    y = x.new_empty((M, D))
     if _use_fp8(lin, Kd):
         a, (w, sw) = fp8_act(x, lin), fp8_weight(lin)
         a, scales = a[0], (a[1], sw)
     else:
         a, w, scales = x, lin.w, None
-    if _geglu_fused and y.dtype == torch.bfloat16 and k.geglu_gemm_ok(a, w, M, N2, Kd):
+    fused = _geglu_fused and x.dtype == torch.bfloat16 and k.geglu_gemm_ok(a, w, M, N2, Kd)
+    site = _fp8_producer_site(fp8_for, D, x.device) if (fused and scales is not None and _fp8_geglu_q8) else None
+    if site is not None:
+        pre = x.new_empty((M, N2)) if need_pre else None
+        q8 = torch.empty((M, D), dtype=torch.uint8, device=x.device)
+        k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales, geglu=(None, need_pre), q8=(q8, site[0], site[1]))
+        return None, pre, (q8, site[0])
+    y = x.new_empty((M, D))
+    if fused:
         pre = x.new_empty((M, N2)) if need_pre else None
         k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales, geglu=(y, need_pre))
     else:
         pre = x.new_empty((M, N2))
         k.gemm(a, w, pre, M, N2, Kd, Kd, Kd, N2, bias=lin.bias, scales=scales)
         k.geglu_il_fwd(pre, y, M, D)
-    return y, (pre if need_pre else None)
+    return y, (pre if need_pre else None), None
 
 
 class _GegluLinear(Function):
@@ -955,7 +966,7 @@ class _GegluLinear(Function):
     @staticmethod
     def forward(ctx, x, lin):
         x = _c(x)
-        y, pre = _geglu_linear_fwd(x, lin, ctx.needs_input_grad[0])
+        y, pre, _ = _geglu_linear_fwd(x, lin, ctx.needs_input_grad[0])
         ctx.lin = lin
         if pre is not None:
             ctx.save_for_backward(pre)
@@ -986,15 +997,15 @@ class _GegluFeedForward(Function):
     def forward(ctx, x, residual, ff1, ff2):
         x = _c(x)
         need = ctx.needs_input_grad[0]
-        f, pre = _geglu_linear_fwd(x, ff1, need)
-        M, D = f.shape
+        f, pre, f8q = _geglu_linear_fwd(x, ff1, need, fp8_for=ff2)  # (fp8 forward, delayed scales: e4m3 bytes instead of f)
+        M, D = x.shape[0], ff1.out_features
         N = ff2.out_features
         y = x.new_empty((M, N))
         k = kernels()
         residual = _c(residual) if residual is not None else None
         beta = 1.0 if residual is not None else 0.0
         if _use_fp8(ff2, D):
-            f8, sf = fp8_act(f, ff2)
+            f8, sf = f8q if f8q is not None else fp8_act(f, ff2)
             w8, sw = fp8_weight(ff2)
             k.gemm(f8, w8, y, M, N, D, D, D, N, bias=ff2.bias, R=residual, ldr=N, beta=beta, scales=(sf, sw))
         else:

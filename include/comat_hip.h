@@ -123,6 +123,14 @@ typedef struct {
     const void* A2k;
     const void* B2k;
     int64_t K2, lda2k, ldb2k, sA2k, sB2k;
+    /* ABI 8, epi2 = 1 / 2 on the pipelined kernel only (else COMAT_EINVAL): the GEGLU epilogue ALSO emits q8 [M, N / 2] (leading
+     * dimension ldq8) = the e4m3 bytes of value * gelu(gate) under *q_scale, and folds its abs-max into *q_amax - what
+     * comat_fp8_quantize_scaled would make of C2, for the `ff.net.2` product that consumes it (delayed scaling, see the fp8 section).
+     * With q8 given C2 may be NULL: the bf16 copy is then never written. */
+    void* q8;
+    const float* q_scale;
+    uint32_t* q_amax;
+    int64_t ldq8;
 } comat_gemm_params;
 int comat_gemm(const comat_gemm_params* p, void* stream);
 
@@ -134,7 +142,9 @@ int comat_gemm(const comat_gemm_params* p, void* stream);
  *   [COMAT_WS_COUNTER_BYTES, ws_bytes)  fp32 partial tiles.
  * One workspace serves any number of calls on ONE stream; calls that may overlap (different streams) need a
  * workspace each.  comat_gemm_workspace_bytes() returns the size that lets a problem use its full planned split (a
- * smaller buffer only lowers the split count). */
+ * smaller buffer only lowers the split count).  It does NOT include the scratch of the two-launch forms of the second epilogue
+ * (epi2 = 2 or 3 on a problem the pipelined kernel declines: M * N * 2 bytes behind the counters, see comat_gemm_params::epi2):
+ * a caller that relies on those forms adds it. */
 #define COMAT_WS_COUNTER_BYTES (256 * 1024)
 int64_t comat_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int64_t batch, int32_t in_dtype);
 

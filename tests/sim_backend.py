@@ -41,7 +41,7 @@ class SimKernels:
     # ---- contraction ---------------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, batch=(1, 1), sA=(0, 0),
              sB=(0, 0), sC=(0, 0), bias=None, bias2=None, rows_per_bias2=0, R=None, ldr=0, sR=(0, 0), alpha=1.0,
-             beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None):
+             beta=0.0, act=ACT_NONE, scales=None, geglu=None, tail=None, ktail=None, q8=None):
         b1, b2 = batch
         if tail is not None:  # comat_gemm_params::epi2 = 4: the last n2 columns are alpha2 * A B2^T into C2, the rest as usual
             B2, C2t, n2, ldc2, sB2t, sC2t, alpha2 = tail
@@ -81,11 +81,16 @@ class SimKernels:
         if geglu is not None:  # comat_gemm_params::epi2: value / gate columns interleaved in sixteens, both rounded first
             y, keep = geglu
             assert b1 == b2 == 1 and N % 32 == 0 and R is None and act == ACT_NONE and bias2 is None
-            pre = acc.reshape(M, N).to(y.dtype)
+            assert y is not None or q8 is not None
+            pre = acc.reshape(M, N).to(torch.bfloat16 if y is None else y.dtype)
             if keep:
                 _v(Cout, (M, N), (ldc, 1)).copy_(pre)
             t = pre.float().reshape(M, N // 32, 2, 16)
-            y.copy_((t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, N // 2).to(y.dtype))
+            out = (t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, N // 2).to(pre.dtype)
+            if y is not None:
+                y.copy_(out)
+            if q8 is not None:  # comat_gemm_params::q8: the e4m3 bytes of the rounded product + its abs-max
+                self._quantize_scaled(out, q8[1], q8[2], out=q8[0])
             return
         _v(Cout, (b1, b2, M, N), (sC[0], sC[1], ldc, 1)).copy_(acc.to(Cout.dtype))
 

@@ -33,8 +33,8 @@ def test_struct_layouts_match_header():
     from comat_amd import _hip
     # 6 pointers + 18 int64 + 2 float + 6 int32 + pointer + int64 + 2 scale pointers (ABI 3)
     # ABI 5: + C2, ldc2, epi2 (+ 4 bytes of padding); ABI 7: + B2, n2, sB2_tail, sC2_tail, alpha2 (+ 4 bytes of padding)
-    # ABI 8: + s_scale_b, + A2k, B2k, K2, lda2k, ldb2k, sA2k, sB2k
-    assert C.sizeof(_hip.GemmParams) == 6 * 8 + 18 * 8 + 2 * 4 + 6 * 4 + 8 + 8 + 2 * 8 + 8 + 8 + 8 + 4 * 8 + 8 + 8 + 7 * 8
+    # ABI 8: + s_scale_b, + A2k, B2k, K2, lda2k, ldb2k, sA2k, sB2k, + q8, q_scale, q_amax, ldq8
+    assert C.sizeof(_hip.GemmParams) == 6 * 8 + 18 * 8 + 2 * 4 + 6 * 4 + 8 + 8 + 2 * 8 + 8 + 8 + 8 + 4 * 8 + 8 + 8 + 7 * 8 + 4 * 8
     assert C.sizeof(_hip.TTProblem) == 3 * 8 + 6 * 8  # comat_tt_problem (ABI 4)
     assert C.sizeof(_hip.ConvParams) == 6 * 8 + 13 * 4 + 2 * 4 + 4 * 4 + 4 + 8 + 8 + 2 * 8  # incl. 4 bytes of padding
 

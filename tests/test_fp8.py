@@ -624,3 +624,48 @@ def test_fp8_batched_gemm_with_per_batch_weight_scales_and_k_tail(dev):
     k.gemm(x8, w8, ys, M, N, K, K, K, N, batch=(G, 1), sB=(N * K, 0), sC=(M * N, 0), scales=(sxd, sc, 1),
            ktail=(h.to(dev), us.to(dev), r, G * r, r, r, N * r))
     assert rel_l2(ys, ref) < 6e-3, rel_l2(ys, ref)
+
+
+@pytest.mark.parametrize("need_grad", [False, True])
+def test_geglu_epilogue_emits_the_bytes_its_consumer_multiplies(dev, delayed, need_grad):
+    """comat_gemm_params::q8 (ABI 8): under the fp8 forward with delayed scaling `ff.net.0.proj` + GEGLU writes the e4m3 bytes of its
+    product for `ff.net.2` instead of the bf16 product - the same bits as the two-step form (bf16 product, comat_fp8_quantize_scaled),
+    one launch and one [M, D] round trip less; the site's running maximum sees the same abs-max"""
+    T = torch.bfloat16
+    M, Kd, D, N = 200, 128, 256, 128
+    ff1 = _tagged(ops.FrozenGegluLinear(rnd(2 * D, Kd, seed=1) * 0.1, rnd(2 * D, seed=2) * 0.1, T, dev))
+    ff2 = _tagged(ops.FrozenLinear(rnd(N, D, seed=3) * 0.1, rnd(N, seed=4) * 0.1, T, dev))
+    x = rnd(M, Kd, seed=5).to(T).to(dev)
+    k = ops.kernels()
+    n_scaled = [0]
+    orig = k.fp8_quantize_scaled
+
+    def counted(*a, **kw):
+        n_scaled[0] += 1
+        return orig(*a, **kw)
+    k.fp8_quantize_scaled = counted
+    try:
+        with ops.fp8_forward(True):
+            with torch.no_grad(), ops.fp8_calibration():
+                ops.geglu_feed_forward(x, ff1, ff2)
+            ops.fp8_end_of_step()
+            outs, maxima = [], []
+            for fused in (True, False):
+                ops.set_geglu_fused(fused)
+                xin = x.clone().requires_grad_(need_grad)
+                n_scaled[0] = 0
+                with torch.set_grad_enabled(need_grad):
+                    y = ops.geglu_feed_forward(xin, ff1, ff2)
+                outs.append((y.detach().clone(), n_scaled[0]))
+                maxima.append(int(ff2._fp8_site[1].cpu()))
+                if need_grad:
+                    y.backward(torch.ones_like(y))
+                    outs[-1] += (xin.grad.clone(),)
+                ops.fp8_end_of_step()
+    finally:
+        ops.set_geglu_fused(True)
+        k.fp8_quantize_scaled = orig
+    assert torch.equal(outs[0][0], outs[1][0]) and maxima[0] == maxima[1] and maxima[0] != 0
+    assert outs[0][1] == 1 and outs[1][1] == 2  # fused: only x is quantised by a launch of its own
+    if need_grad:
+        assert torch.equal(outs[0][2], outs[1][2])
