@@ -227,7 +227,7 @@ static bool gn_try_one(const void* x, const void* dy, const float* gamma, const 
     // The backward form holds two tensors per thread and gains less: 16x16 x 1 280 channels 13.8 -> 16.6 us (a loss), x 2 560
     // 21.4 -> 14.4 us, 8x8 13.5 -> 7.4 us - it serves HW <= 64, and HW <= 256 from 1 920 channels on.
     const bool pays = MODE == 0 ? HW <= 256 : (HW <= 64 || (HW <= 256 && C >= 1920));
-    if (!must && (comat_option(COMAT_OPT_NORM_FUSED) != 3 || !pays)) return false;
+    if (!must && ((comat_option(COMAT_OPT_NORM_FUSED) != 3 && comat_option(COMAT_OPT_NORM_FUSED) != 4) || !pays)) return false;
     const int cpg = C / G;
     if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
     if (dtype == COMAT_F32) {
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
     constexpr int EPV = 16 / sizeof(T);
     // per-(row lane, channel) partial sums: reduced in a FIXED order below, so the block result is deterministic
     // (LDS float atomics from many waves made run-to-run results differ in the last bf16 bit of a few outputs)
-    __shared__ float p_a[4096], p_b[4096];
+    __shared__ __attribute__((aligned(16))) float p_a[4096], p_b[4096];
     const int b = blockIdx.y;
     const int VPR = C / EPV;
     const int R = VPR >= NT ? 1 : NT / VPR;  // rows processed in parallel
@@ -340,28 +340,53 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
     // same fixed order as gn_reduce(_finalize)_kernel (lane l takes slabs l, l+64, ..., then a fixed butterfly), so the
     // statistics stay bit-reproducible and identical to the three-launch form.
     if (!splitk_ticket_is_last(tickets + b, (int)gridDim.x, (unsigned*)p_a)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nblk = gridDim.x;
-    const int64_t n = (int64_t)gridDim.y * G * 2;
-    for (int g2 = wave; g2 < G; g2 += NT / 64) {
-        const int64_t i = (int64_t)b * G + g2;
+    // Round 6: the last arriver's reads are ONE burst of independent 16-byte sc1 buffer loads (a (s1, s2) pair each), not a chain of
+    // dependent atomic loads (round 5: every one of them waited out a full memory round trip - the two-launch form measured 26.8 us
+    // against 14.1 for three launches).  Thread t owns group t % G and takes slabs t / G, t / G + S, ... (S = 256 / G); the S
+    // partial sums of a group are then added in slab-lane order through LDS: a fixed order, bit-reproducible.
+    {
+        const int nblk = gridDim.x;
+        const int64_t n = (int64_t)gridDim.y * G * 2;  // doubles per slab
+        const int S = NT / G, g2 = threadIdx.x % G, sl = threadIdx.x / G;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ws, 0, 0x7ffffff0, 0x00020000);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         double s1 = 0.0, s2 = 0.0;
-        for (int k = lane; k < nblk; k += 64) {  // sc1 loads: the partials come from other workgroups of this launch
-            s1 += __hip_atomic_load(ws + (int64_t)(1 + k) * n + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s2 += __hip_atomic_load(ws + (int64_t)(1 + k) * n + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sl < S) {
+            const int64_t off0 = ((int64_t)b * G + g2) * 16;  // byte offset of the group's pair inside a slab
+#pragma unroll 4
+            for (int k = sl; k < nblk; k += S) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((int64_t)(1 + k) * n * 8 + off0), 0, /*sc1*/ 16);
+                double d0, d1;
+                const unsigned lo[2] = {v[0], v[1]}, hi[2] = {v[2], v[3]};
+                __builtin_memcpy(&d0, lo, 8);
+                __builtin_memcpy(&d1, hi, 8);
+                s1 += d0;
+                s2 += d1;
+            }
         }
-        s1 = wave_sum_f64(s1);
-        s2 = wave_sum_f64(s2);
-        if (lane == 0) {
+        double* red = (double*)p_b;  // [S][G][2] doubles <= 4 KiB of the 16 KiB array (p_a holds the ticket flag)
+        __syncthreads();
+        if (sl < S) {
+            red[(sl * G + g2) * 2] = s1;
+            red[(sl * G + g2) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x < G) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int q = 0; q < S; ++q) {
+                t1 += red[(q * G + threadIdx.x) * 2];
+                t2 += red[(q * G + threadIdx.x) * 2 + 1];
+            }
+            const int64_t i = (int64_t)b * G + threadIdx.x;
             if (MODE == 0) {
-                const double mean = s1 / count;
-                double var = s2 / count - mean * mean;
+                const double mean = t1 / count;
+                double var = t2 / count - mean * mean;
                 if (var < 0) var = 0;
                 stats_out[2 * i] = (float)mean;
                 stats_out[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
             } else {
-                ws[2 * i] = s1;
-                ws[2 * i + 1] = s2;
+                ws[2 * i] = t1;
+                ws[2 * i + 1] = t2;
             }
         }
     }
@@ -565,7 +590,11 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
 
 // workspace: [GN_TICKETS uint32 ticket counters (zeroed once by the caller, re-armed by the kernels) | doubles]
 constexpr int GN_TICKETS = 1024;
-static inline bool gn_two_launch(int B) { return comat_option(COMAT_OPT_NORM_FUSED) == 1 && B <= GN_TICKETS; }
+// (4 = the one-launch form where it pays, the two-launch ticket form elsewhere)
+static inline bool gn_two_launch(int B) {
+    const int o = comat_option(COMAT_OPT_NORM_FUSED);
+    return (o == 1 || o == 4) && B <= GN_TICKETS;
+}
 // norm_fused = 2: the apply kernel finalises (gn_vapply2_kernel<.., FIN>); needs whole waves of 8-lane groups
 static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_FUSED) == 2 && G % 8 == 0 && G <= 32; }
 
@@ -870,7 +899,8 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
 // 1 when comat_groupnorm_fwd_q takes the shape: the vectorised three-launch form, i.e. not the shapes the one-launch form serves
 extern "C" int comat_groupnorm_fwd_q_ok(int32_t B, int64_t HW, int32_t C, int32_t G, int32_t dtype) {
     if (!dtype_ok(dtype) || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || G > MAX_G || B > 65535) return 0;
-    if (comat_option(COMAT_OPT_NORM_FUSED) == 3 && HW <= 256 && C / G <= GN_ONE_MAXCPG) return 0;  // gn_try_one<0> "pays"
+    if ((comat_option(COMAT_OPT_NORM_FUSED) == 3 || comat_option(COMAT_OPT_NORM_FUSED) == 4) && HW <= 256 && C / G <= GN_ONE_MAXCPG)
+        return 0;  // gn_try_one<0> "pays"
     return gn_vec_ok(nullptr, nullptr, C, dtype, HW) ? 1 : 0;
 }
 
