@@ -1314,6 +1314,9 @@ template <typename T> __global__ __launch_bounds__(NT) void flash_kv_reduce_kern
     const int bh = (int)(i / ((int64_t)a.d * a.Nk));
     const int b = bh / a.H, h = bh % a.H;
     float sk = 0.f, sv = 0.f;
+    // (unrolled: eight ranges' loads are in flight before the first add - the sums still run in range order, same bits; as a
+    // rolled loop every iteration waited out its own memory round trip, up to 64 of them)
+#pragma unroll 8
     for (int z = 0; z < a.qsplit; ++z) {
         sk += a.part[(int64_t)z * slab + i];
         sv += a.part[((int64_t)a.qsplit + z) * slab + i];

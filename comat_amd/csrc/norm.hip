@@ -254,6 +254,7 @@ template <typename T> __device__ __forceinline__ void gv_set(GV16& v, int e, flo
 }
 
 constexpr int VSLOTS = 2;  // channel vectors per thread: C <= 256 * 2 * EPV
+constexpr int GN_TG = 16;   // blocks per first-level ticket counter of the two-launch form
 
 // MODE 0: sum x, sum x^2.   MODE 1 (backward): s1 = sum gy*gamma, s2 = sum gy*gamma*xhat
 template <typename T, int MODE>
@@ -339,7 +340,15 @@ __global__ __launch_bounds__(NT) void gn_vstats_kernel(const T* __restrict__ x, 
     // Two-launch form: the LAST block of this sample to arrive combines the per-block partials of its G groups, in the
     // same fixed order as gn_reduce(_finalize)_kernel (lane l takes slabs l, l+64, ..., then a fixed butterfly), so the
     // statistics stay bit-reproducible and identical to the three-launch form.
-    if (!splitk_ticket_is_last(tickets + b, (int)gridDim.x, (unsigned*)p_a)) return;
+    // Two ticket levels (round 6): a memory-side atomic on ONE address serialises at ~20 ns per arrival - 512 blocks of a sample on one
+    // counter cost the last of them ~11 us (measured: the form lost to three launches by exactly that, growing with the block
+    // count).  Groups of GN_TG blocks share a first-level counter; the last of each group takes the sample's second-level ticket.
+    {
+        const int nblk = gridDim.x, ngrp = (nblk + GN_TG - 1) / GN_TG, grp = blockIdx.x / GN_TG;
+        const int in_grp = min(GN_TG, nblk - grp * GN_TG);
+        if (!splitk_ticket_is_last(tickets + gridDim.y + b * ngrp + grp, in_grp, (unsigned*)p_a)) return;
+        if (!splitk_ticket_is_last(tickets + b, ngrp, (unsigned*)p_a)) return;
+    }
     // Round 6: the last arriver's reads are ONE burst of independent 16-byte sc1 buffer loads (a (s1, s2) pair each), not a chain of
     // dependent atomic loads (round 5: every one of them waited out a full memory round trip - the two-launch form measured 26.8 us
     // against 14.1 for three launches).  Thread t owns group t % G and takes slabs t / G, t / G + S, ... (S = 256 / G); the S
@@ -590,10 +599,11 @@ static inline int gn_rows_per_block(int B, int64_t HW, int C, int epv) {
 
 // workspace: [GN_TICKETS uint32 ticket counters (zeroed once by the caller, re-armed by the kernels) | doubles]
 constexpr int GN_TICKETS = 1024;
-// (4 = the one-launch form where it pays, the two-launch ticket form elsewhere)
-static inline bool gn_two_launch(int B) {
+// (4 = the one-launch form where it pays, the two-launch ticket form elsewhere; its counters: B second-level + B * ceil(nblk / GN_TG)
+// first-level ones - a call that needs more takes the three-launch form)
+static inline bool gn_two_launch(int B, int nblk) {
     const int o = comat_option(COMAT_OPT_NORM_FUSED);
-    return (o == 1 || o == 4) && B <= GN_TICKETS;
+    return (o == 1 || o == 4) && (int64_t)B * (1 + (nblk + GN_TG - 1) / GN_TG) <= GN_TICKETS;
 }
 // norm_fused = 2: the apply kernel finalises (gn_vapply2_kernel<.., FIN>); needs whole waves of 8-lane groups
 static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_FUSED) == 2 && G % 8 == 0 && G <= 32; }
@@ -608,7 +618,7 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
-    const bool fused = !fin && gn_two_launch(B);
+    const bool fused = !fin && gn_two_launch(B, (int)sg.x);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 0>), sg, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                        (const float*)nullptr, ws, (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, stats,
                        (double)HW * (C / G), eps);
@@ -643,7 +653,7 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
-    const bool fused = !fin && gn_two_launch(B);
+    const bool fused = !fin && gn_two_launch(B, (int)sg.x);
     hipLaunchKernelGGL((gn_vstats_kernel<T, 1>), sg, dim3(NT), 0, st, (const T*)x, (const T*)dy, gamma, beta, stats, ws,
                        (int)HW, C, G, silu, rpb, fused ? tickets : (unsigned*)nullptr, (float*)nullptr, 0.0, 0.0f);
     if (!fused && !fin) hipLaunchKernelGGL(gn_reduce_kernel, dim3(B * G * 2), dim3(64), 0, st, ws, (int)sg.x, B * G * 2);
