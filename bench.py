@@ -130,9 +130,11 @@ class CallRecorder:
             return f"tt_grouped n={len(a[0])} " + " ".join(f"{m}x{n}x{k}*{c}" for (m, n, k), c in sorted(shapes.items()))
         if name == "gemm":
             out = a[2] if a[2] is not None else kw["geglu"][0]  # fused GEGLU without stored pre-activations: C is absent
+            odt = out.dtype if out is not None else "e4m3"   # ... and with the e4m3 output only (q8) there is no bf16 product either
             return (f"gemm M={a[3]} N={a[4]} K={a[5]} ld={a[6]},{a[7]},{a[8]} tA={int(kw.get('transA', False))} "
-                    f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={out.dtype} "
-                    + cls._epi(kw) + (f" geglu={1 if kw['geglu'][1] else 2}" if kw.get("geglu") is not None else ""))
+                    f"tB={int(kw.get('transB', False))} b={kw.get('batch', (1, 1))} in={a[0].dtype} out={odt} "
+                    + cls._epi(kw) + (f" geglu={1 if kw['geglu'][1] else 2}" if kw.get("geglu") is not None else "")
+                    + (" q8" if kw.get("q8") is not None else "") + (f" ktail={kw['ktail'][2]}" if kw.get("ktail") is not None else ""))
         if name == "gemm_segments":
             return (f"gemm_segments M={a[2]} N={a[3]} K={'+'.join(str(sg[2]) for sg in a[0])} b={kw.get('batch', 1)} "
                     f"in={a[0][0][0].dtype} out={a[1].dtype} " + cls._epi(kw))
@@ -150,7 +152,7 @@ class CallRecorder:
         if name == "gemm":
             M, N, K = a[3], a[4], a[5]
             b = kw.get("batch", (1, 1))
-            return 2.0 * M * N * K * b[0] * b[1]
+            return 2.0 * M * N * (K + (kw["ktail"][2] if kw.get("ktail") is not None else 0)) * b[0] * b[1]
         if name == "gemm_segments":
             return 2.0 * a[2] * a[3] * sum(sg[2] for sg in a[0]) * kw.get("batch", 1)
         if name == "conv2d":
@@ -174,8 +176,13 @@ class CallRecorder:
             r = M * N * sz(kw["R"]) if kw.get("R") is not None else 0
             if kw.get("geglu") is not None:  # + the [M, N / 2] product; the pre-activations only when they are stored
                 y, keep = kw["geglu"]
-                return (M * K + N * K) * sz(a[0]) + (M * N * sz(y) if keep else 0) + M * (N // 2) * sz(y)
-            return nb * ((M * K + N * K) * sz(a[0]) + M * N * sz(a[2]) + r)
+                if isinstance(y, str) or y is None:  # "bwd" form: (pre, "bwd") / e4m3 output only (q8): no bf16 product is written
+                    y = None
+                out = (M * (N // 2) * sz(y) if y is not None else 0) + (M * (N // 2) if kw.get("q8") is not None else 0)
+                return (M * K + N * K) * sz(a[0]) + (M * N * 2 if keep else 0) + out
+            kt = kw.get("ktail")  # bf16 k-tail of an fp8 product: its two operands once
+            tail = (M + N) * kt[2] * 2 * nb if kt is not None else 0
+            return nb * ((M * K + N * K) * sz(a[0]) + M * N * sz(a[2]) + r) + tail
         if name == "gemm_segments":
             M, N, nb = a[2], a[3], kw.get("batch", 1)
             r = M * N * sz(kw["R"]) if kw.get("R") is not None else 0
@@ -539,29 +546,31 @@ def secondary_c3(trainer, batch, rank, sync, steps=3):
             "gpu_ms_per_step_by_piece": phases}
 
 
-def secondary_c4_own_process(timeout_s=400):
-    """C4 measured the way a training job would run it - in a process of its own (`bench.py --config c4`), started from the
+def secondary_c4_own_process(timeout_s=400, config="c4", steps=4):
+    """(config = "c5", round 6: the SDXL 1024^2 fp8-forward step the same way, two timed steps.)
+    C4 measured the way a training job would run it - in a process of its own (`bench.py --config c4`), started from the
     default line.  Inside the process that already holds the C2 and C3 worlds, their graphs and ~100 GB of allocations the same
     step measured 12 - 19 % slower on every box (1 035 - 1 081 ms against 911 - 938: the segment replays themselves 3 - 6 %
     slower, the eager glue between them twice as slow; profiles/r04_w_c4_in_process.txt) - a property of this benchmark
     process, not of the step.  COMAT_SECONDARY_C4=inproc keeps the old form."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", "c4", "--no-cpu-baseline", "--no-kernel-timing",
-           "--steps", "4", "--warmup", "1"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config, "--no-cpu-baseline", "--no-kernel-timing",
+           "--steps", str(steps), "--warmup", "1"]
     t0 = time.time()
     env = dict(os.environ, COMAT_SECONDARY="0")
     env.pop("COMAT_BENCH_DUMP", None)  # the parent's per-problem dump is the parent's
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
     line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{") and '"metric"' in l), None)
     if r.returncode != 0 or line is None:
-        raise RuntimeError(f"bench.py --config c4 exited with {r.returncode}: {r.stderr[-300:]}")
+        raise RuntimeError(f"bench.py --config {config} exited with {r.returncode}: {r.stderr[-300:]}")
     d = json.loads(line)
     c = d["config"]
     return {"workload": c["workload"], "ms_per_step": round(d["ms_per_step"], 1), "images_per_sec": round(d["value"], 3),
             "steps": d["steps"], "warmup": d["warmup"], "build_s": c.get("build_s"), "wall_s": round(time.time() - t0, 1),
             "host_enqueue_ms_per_step": c.get("host_enqueue_ms_per_step"), "launch_mode": c.get("launch_mode"),
-            "how": "`python bench.py --config c4 --no-cpu-baseline --no-kernel-timing --steps 4 --warmup 1` in a process of its "
-                   "own, started by the default line (the C2 / C3 worlds of the parent stay allocated and idle meanwhile)"}
+            "dtype": d.get("dtype"),
+            "how": f"`python bench.py --config {config} --no-cpu-baseline --no-kernel-timing --steps {steps} --warmup 1` in a process of "
+                   "its own, started by the default line (the C2 / C3 worlds of the parent stay allocated and idle meanwhile)"}
 
 
 def secondary_c2_bs4_own_process(bs=4, timeout_s=300):
@@ -970,6 +979,15 @@ def main():
                     secondary["c2_bs4"] = secondary_c2_bs4_own_process()
                 except Exception as e:  # noqa: BLE001
                     secondary["c2_bs4"] = {"error": f"{type(e).__name__}: {e}"}
+        if os.environ.get("COMAT_SECONDARY_C5", "1") != "0":  # BASELINE.json configs[4]: SDXL 1024^2, fp8 forward (delayed scales)
+            if time.time() - T_PROCESS > 480:
+                secondary["c5"] = {"skipped": "the run had used more than 480 s before the SDXL 1024^2 measurement"}
+            else:
+                stage("secondary c5")
+                try:
+                    secondary["c5"] = secondary_c4_own_process(timeout_s=400, config="c5", steps=2)
+                except Exception as e:  # noqa: BLE001
+                    secondary["c5"] = {"error": f"{type(e).__name__}: {e}"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config not in ("c4", "c5") and not args.selftest:
         stage("cpu baseline")

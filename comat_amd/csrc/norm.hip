@@ -227,7 +227,8 @@ static bool gn_try_one(const void* x, const void* dy, const float* gamma, const 
     // The backward form holds two tensors per thread and gains less: 16x16 x 1 280 channels 13.8 -> 16.6 us (a loss), x 2 560
     // 21.4 -> 14.4 us, 8x8 13.5 -> 7.4 us - it serves HW <= 64, and HW <= 256 from 1 920 channels on.
     const bool pays = MODE == 0 ? HW <= 256 : (HW <= 64 || (HW <= 256 && C >= 1920));
-    if (!must && ((comat_option(COMAT_OPT_NORM_FUSED) != 3 && comat_option(COMAT_OPT_NORM_FUSED) != 4) || !pays)) return false;
+    const int nf = comat_option(COMAT_OPT_NORM_FUSED);
+    if (!must && ((nf != 3 && nf != 4 && nf != 5) || !pays)) return false;
     const int cpg = C / G;
     if (cpg > GN_ONE_MAXCPG || HW * (int64_t)C >= (1ll << 31)) return false;
     if (dtype == COMAT_F32) {
@@ -467,38 +468,47 @@ __global__ __launch_bounds__(NT) void gn_vapply2_kernel(const T* __restrict__ x,
     float qinv = 0.f, qmax = 0.f;
     if (Q) qinv = 1.0f / *gq.scale;
     __shared__ float sm_a[FIN ? 64 : 1], sm_b[FIN ? 64 : 1];
+    __shared__ __attribute__((aligned(16))) double sm_red[FIN ? 2 * NT : 1];
     if (FIN) {
-        constexpr int SUB = 8;
-        const int g2 = threadIdx.x / SUB, sub = threadIdx.x % SUB;
-        if (g2 < G) {  // G is a multiple of 8 and <= 32 here (host): whole waves take this branch
-            const int64_t n = (int64_t)gridDim.y * G * 2;
-            const int64_t i = (int64_t)b * G + g2;
-            double s1 = 0.0, s2 = 0.0;
-            for (int k = sub; k < fin.nblk; k += SUB) {
-                s1 += fin.part[(int64_t)(1 + k) * n + 2 * i];
-                s2 += fin.part[(int64_t)(1 + k) * n + 2 * i + 1];
+        // Round 6: ONE burst of independent 16-byte loads per thread (thread t: group t % G, slabs t / G, t / G + S, ..), then the S
+        // partial sums of a group are added in slab-lane order through LDS - one memory round trip per block instead of a chain
+        // of <= 8 dependent pairs per lane followed by 64-bit shuffles (round-6 call gn_fin: that form cost the C2 step +3.6 ms).
+        const int S = NT / G, g2 = threadIdx.x % G, sl = threadIdx.x / G;
+        const int64_t n = (int64_t)gridDim.y * G * 2;
+        double s1 = 0.0, s2 = 0.0;
+        if (sl < S) {
+            const double* src = fin.part + 2 * ((int64_t)b * G + g2);
+#pragma unroll 8
+            for (int k = sl; k < fin.nblk; k += S) {
+                const double2 v = *(const double2*)(src + (int64_t)(1 + k) * n);
+                s1 += v.x;
+                s2 += v.y;
             }
-#pragma unroll
-            for (int o = 1; o < SUB; o <<= 1) {
-                s1 += __shfl_xor(s1, o, 64);
-                s2 += __shfl_xor(s2, o, 64);
+            sm_red[(sl * G + g2) * 2] = s1;
+            sm_red[(sl * G + g2) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x < G) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int q = 0; q < S; ++q) {
+                t1 += sm_red[(q * G + threadIdx.x) * 2];
+                t2 += sm_red[(q * G + threadIdx.x) * 2 + 1];
             }
-            if (sub == 0) {
-                if (MODE == 0) {
-                    const double mean = s1 / fin.count;
-                    double var = s2 / fin.count - mean * mean;
-                    if (var < 0) var = 0;
-                    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)fin.eps));
-                    sm_a[g2] = m;
-                    sm_b[g2] = r;
-                    if (blockIdx.x == 0) {
-                        fin.stats_out[2 * i] = m;
-                        fin.stats_out[2 * i + 1] = r;
-                    }
-                } else {
-                    sm_a[g2] = (float)s1;
-                    sm_b[g2] = (float)s2;
+            const int64_t i = (int64_t)b * G + threadIdx.x;
+            if (MODE == 0) {
+                const double mean = t1 / fin.count;
+                double var = t2 / fin.count - mean * mean;
+                if (var < 0) var = 0;
+                const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)fin.eps));
+                sm_a[threadIdx.x] = m;
+                sm_b[threadIdx.x] = r;
+                if (blockIdx.x == 0) {
+                    fin.stats_out[2 * i] = m;
+                    fin.stats_out[2 * i + 1] = r;
                 }
+            } else {
+                sm_a[threadIdx.x] = (float)t1;
+                sm_b[threadIdx.x] = (float)t2;
             }
         }
         __syncthreads();
@@ -605,8 +615,13 @@ static inline bool gn_two_launch(int B, int nblk) {
     const int o = comat_option(COMAT_OPT_NORM_FUSED);
     return (o == 1 || o == 4) && (int64_t)B * (1 + (nblk + GN_TG - 1) / GN_TG) <= GN_TICKETS;
 }
-// norm_fused = 2: the apply kernel finalises (gn_vapply2_kernel<.., FIN>); needs whole waves of 8-lane groups
-static inline bool gn_fin_in_apply(int G) { return comat_option(COMAT_OPT_NORM_FUSED) == 2 && G % 8 == 0 && G <= 32; }
+// norm_fused = 2 / 5: the apply kernel finalises (gn_vapply2_kernel<.., FIN>): every block sums the per-block partials of its sample in
+// its prologue (5 = with the one-launch form where that pays, like 3)
+constexpr int GN_FIN_MAX_SLABS = 256;
+static inline bool gn_fin_in_apply(int G) {
+    const int o = comat_option(COMAT_OPT_NORM_FUSED);
+    return (o == 2 || o == 5) && G <= 64;
+}
 
 template <typename T>
 static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
@@ -614,7 +629,7 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     constexpr int EPV = 16 / sizeof(T);
     const bool fin = !q && gn_fin_in_apply(G);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
-    if (fin && rpb < cdiv64(HW, 64)) rpb = (int)cdiv64(HW, 64);  // at most 64 partial slabs per sample
+    if (fin && rpb < cdiv64(HW, GN_FIN_MAX_SLABS)) rpb = (int)cdiv64(HW, GN_FIN_MAX_SLABS);  // bounded prologue of the apply blocks
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
@@ -649,7 +664,7 @@ static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const 
     constexpr int EPV = 16 / sizeof(T);
     const bool fin = gn_fin_in_apply(G);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
-    if (fin && rpb < cdiv64(HW, 64)) rpb = (int)cdiv64(HW, 64);
+    if (fin && rpb < cdiv64(HW, GN_FIN_MAX_SLABS)) rpb = (int)cdiv64(HW, GN_FIN_MAX_SLABS);
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
     unsigned* tickets = (unsigned*)ws_all;
     double* ws = ws_all + GN_TICKETS / 2;
@@ -909,7 +924,7 @@ extern "C" int comat_groupnorm_fwd(const void* x, const float* gamma, const floa
 // 1 when comat_groupnorm_fwd_q takes the shape: the vectorised three-launch form, i.e. not the shapes the one-launch form serves
 extern "C" int comat_groupnorm_fwd_q_ok(int32_t B, int64_t HW, int32_t C, int32_t G, int32_t dtype) {
     if (!dtype_ok(dtype) || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G || G > MAX_G || B > 65535) return 0;
-    if ((comat_option(COMAT_OPT_NORM_FUSED) == 3 || comat_option(COMAT_OPT_NORM_FUSED) == 4) && HW <= 256 && C / G <= GN_ONE_MAXCPG)
+    if (comat_option(COMAT_OPT_NORM_FUSED) >= 3 && HW <= 256 && C / G <= GN_ONE_MAXCPG)
         return 0;  // gn_try_one<0> "pays"
     return gn_vec_ok(nullptr, nullptr, C, dtype, HW) ? 1 : 0;
 }

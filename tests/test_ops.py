@@ -206,8 +206,8 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
     xr.grad += gy2.reshape(B_, HW, C)
     res = []
     vec_ok = C % (4 if dtype == torch.float32 else 8) == 0  # what the multi-launch forms need (else: one launch or an error)
-    for mode in (0, 1, 2, 3, 3, 4):  # 4: one launch where it pays, the two-launch ticket form elsewhere (round 6)
-        if mode not in (3, 4) and not vec_ok:
+    for mode in (0, 1, 2, 3, 3, 4, 5):  # 4 / 5: one launch where it pays, else the two-launch ticket / finalize-in-apply form (round 6)
+        if mode not in (3, 4, 5) and not vec_ok:
             res.append(None)
             continue
         _set_opts(norm_fused=mode)
@@ -218,7 +218,7 @@ def test_groupnorm_two_launch_forms(hip, dtype, shape, default_opts):
         check(y, yr, dtype, f"gn fwd (norm_fused={mode})")
         check(xd.grad, xr.grad.reshape(B_ * HW, C), dtype, f"gn bwd (norm_fused={mode})", factor=2)
     lim = 2e-6 if dtype == torch.float32 else 1e-2  # bf16: an output may flip by one ulp
-    for mode in (1, 2, 3, 5):
+    for mode in (1, 2, 3, 5, 6):
         if res[0] is None:
             continue
         for a, b_, name in zip(res[0], res[mode], ("y", "dx")):

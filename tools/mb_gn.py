@@ -35,7 +35,7 @@ def graph_time(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e3
 
 
-print("# B HW C G : fwd us (norm_fused 0 -> 3 -> 4), bwd us (0 -> 3 -> 4), bytes moved fwd; 0 = three launches, 3 = one launch where it pays else three, 4 = one launch where it pays else two (ticket)")
+print("# B HW C G : fwd us (norm_fused 0 -> 3 -> 4 -> 5), bwd us (0 -> 3 -> 4 -> 5), bytes moved fwd; 0 = three launches, 3 = one launch where it pays else three, 4 = one launch where it pays else two (ticket), 5 = ... else two (finalize in the apply kernel's prologue)")
 for B, HW, C, G in [(2, 4096, 320, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), (2, 1024, 640, 32), (2, 1024, 1280, 32),
                     (2, 1024, 1920, 32), (2, 256, 1280, 32), (2, 256, 2560, 32), (2, 64, 1280, 32), (2, 64, 2560, 32),
                     (1, 4096, 320, 32), (1, 4096, 512, 32), (1, 16384, 512, 32), (1, 65536, 256, 32), (1, 262144, 128, 32)]:
@@ -46,10 +46,10 @@ for B, HW, C, G in [(2, 4096, 320, 32), (2, 4096, 640, 32), (2, 4096, 960, 32), 
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     stats = torch.empty(B, G, 2, device=dev)
     row = []
-    for mode in (0, 3, 4):
+    for mode in (0, 3, 4, 5):
         _hip.set_option("norm_fused", mode)
         tf = graph_time(lambda: k.groupnorm_fwd(x, gamma, beta, y, stats, B, HW, C, G, 1e-5, True))
         tb = graph_time(lambda: k.groupnorm_bwd(dy, x, gamma, beta, stats, dx, B, HW, C, G, True, add=add))
         row.append((tf, tb))
-    print(f"{B} {HW:5d} {C:5d} {G}: fwd {row[0][0]:6.1f} -> {row[1][0]:6.1f} -> {row[2][0]:6.1f}   bwd {row[0][1]:6.1f} -> {row[1][1]:6.1f} -> {row[2][1]:6.1f}   "
+    print(f"{B} {HW:5d} {C:5d} {G}: fwd {row[0][0]:6.1f} -> {row[1][0]:6.1f} -> {row[2][0]:6.1f} -> {row[3][0]:6.1f}   bwd {row[0][1]:6.1f} -> {row[1][1]:6.1f} -> {row[2][1]:6.1f} -> {row[3][1]:6.1f}   "
           f"({2 * x.numel() * 2 / 1e6:.1f} MB)", flush=True)
