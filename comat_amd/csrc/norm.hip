@@ -617,17 +617,20 @@ static inline bool gn_two_launch(int B, int nblk) {
 }
 // norm_fused = 2 / 5: the apply kernel finalises (gn_vapply2_kernel<.., FIN>): every block sums the per-block partials of its sample in
 // its prologue (5 = with the one-launch form where that pays, like 3)
+// Measured (profiles/r06_ag_gn_fin_burst.txt): forward 18.5 -> 16.4 us at 2 x 64^2 x 640, 28.4 -> 23.0 at 128^2 x 512, equal on the small
+// levels; the VAE's 256^2 / 512^2 tensors lose (the slab cap starves their statistics pass): they keep three launches.
 constexpr int GN_FIN_MAX_SLABS = 256;
-static inline bool gn_fin_in_apply(int G) {
+constexpr int64_t GN_FIN_MAX_HW = 16384;
+static inline bool gn_fin_in_apply(int G, int64_t HW) {
     const int o = comat_option(COMAT_OPT_NORM_FUSED);
-    return (o == 2 || o == 5) && G <= 64;
+    return (o == 2 || (o == 5 && HW <= GN_FIN_MAX_HW)) && G <= 64;
 }
 
 template <typename T>
 static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
                        int64_t HW, int C, int G, float eps, int silu, hipStream_t st, const GnQ* q = nullptr) {
     constexpr int EPV = 16 / sizeof(T);
-    const bool fin = !q && gn_fin_in_apply(G);
+    const bool fin = !q && gn_fin_in_apply(G, HW);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
     if (fin && rpb < cdiv64(HW, GN_FIN_MAX_SLABS)) rpb = (int)cdiv64(HW, GN_FIN_MAX_SLABS);  // bounded prologue of the apply blocks
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
@@ -662,7 +665,7 @@ template <typename T>
 static void gn_bwd_vec(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats, void* dx,
                        double* ws_all, int B, int64_t HW, int C, int G, int silu, const void* add, hipStream_t st) {
     constexpr int EPV = 16 / sizeof(T);
-    const bool fin = gn_fin_in_apply(G);
+    const bool fin = gn_fin_in_apply(G, HW);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
     if (fin && rpb < cdiv64(HW, GN_FIN_MAX_SLABS)) rpb = (int)cdiv64(HW, GN_FIN_MAX_SLABS);
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);

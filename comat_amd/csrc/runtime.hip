@@ -52,13 +52,14 @@ Opt g_opts[COMAT_N_OPTIONS] = {
     {"g2_cfg", "COMAT_G2_CFG", 0, 0, false},              // force its block tile: 1 128x128, 2 128x64, 3 256x128, 4 64x128
     {"g2_splits", "COMAT_G2_SPLITS", 0, 0, false},        // force its split-K count
     {"force_splits", "COMAT_FORCE_SPLITS", 0, 0, false},  // force the split-K count of the general 64x64 kernel
-    {"norm_fused", "COMAT_NORM_FUSED", 3, 0, false},      // GroupNorm: 3 = ONE launch wherever a (sample, group) fits a
-                                                          // workgroup's registers (every UNet level), 0 = always the
-                                                          // three-launch form, 1 / 2 = two launches (statistics finalised
-                                                          // by the last-arriving block / by the apply kernel's prologue).
-                                                          // (Round 5 measured a cooperative one-launch form - resident blocks,
-                                                          // rows in registers, a grid barrier - at 29 vs 14 us for 2 x 64^2 x 320:
-                                                          // profiles/r05_a_mb_gn_coop.txt; branch exp/r5-coop-gn-keysplit)
+    {"norm_fused", "COMAT_NORM_FUSED", 5, 0, false},      // GroupNorm: ONE launch wherever a (sample, group) fits a workgroup's
+                                                          // registers and that pays (HW <= 256); for the rest 3 = three launches
+                                                          // (statistics, finalize, apply), 4 = two (the last-arriving statistics block
+                                                          // finalises), 5 (default, round 6) = two (every apply block sums the
+                                                          // partials in its prologue, one burst of loads; tensors up to 128^2 pixels).
+                                                          // 0 = always three, 1 / 2 = always the two-launch forms.
+                                                          // Measured: profiles/r06_af_gn_ticket_ab.txt, r06_ag_gn_fin_burst.txt; the
+                                                          // cooperative one-launch form of round 5: r05_a_mb_gn_coop.txt
     {"gemm2_tt", "COMAT_GEMM2_TT", 1, 0, false},          // k-major x k-major GEMMs (weight gradients) on the pipelined
                                                           // kernel with hardware transpose reads
     {"flash_kt", "COMAT_FLASH_KT", 4, 0, false},          // fused attention (bf16), two 32-row tiles per iteration: 1 nowhere,

@@ -779,7 +779,7 @@ def test_adamw_with_clip(dev):
 
 
 # the library's defaults for the options whose default moved in round 4 (runtime.hip)
-DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1)
+DEFAULT_OPTS = dict(flash_xcd=1, g2_order=2, gemm3=1, norm_fused=5)
 
 
 def _set_opts(**kw):
@@ -793,7 +793,7 @@ def default_opts():
     """restore the library's kernel-selection options after a test that forces variants"""
     yield
     _set_opts(gemm2=1, gemm2_tt=1, g2_cfg=0, g2_splits=0, force_splits=0, flash_trim=1, flash_tr=1, flash_kt=4, flash_merge=1, flash_xcd=DEFAULT_OPTS['flash_xcd'],
-              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=3, gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0)
+              g2_order=DEFAULT_OPTS['g2_order'], norm_fused=DEFAULT_OPTS['norm_fused'], gemm3=DEFAULT_OPTS['gemm3'], g3_cfg=0)
 
 
 G2_GEMMS = [  # (M, N, K, batch): k-contiguous bf16 problems the pipelined kernel takes (K % 32 == 0)
