@@ -897,22 +897,34 @@ __device__ __forceinline__ void flash_dkdv_body(const FlashArgs& a, char* smem, 
                         ? a.part + ((int64_t)bz * a.B * a.H + by) * a.Nk * a.d + (int64_t)key * a.d
                         : nullptr;
         float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
+        if (a.qsplit > 1) {
+            // fp32 partials of this query range: accumulator registers 4 j .. 4 j + 3 are 4 consecutive head-dim columns (crow), so a
+            // lane writes 16-byte pieces instead of single floats (same values; d is a multiple of 4, the slabs are 16-byte aligned)
 #pragma unroll
-        for (int t2 = 0; t2 < G::NT32; ++t2)
+            for (int t2 = 0; t2 < G::NT32; ++t2)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = t2 * 32 + crow(i, hh);
-                if (n < a.d) {
-                    const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
-                    if (a.qsplit > 1) {
-                        pk[n] = dk;
-                        pv[n] = dvT[t2][i];
-                    } else {
+                for (int j = 0; j < 4; ++j) {
+                    const int n0 = t2 * 32 + crow(4 * j, hh);
+                    if (n0 < a.d) {
+                        const float sc = SCALE_OUT ? a.scale : 1.0f;
+                        *(float4*)(pk + n0) = SCALE_OUT ? make_float4(dkT[t2][4 * j] * sc, dkT[t2][4 * j + 1] * sc, dkT[t2][4 * j + 2] * sc, dkT[t2][4 * j + 3] * sc)
+                                                        : make_float4(dkT[t2][4 * j], dkT[t2][4 * j + 1], dkT[t2][4 * j + 2], dkT[t2][4 * j + 3]);
+                        *(float4*)(pv + n0) = make_float4(dvT[t2][4 * j], dvT[t2][4 * j + 1], dvT[t2][4 * j + 2], dvT[t2][4 * j + 3]);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = t2 * 32 + crow(i, hh);
+                    if (n < a.d) {
+                        const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
                         stf<T>(dKb + (int64_t)key * a.ldk + n, dk);
                         stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
                     }
                 }
-            }
+        }
     }
 }
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
@@ -1229,22 +1241,34 @@ __device__ __forceinline__ void flash_dkdv2_body(const FlashArgs& a, char* smem,
                         ? a.part + ((int64_t)bz * a.B * a.H + by) * a.Nk * a.d + (int64_t)key * a.d
                         : nullptr;
         float* pv = a.qsplit > 1 ? pk + (int64_t)a.qsplit * slab : nullptr;
+        if (a.qsplit > 1) {
+            // fp32 partials of this query range: accumulator registers 4 j .. 4 j + 3 are 4 consecutive head-dim columns (crow), so a
+            // lane writes 16-byte pieces instead of single floats (same values; d is a multiple of 4, the slabs are 16-byte aligned)
 #pragma unroll
-        for (int t2 = 0; t2 < G::NT32; ++t2)
+            for (int t2 = 0; t2 < G::NT32; ++t2)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int n = t2 * 32 + crow(i, hh);
-                if (n < a.d) {
-                    const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
-                    if (a.qsplit > 1) {
-                        pk[n] = dk;
-                        pv[n] = dvT[t2][i];
-                    } else {
+                for (int j = 0; j < 4; ++j) {
+                    const int n0 = t2 * 32 + crow(4 * j, hh);
+                    if (n0 < a.d) {
+                        const float sc = SCALE_OUT ? a.scale : 1.0f;
+                        *(float4*)(pk + n0) = SCALE_OUT ? make_float4(dkT[t2][4 * j] * sc, dkT[t2][4 * j + 1] * sc, dkT[t2][4 * j + 2] * sc, dkT[t2][4 * j + 3] * sc)
+                                                        : make_float4(dkT[t2][4 * j], dkT[t2][4 * j + 1], dkT[t2][4 * j + 2], dkT[t2][4 * j + 3]);
+                        *(float4*)(pv + n0) = make_float4(dvT[t2][4 * j], dvT[t2][4 * j + 1], dvT[t2][4 * j + 2], dvT[t2][4 * j + 3]);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int t2 = 0; t2 < G::NT32; ++t2)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int n = t2 * 32 + crow(i, hh);
+                    if (n < a.d) {
+                        const float dk = SCALE_OUT ? dkT[t2][i] * a.scale : dkT[t2][i];
                         stf<T>(dKb + (int64_t)key * a.ldk + n, dk);
                         stf<T>(dVb + (int64_t)key * a.ldv + n, dvT[t2][i]);
                     }
                 }
-            }
+        }
     }
 }
 template <int DMAX, int NK>
@@ -1469,8 +1493,8 @@ extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V,
     a.qsplit = 1;
     a.part = ws;
     const int64_t base_blocks = (int64_t)((Nk + 127) / 128) * B * H, ntq = (Nq + 31) / 32;
-    if (ws && base_blocks < 256 && ntq >= 8) {
-        int64_t qs = cdiv64(512, base_blocks);
+    if (ws && (((uintptr_t)ws) & 15) == 0 && d % 4 == 0 && base_blocks < 256 && ntq >= 8) {  // (16-byte partial stores)
+        int64_t qs = cdiv64(comat_option(COMAT_OPT_FLASH_QS) > 0 ? comat_option(COMAT_OPT_FLASH_QS) : 512, base_blocks);
         if (qs > ntq / 4) qs = ntq / 4;
         const int64_t cap = ws_bytes / (2 * (int64_t)B * H * Nk * d * 4);
         if (qs > cap) qs = cap;

@@ -104,7 +104,7 @@ int comat_check_launch(const char* what);
 // tuning options (runtime.hip): environment default read once, comat_set_option() overrides
 enum { COMAT_OPT_FLASH_TRIM = 0, COMAT_OPT_FLASH_TR, COMAT_OPT_GEMM2, COMAT_OPT_G2_CFG, COMAT_OPT_G2_SPLITS,
        COMAT_OPT_FORCE_SPLITS, COMAT_OPT_NORM_FUSED, COMAT_OPT_GEMM2_TT, COMAT_OPT_FLASH_KT, COMAT_OPT_FLASH_MERGE,
-       COMAT_OPT_G2_ORDER, COMAT_OPT_FLASH_XCD, COMAT_OPT_GEMM3, COMAT_OPT_G3_CFG,
+       COMAT_OPT_G2_ORDER, COMAT_OPT_FLASH_XCD, COMAT_OPT_GEMM3, COMAT_OPT_G3_CFG, COMAT_OPT_FLASH_QS,
        COMAT_N_OPTIONS };
 int comat_option(int id);
 // which kernel family served the calling thread's last comat_gemm / comat_gemm_segments / comat_conv2d call

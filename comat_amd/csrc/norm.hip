@@ -630,7 +630,7 @@ template <typename T>
 static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, void* y, float* stats, double* ws_all, int B,
                        int64_t HW, int C, int G, float eps, int silu, hipStream_t st, const GnQ* q = nullptr) {
     constexpr int EPV = 16 / sizeof(T);
-    const bool fin = !q && gn_fin_in_apply(G, HW);
+    const bool fin = gn_fin_in_apply(G, HW);
     int rpb = gn_rows_per_block(B, HW, C, EPV);
     if (fin && rpb < cdiv64(HW, GN_FIN_MAX_SLABS)) rpb = (int)cdiv64(HW, GN_FIN_MAX_SLABS);  // bounded prologue of the apply blocks
     dim3 sg((unsigned)cdiv64(HW, rpb), (unsigned)B);
@@ -647,7 +647,11 @@ static void gn_fwd_vec(const void* x, const float* gamma, const float* beta, voi
     const dim3 ag((unsigned)cdiv64(HW, arpb), (unsigned)B);
     const GnFin f = {ws, stats, (int)sg.x, (double)HW * (C / G), eps};
     const GnQ noq = {nullptr, nullptr, nullptr};
-    if (q)  // (the finalize-in-apply experiment has no e4m3 form: the host keeps fin off for these calls)
+    if (q && fin)  // (same statistics path as the plain call: the two forms of a norm stay bit-identical in y and stats)
+        hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, true, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
+                           (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
+                           f, *q);
+    else if (q)
         hipLaunchKernelGGL((gn_vapply2_kernel<T, 0, false, true>), ag, dim3(NT), 0, st, (const T*)x, (const T*)nullptr, gamma, beta,
                            (const float*)stats, (const double*)nullptr, (T*)y, (int)HW, C, G, silu, arpb, (const T*)nullptr,
                            f, *q);

@@ -75,11 +75,40 @@ def merge_table(k, dev):
     _hip.set_option("flash_merge", 1)
 
 
+def qs_table(k, dev):
+    """option flash_qs: target block count of the dK / dV query split (cross-attention: one key block per (batch, head))"""
+    T = torch.bfloat16
+    print("# backward of the cross-attention shapes, us per call replayed from a hipGraph, by flash_qs (blocks the query split aims at) x flash_merge")
+    for (B, H, Nq, Nk, d) in [(2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 8, 64, 77, 160), (2, 20, 1024, 77, 64), (2, 10, 4096, 77, 64)]:
+        HD = H * d
+        q = torch.randn(B * Nq, HD, device=dev).to(T)
+        kk = torch.randn(B * Nk, HD, device=dev).to(T)
+        v = torch.randn(B * Nk, HD, device=dev).to(T)
+        g = torch.randn(B * Nq, HD, device=dev).to(T)
+        o = torch.empty_like(q)
+        lse = torch.empty(B, H, Nq, device=dev)
+        dbuf = torch.empty(B, H, Nq, device=dev)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(kk), torch.empty_like(v)
+        k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+        cells = []
+        for qs in (64, 128, 256, 512, 1024):
+            for mg in (0, 1, 2):
+                _hip.set_option("flash_qs", qs)
+                _hip.set_option("flash_merge", mg)
+                t = timeit_graph(lambda: k.flash_attn_bwd(q, kk, v, o, g, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5))
+                cells.append(f"qs={qs:4d}/mg={mg} {t:6.1f}")
+        print(f"B={B} H={H:2d} Nq={Nq:4d} Nk={Nk} d={d:3d}: " + "  ".join(cells), flush=True)
+    _hip.set_option("flash_qs", 512)
+    _hip.set_option("flash_merge", 1)
+
+
 def main():
     dev = torch.device("cuda:0")
     k = _hip.HipKernels()
     ops.set_kernel_backend(k)
     T = torch.bfloat16
+    if "qs" in sys.argv[1:]:
+        return qs_table(k, dev)
     if "merge" in sys.argv[1:]:
         return merge_table(k, dev)
     if "kt" in sys.argv[1:]:
