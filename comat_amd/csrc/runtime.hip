@@ -87,9 +87,10 @@ Opt g_opts[COMAT_N_OPTIONS] = {
                                                           // decoder), 2 every eligible problem (tests, microbenchmarks)
     {"g3_cfg", "COMAT_G3_CFG", 0, 0, false},              // force its tile shape: 1 32x32 / 8 waves, 2 64x32 / 8, 3 32x64 / 8,
                                                           // 4 64x64 / 4, 5 64x64 / 8, 6 32x32 / 4, 7 64x32 / 4, 8 32x32 / 16, 9 64x32 / 16
-    {"flash_qs", "COMAT_FLASH_QS", 512, 0, false},        // fused attention backward with few key blocks (cross-attention): the query
+    {"flash_qs", "COMAT_FLASH_QS", 256, 0, false},        // fused attention backward with few key blocks (cross-attention): the query
                                                           // loop of dK / dV is cut into ranges until the grid holds about this many
-                                                          // blocks (each range writes an fp32 partial that flash_kv_reduce sums)
+                                                          // blocks (each range writes an fp32 partial that flash_kv_reduce sums).
+                                                          // 256 since round 6 (was 512): profiles/r06_ah_mb_flash_qs.txt
 };
 }  // namespace
 
