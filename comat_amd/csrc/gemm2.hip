@@ -446,12 +446,14 @@ __device__ __forceinline__ void gemm2_body(const Args2& g, const unsigned bid, c
         for (int i = 0; i < IA; ++i) {
             const int64_t gm = m0 + (i * NW + wave) * RPI + drow;
             rv[i] = gm < g.M;
-            const int64_t gmc = rv[i] ? gm : 0;
-            const int b = (int)(gmc / hw), rem = (int)(gmc - (int64_t)b * hw);
-            const int oy = rem / g.Wout, ox = rem - oy * g.Wout;
-            bb[i] = b * g.Hin;
-            by[i] = oy * g.stride - g.pad;
-            bx[i] = ox * g.stride - g.pad;
+            // (M < 2^31 - the host checks - so the pixel index splits with 32-bit UNSIGNED divisions: a 64-bit signed division by a
+            // run-time value is ~150 dependent instructions per lane, twice per DMA row, in front of the kernel's first load)
+            const unsigned gmc = rv[i] ? (unsigned)gm : 0u;
+            const unsigned b = gmc / (unsigned)hw, rem = gmc - b * (unsigned)hw;
+            const unsigned oy = rem / (unsigned)g.Wout, ox = rem - oy * (unsigned)g.Wout;
+            bb[i] = (int)b * g.Hin;
+            by[i] = (int)oy * g.stride - g.pad;
+            bx[i] = (int)ox * g.stride - g.pad;
         }
         const int k0 = kt0 * KE;
         const int tap = k0 / g.Cin;
