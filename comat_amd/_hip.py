@@ -116,6 +116,8 @@ SIGNATURES = {
     "comat_gemm_workspace_bytes": [_i64, _i64, _i64, _i64, _i32],
     "comat_set_option": [C.c_char_p, _i32],
     "comat_last_gemm_kernel": [],
+    "comat_flash_attn_fwd_q": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f, _i32, _vp, _i64, _vp, _vp,
+                               _vp],
     "comat_fp8_scale": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
     "comat_fp8_quantize": [_vp, _i64, _i32, _vp, _vp, _vp],
     "comat_fp8_quantize_scaled": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
@@ -525,7 +527,13 @@ class HipKernels:
         _check(_lib.comat_softmax_bwd(_ptr(P), _ptr(dP), _ptr(dS), rows, cols, scale, dt(P), dt(dP), dt(dS),
                                       _stream()), "comat_softmax_bwd")
 
-    def flash_attn_fwd(self, q, k, v, o, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+    def flash_attn_fwd(self, q, k, v, o, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale, q8=None):
+        """q8 = (bytes [B*Nq, H*d] uint8, scale [1], amax [1] int32): the forward also emits the e4m3 bytes of its output (delayed fp8 scaling)"""
+        if q8 is not None:
+            _check(_lib.comat_flash_attn_fwd_q(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale,
+                                               dt(q), _ptr(q8[0]), q8[0].shape[1], _ptr(q8[1]), _ptr(q8[2]), _stream()),
+                   "comat_flash_attn_fwd_q")
+            return
         _check(_lib.comat_flash_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), B, H, Nq, Nk, d, ldq, ldk, ldv,
                                          ldo, scale, dt(q), _stream()), "comat_flash_attn_fwd")
 

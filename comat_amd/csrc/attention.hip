@@ -316,6 +316,12 @@ struct FlashArgs {
     int xcd;       // option flash_xcd: renumber the workgroups so that the blocks of one (batch, head) share an XCD
     int qsplit;    // dK/dV: number of query ranges (blockIdx.z) whose fp32 partials are summed by flash_kv_reduce
     float* part;   // [2][qsplit][B*H][Nk][d] fp32 partial dK / dV (qsplit > 1)
+    // forward, fp8 forward with delayed scaling (comat_flash_attn_fwd_q): the e4m3 bytes of the (rounded) output for the projection that
+    // consumes it - layout of Out with leading dimension ldq8 - and its abs-max folded into *q_amax
+    unsigned char* q8;
+    const float* q_scale;
+    unsigned* q_amax;
+    int64_t ldq8;
 };
 
 // NK: MFMA k-steps over the head dim actually issued (< Geo::NKS when the padded tail chunks are all zero)
@@ -333,6 +339,37 @@ __device__ __forceinline__ void flash_block_xy(int xcd, int& bx, int& by) {
         bx = (int)(lin % gridDim.x);
         by = (int)(lin / gridDim.x);
     }
+}
+
+// fp8 forward, delayed scaling: the forward kernels also emit the e4m3 bytes of their output.  Accumulator registers 4 j .. 4 j + 3 of a
+// lane are 4 consecutive head-dim columns of its query row (crow): 4 bytes per store, made from the ROUNDED output values - what
+// comat_fp8_quantize_scaled would make of Out - and one abs-max per wave for the consumer's site.  Every lane of the wave calls this
+// (rows beyond Nq contribute nothing).
+template <typename T, int NT32>
+__device__ __forceinline__ void flash_store_q8(const FlashArgs& a, const f32x16_t (&oT)[NT32], float inv, int q, int hh, int b, int h) {
+    const float qinv = 1.0f / *a.q_scale;
+    float qmax = 0.f;
+    if (q < a.Nq) {
+        unsigned char* qb = a.q8 + ((int64_t)b * a.Nq + q) * a.ldq8 + h * a.d;
+#pragma unroll
+        for (int t2 = 0; t2 < NT32; ++t2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n0 = t2 * 32 + crow(4 * j, hh);
+                if (n0 < a.d) {
+                    float r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = oT[t2][4 * j + e] * inv;
+                        r[e] = sizeof(T) == 2 ? bf16_to_f32(f32_to_bf16(o)) : o;
+                        qmax = fmaxf(qmax, fabsf(r[e]));
+                    }
+                    *(unsigned*)(qb + n0) = fp8_pack4(r, qinv);
+                }
+            }
+    }
+    qmax = wave_max(qmax);
+    if ((threadIdx.x & 63) == 0) fp8_amax_track(a.q_amax, qmax);
 }
 
 template <typename T, int DMAX, int NK = Geo<T, DMAX>::NKS, bool TR = false>
@@ -454,6 +491,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, sizeof(T), false) void flash_fw
         }
         if (DB || more) __syncthreads();
     }
+    if (a.q8) flash_store_q8<T, G::NT32>(a, oT, 1.0f / l, q, hh, b, h);
     if (q < a.Nq) {
         const float inv = 1.0f / l;
 #pragma unroll
@@ -596,6 +634,7 @@ __global__ __launch_bounds__(NT) FLASH_OCC(DMAX, 2, false) void flash_fwd2_kerne
         if (more) store_pair(cur);
         __syncthreads();
     }
+    if (a.q8) flash_store_q8<T, G::NT32>(a, oT, 1.0f / l, q, hh, b, h);
     if (q < a.Nq) {
         const float inv = 1.0f / l;
 #pragma unroll
@@ -1459,20 +1498,37 @@ int check_args(const char* what, const void* Q, const void* K, const void* V, in
 
 }  // namespace
 
-extern "C" int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B,
+static int flash_fwd_impl(const char* what, unsigned char* q8, const float* q_scale, uint32_t* q_amax, int64_t ldq8, const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B,
                                     int32_t H, int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk,
                                     int64_t ldv, int64_t ldo, float scale, int32_t dtype, void* stream) {
-    if (int rc = check_args("comat_flash_attn_fwd", Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
-    COMAT_REQUIRE(O && lse, "comat_flash_attn_fwd: null output");
+    if (int rc = check_args(what, Q, K, V, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, dtype)) return rc;
+    COMAT_REQUIRE(O && lse, "%s: null output", what);
     FlashArgs a = {};
     a.Q = Q; a.K = K; a.V = V; a.Out = O; a.lse = lse;
     a.B = B; a.H = H; a.Nq = Nq; a.Nk = Nk; a.d = d;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.scale = scale;
     a.xcd = comat_option(COMAT_OPT_FLASH_XCD);
+    a.q8 = q8; a.q_scale = q_scale; a.q_amax = (unsigned*)q_amax; a.ldq8 = ldq8;
     const int rc = dtype == COMAT_BF16 ? dispatch<bf16_t>(a, false, (hipStream_t)stream)
                                        : dispatch<float>(a, false, (hipStream_t)stream);
-    COMAT_REQUIRE(rc == 0, "comat_flash_attn_fwd: unsupported head dim");
-    return comat_check_launch("comat_flash_attn_fwd");
+    COMAT_REQUIRE(rc == 0, "%s: unsupported head dim", what);
+    return comat_check_launch(what);
+}
+
+extern "C" int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B, int32_t H, int32_t Nq,
+                                    int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int32_t dtype,
+                                    void* stream) {
+    return flash_fwd_impl("comat_flash_attn_fwd", nullptr, nullptr, nullptr, 0, Q, K, V, O, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale,
+                          dtype, stream);
+}
+
+extern "C" int comat_flash_attn_fwd_q(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B, int32_t H, int32_t Nq,
+                                      int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                                      int32_t dtype, void* q8, int64_t ldq8, const float* q_scale, uint32_t* q_amax, void* stream) {
+    COMAT_REQUIRE(q8 && q_scale && q_amax && ldq8 >= (int64_t)H * d && ldq8 % 4 == 0 && (((uintptr_t)q8) & 3) == 0 && d % 4 == 0,
+                  "comat_flash_attn_fwd_q: q8, q_scale, q_amax, 4-byte aligned rows (ldq8 %% 4 == 0, d %% 4 == 0)");
+    return flash_fwd_impl("comat_flash_attn_fwd_q", (unsigned char*)q8, q_scale, q_amax, ldq8, Q, K, V, O, lse, B, H, Nq, Nk, d, ldq, ldk, ldv,
+                          ldo, scale, dtype, stream);
 }
 
 extern "C" int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,

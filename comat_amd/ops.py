@@ -383,6 +383,8 @@ def fp8_weight_group(lins):
 _fp8_ktail = os.environ.get("COMAT_FP8_KTAIL", "1") != "0"
 # COMAT_FP8_GEGLU_Q8 (default 1): `ff.net.0.proj` + GEGLU emits the e4m3 bytes for `ff.net.2` from its epilogue (comat_gemm_params::q8)
 _fp8_geglu_q8 = os.environ.get("COMAT_FP8_GEGLU_Q8", "1") != "0"
+# COMAT_FP8_FLASH_Q8 (default 1): the fused attention forward emits the e4m3 bytes for its output projection (comat_flash_attn_fwd_q)
+_fp8_flash_q8 = os.environ.get("COMAT_FP8_FLASH_Q8", "1") != "0"
 _FP8_MAX_SITES = 4096
 _fp8_scaling = os.environ.get("COMAT_FP8_SCALING", "jit")
 _fp8_calibrating = False
@@ -1785,12 +1787,18 @@ class _FlashAttention(Function):
     """Fused attention (scores stay on chip); saves Q, K, V, O and the per-row log-sum-exp for the backward kernels."""
 
     @staticmethod
-    def forward(ctx, q, k_, v, B, Nq, Nk, H, d, scale):
+    def forward(ctx, q, k_, v, B, Nq, Nk, H, d, scale, fp8_for=None):
         q, k_, v = _c(q), _c(k_), _c(v)
         HD = H * d
         O = q.new_empty((B * Nq, HD))
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-        kernels().flash_attn_fwd(q, k_, v, O, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
+        site = _fp8_producer_site(fp8_for, HD, q.device) if _fp8_flash_q8 else None
+        if site is not None:  # fp8 forward, delayed scaling: the e4m3 bytes for the output projection leave the same launch
+            q8 = torch.empty((B * Nq, HD), dtype=torch.uint8, device=q.device)
+            kernels().flash_attn_fwd(q, k_, v, O, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, scale, q8=(q8, site[0], site[1]))
+            O._fp8 = (q8, site[0])
+        else:
+            kernels().flash_attn_fwd(q, k_, v, O, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
         ctx.save_for_backward(q, k_, v, O, lse)
         ctx.cfg = (B, Nq, Nk, H, d, scale)
         return O
@@ -1809,7 +1817,7 @@ class _FlashAttention(Function):
             dK, dV = k_.new_empty((2,) + tuple(k_.shape)).unbind(0)
         dbuf = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
         kernels().flash_attn_bwd(q, k_, v, O, gO, lse, dbuf, dQ, dK, dV, B, H, Nq, Nk, d, HD, HD, HD, HD, scale)
-        return dQ, dK, dV, None, None, None, None, None, None
+        return dQ, dK, dV, None, None, None, None, None, None, None
 
 
 def flash_ok(dim, dtype):
@@ -1865,13 +1873,14 @@ def fused_qkv_attention(x, lin_qkv: "FrozenLinear", B, N, heads, scale=None):
     return _FusedQKVAttention.apply(x, lin_qkv, B, N, heads, dim, float(scale if scale is not None else dim ** -0.5))
 
 
-def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None, need_probs=True):
+def attention(q, k, v, B, Nq, Nk, heads, dim, scale=None, causal=False, key_mask=None, need_probs=True, fp8_for=None):
     """q: [B*Nq, heads*dim], k/v: [B*Nk, heads*dim] -> (out [B*Nq, heads*dim], probs [B, heads, Nq, Nk] or None).
-    `need_probs=False` selects the fused kernel (no probability map in HBM) when the layer allows it."""
+    `need_probs=False` selects the fused kernel (no probability map in HBM) when the layer allows it.
+    fp8_for: the frozen projection that consumes the output (ops.group_norm): the fused kernel then also emits its e4m3 bytes."""
     if scale is None:
         scale = dim ** -0.5
     if not need_probs and not causal and key_mask is None and flash_ok(dim, q.dtype):
-        return _FlashAttention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale)), None
+        return _FlashAttention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale), fp8_for), None
     return _Attention.apply(q, k, v, B, Nq, Nk, heads, dim, float(scale), bool(causal), key_mask)
 
 

@@ -163,7 +163,8 @@ class CrossAttnBlock:
 
     def _self_attn(self, att, x, B, N):
         q, k, v = ops.lora_group_linear(x, *att[("attn1", "qkv")])
-        return ops.attention(q, k, v, B, N, N, self.heads, q.shape[1] // self.heads, need_probs=False)[0]
+        return ops.attention(q, k, v, B, N, N, self.heads, q.shape[1] // self.heads, need_probs=False,
+                             fp8_for=att[("attn1", "out")][0][0])[0]
 
     def text_kv(self, att, ctx, kv_cache):
         """(k, v) = the text key / value projections of one layer.  They depend on the context and the LoRA factors only:
@@ -180,7 +181,8 @@ class CrossAttnBlock:
     def _cross_attn(self, att, x, ctx, B, N, L, need_probs, kv_cache):
         (q,) = ops.lora_group_linear(x, *att[("attn2", "q")])
         k, v = self.text_kv(att, ctx, kv_cache)
-        return ops.attention(q, k, v, B, N, L, self.heads, q.shape[1] // self.heads, need_probs=need_probs)
+        return ops.attention(q, k, v, B, N, L, self.heads, q.shape[1] // self.heads, need_probs=need_probs,
+                             fp8_for=att[("attn2", "out")][0][0])
 
     def __call__(self, x, B, H, W, ctx, L, want_probs, kv_cache=None):
         """returns (tokens, [cross-attention probabilities of every transformer layer] or None)"""

@@ -261,6 +261,13 @@ int comat_softmax_bwd(const void* P, const void* dP, void* dS, int64_t rows, int
 int comat_flash_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B, int32_t H,
                          int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                          float scale, int32_t dtype, void* stream);
+/* ABI 8 (fp8 forward, delayed scaling - see the fp8 section below): the same forward that ALSO stores q8 [B*Nq, ldq8] = the e4m3 bytes of
+ * its rounded output under *q_scale (layout of O) and folds max |O| into *q_amax: what comat_fp8_quantize_scaled would make of O,
+ * for the `to_out` projection that consumes it (attn_utils/tc_attn_utils.py:140-146 feeds `attn.to_out[0]`). */
+int comat_flash_attn_fwd_q(const void* Q, const void* K, const void* V, void* O, float* lse, int32_t B, int32_t H,
+                           int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                           float scale, int32_t dtype, void* q8, int64_t ldq8, const float* q_scale, uint32_t* q_amax,
+                           void* stream);
 int comat_flash_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                          const float* lse, float* Dbuf, void* dQ, void* dK, void* dV, int32_t B, int32_t H,
                          int32_t Nq, int32_t Nk, int32_t d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,

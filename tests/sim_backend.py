@@ -306,11 +306,14 @@ class SimKernels:
     def _heads(t, B, N, H, d, ld):
         return _v(t, (B, H, N, d), (N * ld, d, ld, 1)).float()
 
-    def flash_attn_fwd(self, q, k, v, o, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
+    def flash_attn_fwd(self, q, k, v, o, lse, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale, q8=None):
         qh, kh, vh = self._heads(q, B, Nq, H, d, ldq), self._heads(k, B, Nk, H, d, ldk), self._heads(v, B, Nk, H, d, ldv)
         s = qh @ kh.transpose(-1, -2) * scale
         lse.copy_(torch.logsumexp(s, -1))
         _v(o, (B, H, Nq, d), (Nq * ldo, d, ldo, 1)).copy_((torch.softmax(s, -1) @ vh).to(o.dtype))
+        if q8 is not None:  # comat_flash_attn_fwd_q: the e4m3 bytes of the rounded output + its abs-max
+            assert ldo == H * d and o.is_contiguous()
+            self._quantize_scaled(o, q8[1], q8[2], out=q8[0])
 
     def flash_attn_bwd(self, q, k, v, o, do, lse, dbuf, dq, dk, dv, B, H, Nq, Nk, d, ldq, ldk, ldv, ldo, scale):
         qh, kh, vh = self._heads(q, B, Nq, H, d, ldq), self._heads(k, B, Nk, H, d, ldk), self._heads(v, B, Nk, H, d, ldv)

@@ -537,18 +537,19 @@ def test_delayed_scaling_unet_matches_the_jit_form_after_calibration(dev, delaye
     args = (tok(x).to(dev), B, h, w, 417, ctx.reshape(B * L, -1).to(dev).contiguous(), L)
     kw = dict(added=(added[0].to(dev), added[1].tolist()))
     k = ops.kernels()
-    counts = {"jit": 0, "scaled": 0, "ln": 0, "gn": 0}
+    counts = {"jit": 0, "scaled": 0, "ln": 0, "gn": 0, "fa": 0}
 
     def wrap(name, key):
         fn = getattr(k, name)
 
         def f(*a, **kk):
-            counts[key] += 1
+            if key != "fa" or kk.get("q8") is not None:  # the fused attention counts only when it emits the bytes
+                counts[key] += 1
             return fn(*a, **kk)
         setattr(k, name, f)
         return fn
     saved = {n_: wrap(n_, key) for n_, key in (("fp8_quantize", "jit"), ("fp8_quantize_scaled", "scaled"),
-                                                ("layernorm_fwd_q", "ln"), ("groupnorm_fwd_q", "gn"))}
+                                                ("layernorm_fwd_q", "ln"), ("groupnorm_fwd_q", "gn"), ("flash_attn_fwd", "fa"))}
     try:
         with torch.no_grad():
             with ops.fp8_calibration():
@@ -561,12 +562,13 @@ def test_delayed_scaling_unet_matches_the_jit_form_after_calibration(dev, delaye
         for n_, fn in saved.items():
             setattr(k, n_, fn)
     assert counts["jit"] == 0 and counts["ln"] > 0
-    assert counts["scaled"] + counts["ln"] + counts["gn"] == n_sites  # every jit pair became one launch or none
+    assert counts["scaled"] + counts["ln"] + counts["gn"] + counts["fa"] == n_sites  # every jit pair became one launch or none
     ops.set_fp8_scaling("jit")
     with torch.no_grad():
         e_jit, _ = unet(*args, **kw)
     print(f"fp8 UNet delayed vs jit: {rel_l2(e_del, e_jit):.3e}; calibration pass vs jit: {rel_l2(e_cal, e_jit):.3e}; "
-          f"{n_sites} sites: {counts['scaled']} quantize launches, {counts['ln']} LayerNorm + {counts['gn']} GroupNorm producers")
+          f"{n_sites} sites: {counts['scaled']} quantize launches, {counts['ln']} LayerNorm + {counts['gn']} GroupNorm + {counts['fa']} attention "
+          "producers")
     assert rel_l2(e_cal, e_jit) < 1e-6   # the calibration pass IS the jit form
     assert rel_l2(e_del, e_jit) < 2e-2   # same scales; only bytes on a rounding boundary may differ (see the jit UNet test)
 
@@ -669,3 +671,23 @@ def test_geglu_epilogue_emits_the_bytes_its_consumer_multiplies(dev, delayed, ne
     assert outs[0][1] == 1 and outs[1][1] == 2  # fused: only x is quantised by a launch of its own
     if need_grad:
         assert torch.equal(outs[0][2], outs[1][2])
+
+
+@pytest.mark.parametrize("geo", [(2, 4, 200, 200, 40), (1, 8, 130, 77, 64), (2, 2, 64, 64, 160)])
+def test_fused_attention_emits_the_bytes_of_its_own_output(dev, geo):
+    """comat_flash_attn_fwd_q: same O and lse as comat_flash_attn_fwd, q8 = comat_fp8_quantize_scaled(O) bit for bit, abs-max tracked"""
+    k = ops.kernels()
+    B, H, Nq, Nk, d = geo
+    T = torch.bfloat16
+    HD = H * d
+    q, kk, v = (rnd(B * n_, HD, seed=s_).to(T).to(dev) for n_, s_ in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    o0, lse0 = torch.empty_like(q), torch.empty(B, H, Nq, device=dev)
+    k.flash_attn_fwd(q, kk, v, o0, lse0, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5)
+    o, lse = torch.empty_like(q), torch.empty(B, H, Nq, device=dev)
+    q8 = torch.empty((B * Nq, HD), dtype=torch.uint8, device=dev)
+    scale = (OF.scale_of(o0.cpu()) * 0.7).reshape(1).to(dev)
+    amax = torch.zeros(1, dtype=torch.int32, device=dev)
+    k.flash_attn_fwd(q, kk, v, o, lse, B, H, Nq, Nk, d, HD, HD, HD, HD, d ** -0.5, q8=(q8, scale, amax))
+    assert torch.equal(o.cpu(), o0.cpu()) and torch.equal(lse.cpu(), lse0.cpu())
+    assert torch.equal(q8.cpu(), OF.quantize_with_scale(o0.cpu(), scale.cpu()[0]))
+    assert float(amax.cpu().view(torch.float32)) == float(o0.float().abs().max())
