@@ -331,20 +331,9 @@ def test_fp8_forward_touches_only_the_tagged_layers(sim):
     k.fp8_quantize = orig
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_fp8_step_against_oracle_emulation(dev, dtype):
-    """BASELINE config C5 in miniature, at STEP level: SDXL-layout generator with the fp8 forward (bf16 / fp32 backward on
-    the saved unquantised activations), attribute concentration on the two-resolution geometry C5 uses (mid at the lowest
-    map resolution, up at both: `mid_32, up_32, up_64` at 1024^2 -> `mid_2, up_2, up_4` here), SD1.5-layout
-    discriminator, one whole optimisation step against the oracle step with its fp8 emulation (oracle/sd.py fp8_forward:
-    value of the quantised product, gradient of the unquantised one).
-    Tolerance (stated): quantisers in series decorrelate two fp32 implementations (see
-    test_unet_fp8_forward_against_oracle_emulation), so the yardstick is the emulation's own distance to the EXACT step:
-    every loss term within 1.5x that distance (+5e-3 of its scale: on a single scalar the emulation's own distance can
-    be accidentally tiny - measured on MI355X: reward -4.6824 vs -4.6666 where emulation and exact differ by 0.0019), LoRA gradients within 1.5x the emulation-vs-exact
-    gradient distance.  bf16 storage compounds its own rounding with the quantisers' (measured on MI355X: token loss 0.323
-    vs 0.255, gradients 0.77 vs 0.55 relative): + 0.1 of the scale on loss terms, + the bf16 step bound on gradients - the
-    fp32-storage case is the tight one."""
+def _fp8_step_world(dev, dtype):
+    """BASELINE config C5 in miniature: SDXL-layout generator with the fp8 forward, SD1.5-layout discriminator, attribute concentration on
+    the two-resolution geometry C5 uses -> (trainer, bank, batch, cfg, oracle_world(fp8) -> dict)"""
     from comat_amd.blip import Blip
     from comat_amd.gan import D_sd
     from comat_amd.pipeline import TrainableSDXLPipeline
@@ -385,15 +374,34 @@ def test_fp8_step_against_oracle_emulation(dev, dtype):
                     lora={k_: v.clone().requires_grad_(True) for k_, v in lsd.items()},
                     d_lora={k_: v.clone().requires_grad_(True) for k_, v in dl.items()},
                     head_w=head_w.clone().requires_grad_(True), head_b=head_b.clone().requires_grad_(True))
-    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
-    ref8 = OS.train_step(oracle_world(True), batch, cfg, ts, crop, acs)
-    ref = OS.train_step(oracle_world(False), batch, cfg, ts, crop, acs)
     bank = LoRABank(ucfg, lsd, dtype, dev)
     unet = UNet(ucfg, usd, dtype, dev, bank, fp8_forward=True)
     pipe = TrainableSDXLPipeline(unet, VAEDecoder(vcfg, vsd, dtype, dev))
     dbank = LoRABank(config.TINY_UNET, dl, dtype, dev)
     disc = D_sd(UNet(config.TINY_UNET, dsd, dtype, dev, dbank), dbank, head_w, head_b)
     trainer = CoMatTrainer(pipe, bank, Blip(config.TINY_BLIP, bsd, dtype, dev), disc, cfg, seed=0)
+    return trainer, bank, batch, cfg, oracle_world
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fp8_step_against_oracle_emulation(dev, dtype):
+    """BASELINE config C5 in miniature, at STEP level: SDXL-layout generator with the fp8 forward (bf16 / fp32 backward on
+    the saved unquantised activations), attribute concentration on the two-resolution geometry C5 uses (mid at the lowest
+    map resolution, up at both: `mid_32, up_32, up_64` at 1024^2 -> `mid_2, up_2, up_4` here), SD1.5-layout
+    discriminator, one whole optimisation step against the oracle step with its fp8 emulation (oracle/sd.py fp8_forward:
+    value of the quantised product, gradient of the unquantised one).
+    Tolerance (stated): quantisers in series decorrelate two fp32 implementations (see
+    test_unet_fp8_forward_against_oracle_emulation), so the yardstick is the emulation's own distance to the EXACT step:
+    every loss term within 1.5x that distance (+5e-3 of its scale: on a single scalar the emulation's own distance can
+    be accidentally tiny - measured on MI355X: reward -4.6824 vs -4.6666 where emulation and exact differ by 0.0019), LoRA gradients within 1.5x the emulation-vs-exact
+    gradient distance.  bf16 storage compounds its own rounding with the quantisers' (measured on MI355X: token loss 0.323
+    vs 0.255, gradients 0.77 vs 0.55 relative): + 0.1 of the scale on loss terms, + the bf16 step bound on gradients - the
+    fp32-storage case is the tight one."""
+    from oracle import step as OS
+    trainer, bank, batch, cfg, oracle_world = _fp8_step_world(dev, dtype)
+    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
+    ref8 = OS.train_step(oracle_world(True), batch, cfg, ts, crop, acs)
+    ref = OS.train_step(oracle_world(False), batch, cfg, ts, crop, acs)
     n_q = []
     k = ops.kernels()
     kq = k.fp8_quantize
@@ -691,3 +699,40 @@ def test_fused_attention_emits_the_bytes_of_its_own_output(dev, geo):
     assert torch.equal(o.cpu(), o0.cpu()) and torch.equal(lse.cpu(), lse0.cpu())
     assert torch.equal(q8.cpu(), OF.quantize_with_scale(o0.cpu(), scale.cpu()[0]))
     assert float(amax.cpu().view(torch.float32)) == float(o0.float().abs().max())
+
+
+def test_fp8_step_with_delayed_scaling(dev, delayed):
+    """C5 in miniature under DELAYED scaling: calibration on the batch (one eager no-grad sampler pass: every site's abs-max over all
+    denoise steps), then two optimisation steps - the first under the calibrated scales, the second under the abs-maxima the first one
+    recorded.  No just-in-time quantisation after the calibration; the step stays as close to the exact (unquantised) oracle step as
+    the just-in-time form is (both are the same network under fp8 noise: the yardstick is the jit step's own distance to the exact one)."""
+    from oracle import step as OS
+    dtype = torch.float32
+    ts, crop, acs = [1, 2], (1, 0, 63, 63), [2]
+    trainer, bank, batch, cfg, oracle_world = _fp8_step_world(dev, dtype)
+    ref = OS.train_step(oracle_world(False), batch, cfg, ts, crop, acs)
+    cat = lambda d_: torch.cat([d_[n].reshape(-1) for n in bank.names])
+    gx = cat(ref["g_grads"])
+    k = ops.kernels()
+    n_jit = [0]
+    kq = k.fp8_quantize
+    k.fp8_quantize = lambda t, **kw: (n_jit.__setitem__(0, n_jit[0] + 1), kq(t, **kw))[1]
+    try:
+        assert trainer.fp8_calibrate(batch)
+        n_cal = n_jit[0]
+        logs1 = trainer.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+        g1 = bank.flat_grad.detach().clone()
+        logs2 = trainer.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    finally:
+        k.fp8_quantize = kq
+    assert n_cal > 40 and n_jit[0] == n_cal  # calibration quantises just in time; the steps never do
+    d_del = rel_l2(g1, gx)
+    # the jit form of the same step, for the yardstick (a second world: the first one's LoRA factors have been updated)
+    ops.set_fp8_scaling("jit")
+    trainer_j, bank_j, _, _, _ = _fp8_step_world(dev, dtype)
+    trainer_j.train_step(batch, training_steps=ts, crop=crop, attrcon_steps=acs)
+    d_jit = rel_l2(bank_j.flat_grad, gx)
+    print(f"fp8 step, delayed scaling: LoRA gradient vs exact step {d_del:.3e} (just-in-time scales: {d_jit:.3e}); "
+          f"step 1 loss {float(logs1['step_loss']):.4f}, step 2 loss {float(logs2['step_loss']):.4f}")
+    assert torch.isfinite(bank.flat_grad).all() and all(torch.isfinite(torch.as_tensor(float(logs2[k_]))) for k_ in ("step_loss", "Blip", "G_loss", "D_loss"))
+    assert d_del < 2.0 * d_jit + 0.05
